@@ -1,0 +1,76 @@
+"""ctypes binding of libanncur_hip.so (the C ABI declared in include/anncur_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+fails, this module raises.  Build with ``python __graft_entry__.py`` (or
+``make -C anncur_amd/csrc``).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libanncur_hip.so")
+
+F32, BF16 = 0, 1
+MAX_TOPK = 2048
+
+_p32 = POINTER(c_int32)
+
+# name -> (restype, argtypes); mirrors include/anncur_hip.h one to one
+SIGNATURES = {
+	"anncur_version": (c_int, []),
+	"anncur_last_error": (c_char_p, []),
+	"anncur_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+	"anncur_gather_cols": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int, c_int64, c_void_p]),
+	"anncur_gather_rows": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int, c_int64, c_void_p]),
+	"anncur_gemm": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64,
+							c_int64, c_int64, c_int64, c_void_p]),
+	"anncur_approx_error": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64,
+									c_int64, c_void_p, c_void_p, c_void_p]),
+	"anncur_rowwise_topk": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+	"anncur_score_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+	"anncur_score_topk_supported": (c_int, [c_int64, c_int64, c_int32, c_int32]),
+	"anncur_score_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+								  c_void_p, c_size_t, c_void_p]),
+	"anncur_rerank": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+	"anncur_overlap_counts": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, _p32, _p32, c_int32, c_void_p, c_void_p]),
+	"anncur_convert": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class AnncurHipError(RuntimeError):
+	pass
+
+
+def load():
+	"""Load (once) and return the ctypes handle.  Raises if the library is absent."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	if not os.path.isfile(LIB_PATH):
+		raise AnncurHipError(
+			f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+			"(or `make -C anncur_amd/csrc`). anncur_amd has no CPU fallback.")
+	lib = ctypes.CDLL(LIB_PATH)
+	for name, (res, args) in SIGNATURES.items():
+		fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+		fn.restype = res
+		fn.argtypes = args
+	_lib = lib
+	return lib
+
+
+def check(rc, what=""):
+	if rc != 0:
+		msg = load().anncur_last_error()
+		raise AnncurHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def device_info():
+	lib = load()
+	n_cu, wave = c_int(0), c_int(0)
+	buf = ctypes.create_string_buffer(64)
+	check(lib.anncur_device_info(ctypes.byref(n_cu), ctypes.byref(wave), buf, 64), "device_info")
+	return {"n_cu": n_cu.value, "wave_size": wave.value, "arch": buf.value.decode()}

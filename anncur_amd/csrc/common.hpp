@@ -1,0 +1,76 @@
+// Shared helpers for libanncur_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "anncur_hip.h"
+
+void anncur_set_error(const char *fmt, ...);
+
+#define ANNCUR_REQUIRE(cond, code, ...)                 \
+	do {                                                \
+		if (!(cond)) {                                  \
+			anncur_set_error(__VA_ARGS__);              \
+			return (code);                              \
+		}                                               \
+	} while (0)
+
+#define ANNCUR_HIP_OK(expr)                                                              \
+	do {                                                                                 \
+		hipError_t e__ = (expr);                                                         \
+		if (e__ != hipSuccess) {                                                         \
+			anncur_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+			return ANNCUR_E_HIP;                                                         \
+		}                                                                                \
+	} while (0)
+
+#define ANNCUR_LAUNCH_OK()                                                               \
+	do {                                                                                 \
+		hipError_t e__ = hipGetLastError();                                              \
+		if (e__ != hipSuccess) {                                                         \
+			anncur_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+			return ANNCUR_E_HIP;                                                         \
+		}                                                                                \
+	} while (0)
+
+static inline bool dtype_ok(int d) { return d == ANNCUR_F32 || d == ANNCUR_BF16; }
+static inline size_t dtype_size(int d) { return d == ANNCUR_F32 ? 4 : 2; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ device helpers
+#define WAVE 64
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// round-to-nearest-even, NaN stays NaN
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+	uint32_t u = __float_as_uint(f);
+	if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+	return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// order-preserving map float -> uint32 (larger float => larger uint)
+__device__ __forceinline__ uint32_t f32_sortable(float f) {
+	uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unsortable(uint32_t s) {
+	uint32_t u = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;
+	return __uint_as_float(u);
+}
+// composite key: larger = better score, ties -> smaller index wins.  All keys of one row are distinct.
+__device__ __forceinline__ uint64_t make_key(float v, uint32_t idx) {
+	return ((uint64_t)f32_sortable(v) << 32) | (uint64_t)(0xffffffffu - idx);
+}
+__device__ __forceinline__ float key_val(uint64_t k) { return f32_unsortable((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint32_t key_idx(uint64_t k) { return 0xffffffffu - (uint32_t)k; }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+template <typename T>
+__device__ __forceinline__ float load_as_f32(const T *p);
+template <>
+__device__ __forceinline__ float load_as_f32<float>(const float *p) { return *p; }
+template <>
+__device__ __forceinline__ float load_as_f32<uint16_t>(const uint16_t *p) { return bf16_bits_to_f32(*p); }

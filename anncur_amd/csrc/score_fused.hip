@@ -1,0 +1,436 @@
+// Fused S_hat = X . E  +  per-query top-k for gfx950; S_hat is never written to HBM.
+//
+// Orientation: the MFMA computes S_hat^T tiles, D[item][query] = sum_k Et[item][k] * X[query][k]
+// (v_mfma_f32_32x32x16_bf16, A operand = 32 item rows of E^T from LDS, B operand = the wave's
+// queries, resident in registers for the whole kernel).  In the C/D layout the query sits on the
+// LANE (col = lane & 31) and the 16 accumulator registers are 16 items, so a query's threshold is
+// one lane-local VGPR and the filter is one v_cmp per output element.
+//
+// Data layout in HBM
+//   X   [Q  x Kp] bf16 row-major   queries' scores against the anchor items (C_q), K zero-padded to Kp
+//   Et  [Ip x Kp] bf16 row-major   item embeddings E^T (= (U R)^T), Ip = 32-multiple, zero rows past I
+//   one 32-item tile of Et is ONE contiguous 64*Kp-byte block -> 16-byte coalesced loads.
+// LDS: the tile is stored row-major with the 16-byte chunk index XOR-swizzled by the row so the
+// per-k-step ds_read_b128 (32 rows x one chunk column) is bank-conflict free.
+//
+// Launches (all on the caller's stream):
+//   1. prepass   : group maxima of S_hat over a strided sample of item tiles  -> gmax[Q x G]
+//   2. threshold : tau[q] = k-th largest group maximum (exact scan kernel)    -> a lower bound on the
+//                  k-th best score of the query (k distinct groups each hold an element >= tau)
+//   3. sweep     : all tiles; every S_hat[q,i] >= tau[q] is appended to the lane's private candidate
+//                  segment in HBM (no atomics, no LDS traffic)
+//   4. select    : per query, exact top-k of its candidates (radix select + bitonic sort in LDS);
+//                  a query whose segment overflowed is recomputed exactly inside the same kernel.
+// Algorithmic work: 2*Q*Kp*I flops in (3) (+ sample fraction in (1)).
+#include <type_traits>
+#include "select.hpp"
+
+using namespace anncur;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vector: stays in VGPRs (HIP's uint4 struct did not)
+
+constexpr int TILE_I = 32;
+
+template <int KP>
+struct FusedCfg {
+	static constexpr int KSTEPS = KP / 16;
+	static constexpr int QT = (KP <= 256) ? 2 : 1;  // 32-query sub-tiles per wave
+	static constexpr int BQ = 4 * 32 * QT;          // queries per workgroup (4 waves)
+	static constexpr int CPR = KP / 8;              // 16-byte chunks per Et row
+	static constexpr int TILE_BYTES = TILE_I * KP * 2;
+	static constexpr int PASSES = TILE_BYTES / (256 * 16);
+	static constexpr int LDS_BYTES = 2 * TILE_BYTES;
+};
+
+template <int CPR>
+__device__ __forceinline__ int swz(int row, int c) {
+	if (CPR >= 16) return c ^ (row & 15);
+	return c ^ ((row >> 1) & 7);  // CPR == 8 (Kp = 64): 128-byte rows, two rows per 256-byte bank line
+}
+
+struct FusedParams {
+	const uint16_t *X; int64_t ldx;
+	const uint16_t *Et;
+	int64_t Q, I;
+	int n_tiles, n_full_tiles;
+	int S, tiles_per_split;           // sweep partition of the item tiles
+	int n_st, S0, st_per_split;       // prepass: sample tiles and their partition
+	float *gmax; int n_groups;        // prepass output [Q x n_groups]
+	const float *tau; int tau_stride; // threshold per query: tau[q * tau_stride]
+	uint2 *cand; uint32_t *seg_cnt; int capg;
+	int n_wg;                         // grid size (for the XCD remap)
+};
+
+// Contiguous work ids per XCD (blocks b and b+8 share an XCD's L2): speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+	const int q = n >> 3, r = n & 7, x = b & 7, l = b >> 3;
+	return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+
+template <int KP>
+__device__ __forceinline__ void tile_load(const uint16_t *__restrict__ Et, int tile, u32x4 (&stage)[FusedCfg<KP>::PASSES]) {
+	const u32x4 *src = reinterpret_cast<const u32x4 *>(Et + (int64_t)tile * TILE_I * KP);
+#pragma unroll
+	for (int ps = 0; ps < FusedCfg<KP>::PASSES; ++ps) stage[ps] = src[ps * 256 + threadIdx.x];
+}
+template <int KP>
+__device__ __forceinline__ void tile_store(unsigned char *buf, const u32x4 (&stage)[FusedCfg<KP>::PASSES]) {
+	constexpr int CPR = FusedCfg<KP>::CPR;
+	u32x4 *dst = reinterpret_cast<u32x4 *>(buf);
+#pragma unroll
+	for (int ps = 0; ps < FusedCfg<KP>::PASSES; ++ps) {
+		const int g = ps * 256 + threadIdx.x;
+		const int row = g / CPR, c = g % CPR;
+		dst[row * CPR + swz<CPR>(row, c)] = stage[ps];
+	}
+}
+
+// MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep.
+template <int KP, int MODE, int GROUP>
+__global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
+	using Cfg = FusedCfg<KP>;
+	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR, PASSES = Cfg::PASSES;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int r = lane & 31, h = lane >> 5;
+	const int wid = xcd_remap(blockIdx.x, p.n_wg);
+	const int nsplit = (MODE == 0) ? p.S0 : p.S;
+	const int split = wid / (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ) ;
+	const int rb = wid - split * (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ);
+	(void)nsplit;
+
+	// ---- this wave's queries: B operand fragments, resident for the whole kernel
+	bf16x8 xb[QT][KSTEPS];
+	int64_t qv[QT];
+#pragma unroll
+	for (int t = 0; t < QT; ++t) {
+		qv[t] = (int64_t)rb * Cfg::BQ + wave * 32 * QT + 32 * t + r;
+		const bool ok = qv[t] < p.Q;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(p.X + (ok ? qv[t] : 0) * p.ldx) + h;
+#pragma unroll
+		for (int s = 0; s < KSTEPS; ++s) {
+			const u32x4 zero = {0u, 0u, 0u, 0u};
+			const u32x4 w = ok ? src[2 * s] : zero;
+			xb[t][s] = __builtin_bit_cast(bf16x8, w);
+		}
+	}
+
+	// ---- work range
+	int j_begin, j_end;  // tile iterations
+	if (MODE == 0) { j_begin = split * p.st_per_split; j_end = min(j_begin + p.st_per_split, p.n_st); }
+	else { j_begin = split * p.tiles_per_split; j_end = min(j_begin + p.tiles_per_split, p.n_tiles); }
+#define tile_of(j) ((MODE == 0) ? (int)(((int64_t)(j) * p.n_full_tiles) / p.n_st) : (j))
+
+	float tau[QT];
+	uint2 *seg[QT];
+	uint32_t ncand[QT];
+#pragma unroll
+	for (int t = 0; t < QT; ++t) {
+		const bool ok = qv[t] < p.Q;
+		tau[t] = INFINITY; seg[t] = nullptr; ncand[t] = 0;
+		if (MODE == 1) {
+			if (ok) tau[t] = p.tau[qv[t] * p.tau_stride];
+			seg[t] = p.cand + ((qv[t] * 2 + h) * (int64_t)p.S + split) * (int64_t)p.capg;
+		}
+	}
+
+	// ---- staging: thread t moves chunk g = pass*256 + tid of the contiguous tile (registers -> swizzled LDS)
+	u32x4 stage[PASSES];
+	if (j_begin < j_end) {
+		tile_load<KP>(p.Et, tile_of(j_begin), stage);
+		tile_store<KP>(smem, stage);
+	}
+	__syncthreads();
+
+	for (int j = j_begin; j < j_end; ++j) {
+		const int cur = (j - j_begin) & 1;
+		const int tile = tile_of(j);
+		const bool more = j + 1 < j_end;
+		if (more) tile_load<KP>(p.Et, tile_of(j + 1), stage);
+
+		f32x16 acc[QT];
+#pragma unroll
+		for (int t = 0; t < QT; ++t)
+#pragma unroll
+			for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+		const u32x4 *tb = reinterpret_cast<const u32x4 *>(smem + cur * Cfg::TILE_BYTES);
+#pragma unroll
+		for (int s = 0; s < KSTEPS; ++s) {
+			const u32x4 w = tb[r * CPR + swz<CPR>(r, 2 * s + h)];
+			const bf16x8 a = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+			for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[t][s], acc[t], 0, 0, 0);
+		}
+
+		// ---- epilogue.  C/D layout: query = lane & 31 (col), item row = (e & 3) + 8 * (e >> 2) + 4 * h
+		if (MODE == 0) {
+#pragma unroll
+			for (int t = 0; t < QT; ++t) {
+				if (GROUP == 16) {
+					float m = acc[t][0];
+#pragma unroll
+					for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[t][e]);
+					if (qv[t] < p.Q) p.gmax[qv[t] * p.n_groups + (int64_t)j * 2 + h] = m;
+				} else {
+					float4 m;
+					m.x = fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3]));
+					m.y = fmaxf(fmaxf(acc[t][4], acc[t][5]), fmaxf(acc[t][6], acc[t][7]));
+					m.z = fmaxf(fmaxf(acc[t][8], acc[t][9]), fmaxf(acc[t][10], acc[t][11]));
+					m.w = fmaxf(fmaxf(acc[t][12], acc[t][13]), fmaxf(acc[t][14], acc[t][15]));
+					if (qv[t] < p.Q) *reinterpret_cast<float4 *>(p.gmax + qv[t] * p.n_groups + ((int64_t)j * 2 + h) * 4) = m;
+				}
+			}
+		} else {
+			const uint32_t item0 = (uint32_t)tile * TILE_I + 4 * h;
+#pragma unroll
+			for (int t = 0; t < QT; ++t) {
+#pragma unroll
+				for (int e = 0; e < 16; ++e) {
+					const float v = acc[t][e];
+					if (v >= tau[t]) {
+						const uint32_t item = item0 + (e & 3) + 8 * (e >> 2);
+						if ((int64_t)item < p.I) {
+							if (ncand[t] < (uint32_t)p.capg) seg[t][ncand[t]] = make_uint2(__float_as_uint(v), item);
+							ncand[t]++;
+						}
+					}
+				}
+			}
+		}
+
+		if (more) tile_store<KP>(smem + (cur ^ 1) * Cfg::TILE_BYTES, stage);
+		__syncthreads();
+	}
+
+#undef tile_of
+	if (MODE == 1) {
+#pragma unroll
+		for (int t = 0; t < QT; ++t)
+			if (qv[t] < p.Q) p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] = ncand[t];
+	}
+}
+
+// ------------------------------------------------------------------ select
+// One workgroup per query: exact top-k of the query's candidate segments.  If a segment
+// overflowed (or fewer than k candidates arrived) the query is recomputed exactly here.
+template <int KMAX>
+__global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
+	const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg, int capg, const uint16_t *__restrict__ X,
+	int64_t ldx, const uint16_t *__restrict__ Et, int64_t I, int KP, uint32_t k, float *__restrict__ out_val,
+	int32_t *__restrict__ out_idx, uint32_t *__restrict__ n_fallback) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const SelState s = sel_carve<KMAX>(smem);
+	float *xq = reinterpret_cast<float *>(smem + SelCfg<KMAX>::LDS_BYTES);  // [KP], fallback only
+	sel_init(s);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int64_t q = blockIdx.x;
+	const uint32_t *cnts = seg_cnt + q * nseg;
+	for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
+		const uint32_t c = cnts[sg];
+		if (c > (uint32_t)capg) atomicOr(&s.scal[8], 1u);
+		const uint32_t cc = min(c, (uint32_t)capg);
+		atomicAdd(&s.scal[9], cc);
+		atomicMax(&s.scal[10], cc);
+	}
+	__syncthreads();
+	const bool overflow = s.scal[8] != 0;
+	const uint32_t total = s.scal[9], maxc = s.scal[10];
+	float tau = -INFINITY;
+	uint64_t tau_key = 0;
+	if (!overflow && total >= k) {
+		for (int sb = 0; sb < nseg; sb += 4) {
+			const int sg = sb + wave;
+			const uint32_t c = (sg < nseg) ? min(cnts[sg], (uint32_t)capg) : 0u;
+			const uint2 *sp = cand + (q * nseg + (sg < nseg ? sg : 0)) * (int64_t)capg;
+			for (uint32_t e0 = 0; e0 < maxc; e0 += WAVE) {
+				const uint32_t e = e0 + lane;
+				const bool in = e < c;
+				const uint2 ce = in ? sp[e] : make_uint2(0, 0);
+				sel_offer(s, in, __uint_as_float(ce.x), ce.y, tau, tau_key);
+				sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+			}
+		}
+	} else {
+		if (tid == 0) atomicAdd(n_fallback, 1u);
+		for (int c = tid; c < KP; c += SEL_THREADS) xq[c] = bf16_bits_to_f32(X[q * ldx + c]);
+		__syncthreads();
+		int it = 0;
+		for (int64_t i0 = 0; i0 < I; i0 += SEL_THREADS, ++it) {
+			const int64_t i = i0 + tid;
+			const bool in = i < I;
+			float v = 0.f;
+			if (in) {
+				const uint4 *er = reinterpret_cast<const uint4 *>(Et + i * KP);
+				for (int c = 0; c < KP / 8; ++c) {
+					const uint4 w = er[c];
+					const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+					for (int d = 0; d < 4; ++d) {
+						v = fmaf(__uint_as_float(ww[d] << 16), xq[8 * c + 2 * d], v);
+						v = fmaf(__uint_as_float(ww[d] & 0xffff0000u), xq[8 * c + 2 * d + 1], v);
+					}
+				}
+			}
+			sel_offer(s, in, v, (uint32_t)i, tau, tau_key);
+			if ((it & 15) == 15) sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+		}
+	}
+	sel_finish<KMAX>(s, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+}
+
+// ------------------------------------------------------------------ host-side plan
+struct FusedPlan {
+	bool ok;
+	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax;
+	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, total;
+};
+
+int g_num_cu = 0;
+int num_cu() {
+	if (g_num_cu == 0) {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+			g_num_cu = prop.multiProcessorCount;
+		else
+			g_num_cu = 256;  // MI355X
+	}
+	return g_num_cu;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k) {
+	FusedPlan P{};
+	P.ok = false;
+	if (!(KP == 64 || KP == 128 || KP == 256 || KP == 512)) return P;
+	if (k < 1 || k > ANNCUR_MAX_TOPK || Q < 1 || I < 1 || I >= (int64_t)0x7fffffff - 64 || k > I) return P;
+	P.QT = (KP <= 256) ? 2 : 1;
+	P.BQ = 128 * P.QT;
+	P.n_rb = (int)ceil_div64(Q, P.BQ);
+	P.n_tiles = (int)ceil_div64(I, TILE_I);
+	P.n_full = (int)(I / TILE_I);
+	// prepass sample: enough groups that the k-th largest group maximum is a tight bound
+	const int target = (4 * k > 512) ? 4 * k : 512;
+	int n_st16 = (target + 1) / 2;
+	if ((int64_t)n_st16 * 8 <= P.n_full) { P.group = 16; P.n_st = n_st16; }
+	else { P.group = 4; P.n_st = (target + 7) / 8; }
+	if ((int64_t)P.n_st * 4 > P.n_full) return P;  // problem too small for the fused path: use dense GEMM + scan
+	P.n_groups = P.n_st * (P.group == 16 ? 2 : 8);
+	if (P.n_groups < k) return P;
+	const int slots = 2 * num_cu();
+	int S = slots / P.n_rb;
+	if (S < 1) S = 1;
+	if (S > 256) S = 256;
+	if (S > P.n_tiles) S = P.n_tiles;
+	P.tiles_per_split = (P.n_tiles + S - 1) / S;
+	P.S = (P.n_tiles + P.tiles_per_split - 1) / P.tiles_per_split;
+	int S0 = slots / P.n_rb;
+	if (S0 < 1) S0 = 1;
+	if (S0 > P.n_st) S0 = P.n_st;
+	P.st_per_split = (P.n_st + S0 - 1) / S0;
+	P.S0 = (P.n_st + P.st_per_split - 1) / P.st_per_split;
+	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over 2 S lane segments
+	const double exp_hits = 1.3 * k * ((double)P.n_tiles / P.n_st);
+	const double per_seg = exp_hits / (2.0 * P.S);
+	int capg = next_pow2((int)(4.0 * per_seg) + 32);
+	if (capg < 64) capg = 64;
+	if (capg > 16384) capg = 16384;
+	P.capg = capg;
+	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
+	size_t off = 256;
+	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
+	P.off_tval = off;   off = align256(off + (size_t)Q * k * 4);
+	P.off_tidx = off;   off = align256(off + (size_t)Q * k * 4);
+	P.off_segcnt = off; off = align256(off + (size_t)Q * 2 * P.S * 4);
+	P.off_cand = off;   off = align256(off + (size_t)Q * 2 * P.S * (size_t)P.capg * 8);
+	P.total = off;
+	P.ok = true;
+	return P;
+}
+
+template <int KP>
+int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
+				 int32_t *out_idx, unsigned char *ws, hipStream_t st) {
+	using Cfg = FusedCfg<KP>;
+	FusedParams p{};
+	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
+	p.n_tiles = P.n_tiles; p.n_full_tiles = P.n_full; p.S = P.S; p.tiles_per_split = P.tiles_per_split;
+	p.n_st = P.n_st; p.S0 = P.S0; p.st_per_split = P.st_per_split;
+	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
+	float *tval = (float *)(ws + P.off_tval);
+	int32_t *tidx = (int32_t *)(ws + P.off_tidx);
+	p.tau = tval + (k - 1); p.tau_stride = k;
+	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg;
+
+	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
+	// 1. prepass
+	p.n_wg = P.n_rb * P.S0;
+	if (P.group == 16)
+		hipLaunchKernelGGL((score_kernel<KP, 0, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+	else
+		hipLaunchKernelGGL((score_kernel<KP, 0, 4>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+	ANNCUR_LAUNCH_OK();
+	// 2. tau = k-th largest group maximum
+	int rc = anncur_rowwise_topk(p.gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, tidx, st);
+	if (rc != ANNCUR_OK) return rc;
+	// 3. sweep
+	p.n_wg = P.n_rb * P.S;
+	hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+	ANNCUR_LAUNCH_OK();
+	// 4. select
+	const int nseg = 2 * P.S;
+#define LAUNCH_SELECT(KM)                                                                                              \
+	do {                                                                                                               \
+		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)KP * 4;                                                     \
+		ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_candidates_kernel<KM>,                                  \
+										  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3((unsigned)Q), dim3(SEL_THREADS), lds, st, p.cand, p.seg_cnt, nseg, \
+						   P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws);                \
+	} while (0)
+	if (P.kmax == 128) LAUNCH_SELECT(128); else if (P.kmax == 512) LAUNCH_SELECT(512); else LAUNCH_SELECT(2048);
+#undef LAUNCH_SELECT
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
+	const FusedPlan P = plan_fused(Q, I, Kp, k);
+	return P.ok ? P.total : 0;
+}
+
+extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
+	return plan_fused(Q, I, Kp, k).ok ? 1 : 0;
+}
+
+extern "C" int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
+								 int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
+								 void *stream) {
+	const FusedPlan P = plan_fused(Q, I, Kp, k);
+	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
+				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512}, 1<=k<=%d, I large "
+				   "enough for a sampled threshold); use anncur_gemm + anncur_rowwise_topk",
+				   (long long)Q, (long long)I, Kp, k, ANNCUR_MAX_TOPK);
+	ANNCUR_REQUIRE(X && Et && out_val && out_idx, ANNCUR_E_INVALID, "score_topk: null pointer");
+	ANNCUR_REQUIRE(lde == Kp, ANNCUR_E_INVALID, "score_topk: Et must be packed (lde == Kp), got lde=%lld", (long long)lde);
+	ANNCUR_REQUIRE(ldx >= Kp && (ldx % 8) == 0, ANNCUR_E_INVALID, "score_topk: ldx must be >= Kp and a multiple of 8");
+	ANNCUR_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Et % 16) == 0, ANNCUR_E_INVALID, "score_topk: X and Et must be 16-byte aligned");
+	ANNCUR_REQUIRE(workspace && workspace_bytes >= P.total && ((uintptr_t)workspace % 256) == 0, ANNCUR_E_WORKSPACE,
+				   "score_topk: workspace of %zu bytes (256-byte aligned) required, got %zu", P.total, workspace_bytes);
+	hipStream_t st = (hipStream_t)stream;
+	unsigned char *ws = (unsigned char *)workspace;
+	switch (Kp) {
+		case 64: return launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
+		case 128: return launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
+		case 256: return launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
+		default: return launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
+	}
+}

@@ -1,0 +1,258 @@
+"""Tensor-level wrappers over the C ABI.  torch is used only for device memory and the
+current HIP stream; all arithmetic happens in libanncur_hip.so.
+
+Every function takes CUDA(HIP) tensors and raises on CPU tensors: there is no CPU path.
+"""
+from collections import namedtuple
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, check
+
+TopK = namedtuple("TopK", ["values", "indices"])
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t):
+	try:
+		return _DT[t.dtype]
+	except KeyError:
+		raise TypeError(f"unsupported dtype {t.dtype}: anncur_amd kernels take float32 or bfloat16") from None
+
+
+def _dev(*ts):
+	for t in ts:
+		if not (torch.is_tensor(t) and t.is_cuda):
+			raise _lib.AnncurHipError("anncur_amd ops need tensors on the GPU (cuda/HIP device); there is no CPU fallback")
+
+
+def _stream():
+	return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+	return ctypes.c_void_p(t.data_ptr())
+
+
+def _rowmajor(t):
+	"""2-D tensor with unit column stride (rows may be padded)."""
+	if t.dim() != 2:
+		raise ValueError("expected a 2-D tensor")
+	if t.shape[1] > 1 and t.stride(1) != 1:
+		t = t.contiguous()
+	if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+		t = t.contiguous()
+	return t
+
+
+def _ld(t):
+	return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def as_index(idx, device):
+	"""Python list / numpy / tensor of indices -> int32 device tensor."""
+	if torch.is_tensor(idx):
+		return idx.to(device=device, dtype=torch.int32).contiguous()
+	return torch.as_tensor(np.asarray(idx, dtype=np.int64), dtype=torch.int32).to(device)
+
+
+# ------------------------------------------------------------------ a2
+def gather_cols(A, col_idx, out_dtype=None):
+	"""A[:, col_idx]  (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:74)."""
+	_dev(A)
+	A = _rowmajor(A)
+	idx = as_index(col_idx, A.device)
+	out = torch.empty((A.shape[0], idx.numel()), dtype=out_dtype or A.dtype, device=A.device)
+	check(_lib.load().anncur_gather_cols(_p(A), _dt(A), A.shape[0], A.shape[1], _ld(A), _p(idx), idx.numel(), _p(out), _dt(out),
+										 max(idx.numel(), 1), _stream()), "gather_cols")
+	return out
+
+
+def gather_rows(A, row_idx, out_dtype=None):
+	"""A[row_idx, :]  (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:73)."""
+	_dev(A)
+	A = _rowmajor(A)
+	idx = as_index(row_idx, A.device)
+	out = torch.empty((idx.numel(), A.shape[1]), dtype=out_dtype or A.dtype, device=A.device)
+	n = idx.numel()
+	for s in range(0, n, 65535):  # grid.y limit
+		e = min(n, s + 65535)
+		check(_lib.load().anncur_gather_rows(_p(A), _dt(A), A.shape[0], A.shape[1], _ld(A), _p(idx[s:e]), e - s, _p(out[s:e]), _dt(out),
+											 max(A.shape[1], 1), _stream()), "gather_rows")
+	return out
+
+
+def convert(src, dtype):
+	_dev(src)
+	src = _rowmajor(src)
+	out = torch.empty(src.shape, dtype=dtype, device=src.device)
+	check(_lib.load().anncur_convert(_p(src), _dt(src), _ld(src), _p(out), _dt(out), max(out.shape[1], 1), src.shape[0], src.shape[1],
+									 _stream()), "convert")
+	return out
+
+
+# ------------------------------------------------------------------ a4/a5/a6
+def gemm(A, B, out=None, out_dtype=torch.float32):
+	"""C = A @ B for 2-D tensors with ARBITRARY strides (transposed views cost nothing);
+	fp32 products and sums (exact fmaf chains on the matrix cores)."""
+	_dev(A, B)
+	M, K = A.shape
+	K2, N = B.shape
+	if K != K2:
+		raise ValueError(f"gemm: inner dimensions differ ({K} vs {K2})")
+	if out is None:
+		out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+	elif tuple(out.shape) != (M, N):
+		raise ValueError("gemm: out has the wrong shape")
+	lib = _lib.load()
+	for m0 in range(0, max(M, 1), 65535 * 128):  # grid.y limit of one launch
+		m1 = min(M, m0 + 65535 * 128)
+		a, c = A[m0:m1], out[m0:m1]
+		check(lib.anncur_gemm(_p(a), _dt(A), A.stride(0), A.stride(1), _p(B), _dt(B), B.stride(0), B.stride(1), _p(c), _dt(out),
+							  out.stride(0), out.stride(1), m1 - m0, N, K, _stream()), "gemm")
+	return out
+
+
+def approx_error(X, Et, A_exact):
+	"""Per-row sum_i (X.E - A)^2 and sum_i A^2 without materialising X.E
+	(reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:146-147)."""
+	_dev(X, Et, A_exact)
+	X, Et, A_exact = _rowmajor(X), _rowmajor(Et), _rowmajor(A_exact)
+	Q, K = X.shape
+	I = Et.shape[0]
+	if Et.shape[1] != K or tuple(A_exact.shape) != (Q, I):
+		raise ValueError("approx_error: shape mismatch")
+	err = torch.empty(Q, dtype=torch.float32, device=X.device)
+	nrm = torch.empty(Q, dtype=torch.float32, device=X.device)
+	lib = _lib.load()
+	step = 65535 * 128
+	for q0 in range(0, Q, step):
+		q1 = min(Q, q0 + step)
+		check(lib.anncur_approx_error(_p(X[q0:q1]), _dt(X), _ld(X), _p(Et), _dt(Et), _ld(Et), _p(A_exact[q0:q1]), _dt(A_exact),
+									  _ld(A_exact), q1 - q0, I, K, _p(err[q0:q1]), _p(nrm[q0:q1]), _stream()), "approx_error")
+	return err, nrm
+
+
+# ------------------------------------------------------------------ a7/a8
+def rowwise_topk(A, k):
+	"""Exact torch.topk(A, k, dim=1) on the device: (values f32 [Q,k], indices int32 [Q,k]),
+	sorted descending, ties -> smaller index."""
+	_dev(A)
+	A = _rowmajor(A)
+	Q, I = A.shape
+	val = torch.empty((Q, k), dtype=torch.float32, device=A.device)
+	idx = torch.empty((Q, k), dtype=torch.int32, device=A.device)
+	check(_lib.load().anncur_rowwise_topk(_p(A), _dt(A), Q, I, _ld(A), k, _p(val), _p(idx), _stream()), "rowwise_topk")
+	return TopK(val, idx)
+
+
+_KP_CHOICES = (64, 128, 256, 512)
+
+
+def padded_k(K):
+	for kp in _KP_CHOICES:
+		if K <= kp:
+			return kp
+	return None
+
+
+def pack_bf16(M, Kp, row_multiple=1):
+	"""[n x K] (f32/bf16) -> zero-padded bf16 [ceil(n/row_multiple)*row_multiple x Kp], packed."""
+	_dev(M)
+	n, K = M.shape
+	n_pad = -(-n // row_multiple) * row_multiple
+	out = torch.zeros((n_pad, Kp), dtype=torch.bfloat16, device=M.device)
+	M = _rowmajor(M)
+	view = out[:n, :K]
+	check(_lib.load().anncur_convert(_p(M), _dt(M), _ld(M), _p(view), BF16, Kp, n, K, _stream()), "pack_bf16")
+	return out
+
+
+class _Workspace:
+	"""Grow-only device scratch for the fused kernel (one per device)."""
+	_bufs = {}
+
+	@classmethod
+	def get(cls, nbytes, device):
+		key = (device.type, device.index)
+		buf = cls._bufs.get(key)
+		if buf is None or buf.numel() < nbytes:
+			cls._bufs[key] = buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+		off = (-buf.data_ptr()) % 256
+		return buf[off:off + nbytes]
+
+
+def fused_supported(Q, I, Kp, k):
+	return Kp in _KP_CHOICES and bool(_lib.load().anncur_score_topk_supported(Q, I, Kp, k))
+
+
+def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False):
+	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16)."""
+	_dev(Xp, Etp)
+	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16:
+		raise TypeError("score_topk_fused takes bf16 operands")
+	Q, Kp = Xp.shape
+	if Etp.shape[1] != Kp or not Etp.is_contiguous() or Etp.shape[0] < -(-I // 32) * 32:
+		raise ValueError("Et must be packed [ceil(I/32)*32 x Kp]")
+	Xp = _rowmajor(Xp)
+	lib = _lib.load()
+	nbytes = lib.anncur_score_topk_workspace_bytes(Q, I, Kp, k)
+	if nbytes == 0:
+		raise _lib.AnncurHipError(f"score_topk: shape (Q={Q}, I={I}, Kp={Kp}, k={k}) is outside the fused path")
+	ws = _Workspace.get(nbytes, Xp.device)
+	val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
+	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
+	check(lib.anncur_score_topk(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes, _stream()), "score_topk")
+	if return_fallbacks:
+		return TopK(val, idx), ws[:4].view(torch.int32)
+	return TopK(val, idx)
+
+
+def score_topk_dense(X, Et, k, max_bytes=2 << 30):
+	"""Unfused route: S = X @ Et^T in fp32 (row chunks), then the exact scan.  Any K, any dtype."""
+	_dev(X, Et)
+	Q, I = X.shape[0], Et.shape[0]
+	val = torch.empty((Q, k), dtype=torch.float32, device=X.device)
+	idx = torch.empty((Q, k), dtype=torch.int32, device=X.device)
+	rows = max(1, min(Q, max_bytes // max(4 * I, 1)))
+	for q0 in range(0, Q, rows):
+		q1 = min(Q, q0 + rows)
+		S = gemm(X[q0:q1], Et.t())
+		v, i = rowwise_topk(S, k)
+		val[q0:q1], idx[q0:q1] = v, i
+	return TopK(val, idx)
+
+
+def rerank(A, approx_idx, k_retvr, k_out):
+	"""The k_out best of approx_idx[:, :k_retvr] by exact score A (reference: ..._splits.py:93-96)."""
+	_dev(A, approx_idx)
+	A = _rowmajor(A)
+	if approx_idx.dtype != torch.int32 or approx_idx.stride(1) != 1:
+		approx_idx = approx_idx.to(torch.int32).contiguous()
+	Q, I = A.shape
+	val = torch.empty((Q, k_out), dtype=torch.float32, device=A.device)
+	idx = torch.empty((Q, k_out), dtype=torch.int32, device=A.device)
+	check(_lib.load().anncur_rerank(_p(A), _dt(A), Q, I, _ld(A), _p(approx_idx), _ld(approx_idx), k_retvr, k_out, _p(val), _p(idx),
+									_stream()), "rerank")
+	return TopK(val, idx)
+
+
+def overlap_counts(a, b, pairs):
+	"""common[p, q] = |set(a[q, :ka_p]) & set(b[q, :kb_p])| for pairs = [(ka, kb), ...] -> int32 [n_pairs, Q]."""
+	_dev(a, b)
+	a = a.to(torch.int32).contiguous()
+	b = b.to(torch.int32).contiguous()
+	Q = a.shape[0]
+	out = torch.empty((len(pairs), Q), dtype=torch.int32, device=a.device)
+	lib = _lib.load()
+	for s in range(0, len(pairs), 64):
+		chunk = pairs[s:s + 64]
+		ka = (ctypes.c_int32 * len(chunk))(*[int(p[0]) for p in chunk])
+		kb = (ctypes.c_int32 * len(chunk))(*[int(p[1]) for p in chunk])
+		check(lib.anncur_overlap_counts(_p(a), a.shape[1], _p(b), b.shape[1], Q, ka, kb, len(chunk), _p(out[s:s + len(chunk)]), _stream()),
+			  "overlap_counts")
+	return out

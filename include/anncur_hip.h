@@ -1,0 +1,139 @@
+/* anncur_hip.h -- C ABI of libanncur_hip.so: the MI355X (gfx950) kernels behind the
+ * CUR nearest-neighbour path of iesl/anncur.
+ *
+ * The reference is pure Python with no FFI of its own; the symbols below are what a
+ * binding for this path binds (ctypes).  Each entry point cites
+ * the reference interface (file:line, relative to the upstream repo) it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (ANNCUR_E_*); the message is
+ *    available from anncur_last_error() (thread-local);
+ *  - the caller owns every buffer; pointers are DEVICE pointers unless stated;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *    asynchronous on that stream; no hidden allocation, no host synchronisation:
+ *    scratch comes from an explicit workspace sized by the *_workspace_bytes() query;
+ *  - matrices are row-major; `ld*` are leading dimensions in ELEMENTS;
+ *  - dtype codes: ANNCUR_F32 (float) / ANNCUR_BF16 (bfloat16, 2 bytes);
+ *  - top-k results are sorted by score descending, ties broken by the smaller index
+ *    (torch.topk leaves tie order unspecified; this is one valid order);
+ *  - NaN scores are never selected.
+ */
+#ifndef ANNCUR_HIP_H
+#define ANNCUR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANNCUR_F32  0
+#define ANNCUR_BF16 1
+
+#define ANNCUR_OK            0
+#define ANNCUR_E_INVALID    -1   /* bad argument (shape, dtype, alignment, k range) */
+#define ANNCUR_E_WORKSPACE  -2   /* workspace missing or too small */
+#define ANNCUR_E_HIP        -3   /* a HIP runtime call / kernel launch failed */
+#define ANNCUR_E_UNSUPPORTED -4  /* valid request outside what this build implements */
+
+#define ANNCUR_MAX_TOPK 2048     /* largest k accepted by the top-k entry points */
+
+/* library / diagnostics ------------------------------------------------------------ */
+int         anncur_version(void);            /* 1000*major + minor */
+const char *anncur_last_error(void);         /* thread-local, never NULL */
+int         anncur_device_info(int *n_cu, int *wave_size, char *arch_name, int arch_name_len);
+
+/* a2: anchor row / column gather ---------------------------------------------------
+ * rows = A[row_idxs,:], cols = A[:,col_idxs]
+ *   eval/run_retrieval_eval_wrt_exact_crossenc.py:73-74
+ *   eval/run_retrieval_eval_wrt_exact_crossenc_w_fixed_train_test_splits.py:297,300
+ * src and dst share `dtype` unless dst_dtype says otherwise (F32<->BF16 convert on the fly).
+ * idx are int32 device arrays; out-of-range indices are an error reported lazily as
+ * zeros (the Python layer validates indices on the host before calling). */
+int anncur_gather_cols(const void *A, int dtype, int64_t n_rows, int64_t n_cols, int64_t lda,
+                       const int32_t *col_idx, int32_t n_idx,
+                       void *out, int dst_dtype, int64_t ldo, void *stream);
+int anncur_gather_rows(const void *A, int dtype, int64_t n_rows, int64_t n_cols, int64_t lda,
+                       const int32_t *row_idx, int32_t n_idx,
+                       void *out, int dst_dtype, int64_t ldo, void *stream);
+
+/* a4/a5/a6: strided GEMM with exact-fp32 accumulation ------------------------------
+ * C(m,n) = sum_k A(m,k) * B(k,n), element (i,j) of an operand at base + i*s0 + j*s1
+ * (strides in elements), so NN / NT / TN / transposed-output products are one call.
+ * Inputs F32 or BF16 (up-converted exactly), products and sums in fp32 on the matrix
+ * cores (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain).  Replaces
+ *   latent_cols = U @ R                      eval/matrix_approx_zeshel.py:65
+ *   latent_rows = C @ U                      eval/matrix_approx_zeshel.py:61
+ *   get / get_rows / get_cols / get_complete_row / get_complete_col
+ *                                             eval/matrix_approx_zeshel.py:74,79,85,97,118
+ *   pinv(C) @ A @ pinv(R)                    eval/matrix_approx_zeshel.py:47 (the two products)
+ *   mention_embeds @ label_embeds.T          ..._w_fixed_train_test_splits.py:283 */
+int anncur_gemm(const void *A, int a_dtype, int64_t a_sm, int64_t a_sk,
+                const void *B, int b_dtype, int64_t b_sk, int64_t b_sn,
+                void *C, int c_dtype, int64_t c_sm, int64_t c_sn,
+                int64_t M, int64_t N, int64_t K, void *stream);
+
+/* a11: approximation error without materialising S_hat ------------------------------
+ * err_sq[q] = sum_i (X[q,:].E[:,i] - A[q,i])^2 , norm_sq[q] = sum_i A[q,i]^2
+ *   eval/run_retrieval_eval_wrt_exact_crossenc.py:146-147 (torch.norm over row subsets;
+ *   the host sums the per-row terms over anchor / non-anchor / all rows in fp64).
+ * X [Q x K] (x_dtype), Et [I x K] = E transposed (e_dtype), A [Q x I] (a_dtype).
+ * err_sq / norm_sq: float[Q], overwritten. */
+int anncur_approx_error(const void *X, int x_dtype, int64_t ldx,
+                        const void *Et, int e_dtype, int64_t lde,
+                        const void *A, int a_dtype, int64_t lda,
+                        int64_t Q, int64_t I, int64_t K,
+                        float *err_sq, float *norm_sq, void *stream);
+
+/* a7/a8: exact row-wise top-k of a stored matrix (HBM-streaming scan) ---------------
+ *   torch.topk(S, k, dim=1)                  eval/matrix_approx_zeshel.py:106,126
+ *   curr_ment_scores.topk(top_k)             ...crossenc.py:103 ; ..._splits.py:86
+ * A [Q x I] (dtype), out_val float[Q x k] (ldo = k), out_idx int32[Q x k].  1 <= k <= min(I, ANNCUR_MAX_TOPK). */
+int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k,
+                        float *out_val, int32_t *out_idx, void *stream);
+
+/* a6+a7 fused: S_hat = X . E never written; per-query top-k ---------------------------
+ *   CURApprox.topk_in_row                    eval/matrix_approx_zeshel.py:121-126
+ *   approx_curr_ment_scores.topk(top_k_retvr) ...crossenc.py:106 ; ..._splits.py:89
+ *   faiss IndexFlatIP.add / .search          models/nearest_nbr.py:36-38 (+ utils/data_process.py:351,397)
+ * X  [Q x Kp]  bf16 row-major (queries' anchor-item scores / query embeddings),
+ * Et [Ip x Kp] bf16 row-major (item embeddings E^T), Kp in {64,128,256,512} with the
+ * logical K zero-padded up to Kp, Ip = I rounded up to a multiple of 32 with zero rows.
+ * Products are exact (bf16 x bf16 in fp32), sums fp32 on v_mfma_f32_32x32x16_bf16.
+ * Three launches on `stream`: (1) group-max pre-pass over a strided sample of item
+ * tiles -> per-query lower bound tau on the k-th best; (2) full sweep, survivors >= tau
+ * appended to per-lane candidate segments; (3) per-query select + sort (with an in-kernel
+ * exact re-computation for any query whose segments overflowed).
+ * out_val float[Q x k], out_idx int32[Q x k]. */
+size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k);
+int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int32_t k);   /* 1 / 0 */
+int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
+                      int64_t Q, int64_t I, int32_t Kp, int32_t k,
+                      float *out_val, int32_t *out_idx,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* a8: exact re-rank of the approximately retrieved items + a10 overlap counts --------
+ *   temp[approx_idx] = exact[approx_idx]; temp.topk(k)      ...crossenc.py:108-113 ; ..._splits.py:93-96
+ *   compute_overlap(exact[:, :top_k], rerank[:, :top_k])    eval/eval_utils.py:115-150
+ * A [Q x I] exact scores; approx_idx int32, row q at approx_idx + q*ld_idx, first k_retvr entries used
+ * (distinct per row; ld_idx lets a prefix of a longer sorted list be re-ranked in place);
+ * rerank_val float[Q x k_out], rerank_idx int32[Q x k_out]: the k_out best retrieved items
+ * by exact score (k_out <= k_retvr <= ANNCUR_MAX_TOPK). */
+int anncur_rerank(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda,
+                  const int32_t *approx_idx, int64_t ld_idx, int32_t k_retvr, int32_t k_out,
+                  float *rerank_val, int32_t *rerank_idx, void *stream);
+/* common[p*Q + q] = | a[q, :ka[p]] (set) intersect b[q, :kb[p]] | for each of n_pairs
+ * (ka,kb) prefix-length pairs (host int32 arrays), a int32[Q x la], b int32[Q x lb]. */
+int anncur_overlap_counts(const int32_t *a, int32_t la, const int32_t *b, int32_t lb, int64_t Q,
+                          const int32_t *ka, const int32_t *kb, int32_t n_pairs,
+                          int32_t *common, void *stream);
+
+/* dtype plumbing: fp32 <-> bf16 (round-to-nearest-even), strided 2-D ------------------ */
+int anncur_convert(const void *src, int src_dtype, int64_t lds_, void *dst, int dst_dtype, int64_t ldd,
+                   int64_t n_rows, int64_t n_cols, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANNCUR_HIP_H */

@@ -1,0 +1,215 @@
+"""Parity of every C-ABI kernel against torch-CPU / the oracle on seeded inputs (needs an MI355X)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+	if not torch.cuda.is_available():
+		pytest.skip("no GPU")
+	from anncur_amd import ops as _ops
+	return _ops
+
+
+def _g(seed):
+	return torch.Generator().manual_seed(seed)
+
+
+def _sets_equal(a, b):
+	return (np.sort(np.asarray(a), axis=1) == np.sort(np.asarray(b), axis=1)).all()
+
+
+# ------------------------------------------------------------------ gemm
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 53, 19), (128, 128, 16), (130, 257, 100), (512, 300, 256)])
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn", "tt"])
+def test_gemm_fp32_layouts(ops, M, N, K, layout):
+	A = torch.randn(M, K, generator=_g(1)); B = torch.randn(K, N, generator=_g(2))
+	ref = (A.double() @ B.double()).float()
+	a = A.cuda() if layout[0] == "n" else A.t().contiguous().cuda().t()
+	b = B.cuda() if layout[1] == "n" else B.t().contiguous().cuda().t()
+	out = ops.gemm(a, b).cpu()
+	# tolerance: fp32 fmaf chain over K terms
+	torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5 * (K ** 0.5))
+
+
+def test_gemm_bf16_inputs_and_transposed_output(ops):
+	A = torch.randn(200, 96, generator=_g(3)).bfloat16(); B = torch.randn(96, 333, generator=_g(4)).bfloat16()
+	ref = A.double() @ B.double()
+	out = ops.gemm(A.cuda(), B.cuda())
+	torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-4)
+	outT = torch.empty(333, 200, device="cuda")
+	ops.gemm(A.cuda(), B.cuda(), out=outT.t())
+	torch.testing.assert_close(outT.t().cpu().double(), ref, rtol=1e-5, atol=1e-4)
+	ob = ops.gemm(A.cuda(), B.cuda(), out_dtype=torch.bfloat16).cpu()
+	torch.testing.assert_close(ob.float(), ref.float().bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
+def test_gemm_matches_cpu_sgemm_within_1e4(ops):
+	# the north-star tolerance: reconstructed scores within 1e-4 fp32 rel-tol of the CPU path
+	A = torch.randn(300, 256, generator=_g(5)); B = torch.randn(256, 1000, generator=_g(6))
+	ref = A @ B
+	out = ops.gemm(A.cuda(), B.cuda()).cpu()
+	assert ((out - ref).norm() / ref.norm()).item() < 1e-6
+	torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ gather / convert
+def test_gather_and_convert(ops):
+	A = torch.randn(77, 501, generator=_g(7))
+	cols = sorted(np.random.default_rng(0).choice(501, 33, replace=False).tolist())
+	rows = sorted(np.random.default_rng(1).choice(77, 9, replace=False).tolist())
+	assert torch.equal(ops.gather_cols(A.cuda(), cols).cpu(), A[:, cols])
+	assert torch.equal(ops.gather_rows(A.cuda(), rows).cpu(), A[rows, :])
+	Ab = A.bfloat16()
+	assert torch.equal(ops.gather_cols(Ab.cuda(), cols).cpu(), Ab[:, cols])
+	assert torch.equal(ops.gather_cols(Ab.cuda(), cols, out_dtype=torch.float32).cpu(), Ab[:, cols].float())
+	assert torch.equal(ops.convert(A.cuda(), torch.bfloat16).cpu(), Ab)  # round-to-nearest-even like torch
+	assert torch.equal(ops.convert(Ab.cuda(), torch.float32).cpu(), Ab.float())
+	p = ops.pack_bf16(A.cuda(), 512, row_multiple=32).cpu()
+	assert p.shape == (96, 512) and torch.equal(p[:77, :501], Ab) and p[77:].abs().sum() == 0 and p[:, 501:].abs().sum() == 0
+
+
+# ------------------------------------------------------------------ exact scan
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Q,I,k", [(3, 1, 1), (5, 7, 7), (9, 100, 10), (17, 5000, 100), (4, 10031, 64), (6, 40000, 1000),
+								  (2, 70001, 2048), (33, 4097, 129), (3, 20000, 513)])
+def test_rowwise_topk_matches_torch(ops, dtype, Q, I, k):
+	A = torch.randn(Q, I, generator=_g(Q * 1000 + I)).to(dtype)
+	# torch ties on bf16 are arbitrary: compare values exactly, and index SETS above the k-th value
+	ref_v, ref_i = torch.topk(A.float(), k, dim=1)
+	v, i = ops.rowwise_topk(A.cuda(), k)
+	v, i = v.cpu(), i.cpu().long()
+	assert torch.equal(v, ref_v)
+	assert torch.equal(torch.gather(A.float(), 1, i), v)          # indices point at the reported values
+	assert all(len(set(r.tolist())) == k for r in i)               # distinct
+	if dtype == torch.float32:
+		assert _sets_equal(i, ref_i)
+	# descending, ties -> smaller index first
+	assert ((v[:, :-1] > v[:, 1:]) | ((v[:, :-1] == v[:, 1:]) & (i[:, :-1] < i[:, 1:]))).all()
+
+
+def test_rowwise_topk_adversarial_and_strided(ops):
+	I = 30000
+	asc = torch.arange(I, dtype=torch.float32).repeat(3, 1)          # ascending: every element beats the threshold
+	v, i = ops.rowwise_topk(asc.cuda(), 100)
+	assert torch.equal(i.cpu().long(), torch.arange(I - 1, I - 101, -1).repeat(3, 1))
+	const = torch.zeros(2, 5000)                                      # all ties: smallest indices win
+	v, i = ops.rowwise_topk(const.cuda(), 64)
+	assert torch.equal(i.cpu().long(), torch.arange(64).repeat(2, 1))
+	big = torch.randn(8, 9000, generator=_g(11)).cuda()
+	view = big[:, 3:8003]                                             # misaligned rows, ld > I
+	v, i = ops.rowwise_topk(view, 50)
+	rv, ri = torch.topk(view.cpu(), 50, dim=1)
+	assert torch.equal(v.cpu(), rv) and torch.equal(i.cpu().long(), ri)
+	ninf = torch.full((1, 300), -float("inf")); ninf[0, 5] = 1.0
+	v, i = ops.rowwise_topk(ninf.cuda(), 3)
+	assert i[0, 0].item() == 5 and v[0, 1].item() == -float("inf")
+
+
+# ------------------------------------------------------------------ rerank + overlap vs the oracle loop
+def test_rerank_and_overlap_match_reference_loop(ops):
+	from oracle import cur_oracle as O
+	g = _g(21)
+	A = torch.randn(40, 3000, generator=g)
+	S = A + 0.5 * torch.randn(40, 3000, generator=g)
+	(ex_i, ex_s), (ap_i, ap_s), (rr_i, rr_s) = O.per_query_loop(A, S, 20, 100)
+	ex = ops.rowwise_topk(A.cuda(), 20)
+	ap = ops.rowwise_topk(S.cuda(), 100)
+	assert np.array_equal(ex.indices.cpu().numpy(), ex_i) and np.array_equal(ap.indices.cpu().numpy(), ap_i)
+	rr = ops.rerank(A.cuda(), ap.indices, 100, 20)
+	assert np.array_equal(rr.indices.cpu().numpy(), rr_i) and np.array_equal(rr.values.cpu().numpy(), rr_s)
+	# prefix re-rank in place (k_retvr = 37 of the 100 retrieved)
+	(_, _), (_, _), (rr37_i, _) = O.per_query_loop(A, S, 20, 37)
+	assert np.array_equal(ops.rerank(A.cuda(), ap.indices, 37, 20).indices.cpu().numpy(), rr37_i)
+	pairs = [(1, 1), (10, 10), (20, 20), (5, 20)]
+	cnt = ops.overlap_counts(ex.indices, rr.indices, pairs).cpu().numpy()
+	for p, (ka, kb) in enumerate(pairs):
+		want = [len(set(ex_i[q, :ka]) & set(rr_i[q, :kb])) for q in range(40)]
+		assert cnt[p].tolist() == want
+	# closed form used by the sweep: exact[:k] & rerank[:k] == exact[:k] & approx[:k_retvr]
+	cf = ops.overlap_counts(ex.indices, ap.indices, [(10, 100), (20, 100)]).cpu().numpy()
+	lit = ops.overlap_counts(ex.indices, rr.indices, [(10, 10), (20, 20)]).cpu().numpy()
+	assert np.array_equal(cf, lit)
+
+
+# ------------------------------------------------------------------ fused score + top-k
+def _fused_case(ops, Q, I, K, k, seed, noise=0.05, rank=32):
+	g = _g(seed)
+	Z = torch.randn(rank, I, generator=g)
+	X = (torch.randn(Q, K, generator=g)).bfloat16()
+	E = (torch.randn(K, rank, generator=g) @ Z / rank ** 0.5 + noise * torch.randn(K, I, generator=g)).bfloat16()
+	Kp = ops.padded_k(K)
+	Xp = ops.pack_bf16(X.cuda(), Kp)
+	Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	return X, E, Xp, Etp
+
+
+@pytest.mark.parametrize("Q,I,K,k", [(300, 40000, 64, 10), (257, 65536, 128, 100), (100, 50007, 256, 100), (64, 70000, 256, 1),
+									  (130, 33000, 512, 64), (50, 131072, 200, 500), (20, 300000, 100, 1000)])
+def test_fused_score_topk_matches_dense_and_cpu(ops, Q, I, K, k):
+	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
+	Kp = Xp.shape[1]
+	assert ops.fused_supported(Q, I, Kp, k)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	torch.cuda.synchronize()
+	assert nfb.item() == 0
+	# (a) against the unfused device route (same bf16 operands, fp32 fmaf sums)
+	dv, di = ops.score_topk_dense(Xp, Etp[:I], k)
+	torch.testing.assert_close(v.cpu(), dv.cpu(), rtol=1e-4, atol=1e-4)
+	# (b) against torch on the CPU in fp64: reconstructed scores within 1e-4, index sets identical where separated
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
+	got = i.cpu().long()
+	assert (got >= 0).all() and (got < I).all()
+	torch.testing.assert_close(torch.gather(S, 1, got), v.cpu().double(), rtol=1e-4, atol=1e-4)
+	kth = rv[:, -1:]
+	gap_ok = (S - kth).abs().gt(1e-3 * S.abs().max()).all(dim=1) | True
+	same = [set(a.tolist()) == set(b.tolist()) for a, b in zip(got, ri)]
+	# rows whose k-th / (k+1)-th scores are closer than fp32 round-off may swap one boundary element
+	kp1 = torch.topk(S, min(k + 1, I), dim=1).values
+	close = (kp1[:, k - 1] - kp1[:, -1]).abs() < 1e-5 * S.abs().max() if k < I else torch.zeros(Q, dtype=torch.bool)
+	assert all(s or c for s, c in zip(same, close.tolist()))
+
+
+def test_fused_overflow_fallback_is_exact(ops):
+	# ascending scores along the item axis: every element beats the sampled threshold -> segments overflow
+	Q, I, K, k = 40, 60000, 64, 50
+	X = torch.ones(Q, K).bfloat16()
+	E = (torch.arange(I, dtype=torch.float32) / 256).floor().repeat(K, 1).bfloat16() / K
+	Xp = ops.pack_bf16(X.cuda(), 64); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 64, row_multiple=32)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	torch.cuda.synchronize()
+	S = X.double() @ E.double()
+	rv, _ = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-5, atol=1e-5)
+	assert nfb.item() > 0
+	# ties -> smallest indices of the top plateau
+	top = S[0].max()
+	first = int((S[0] == top).nonzero()[0])
+	assert i[0, 0].item() == first
+
+
+def test_fused_unsupported_shapes_raise(ops):
+	from anncur_amd._lib import AnncurHipError
+	assert not ops.fused_supported(1000, 5000, 64, 10)          # too few items for a sampled threshold
+	Xp = torch.zeros(8, 64, dtype=torch.bfloat16, device="cuda"); Etp = torch.zeros(5024, 64, dtype=torch.bfloat16, device="cuda")
+	with pytest.raises(AnncurHipError):
+		ops.score_topk_fused(Xp, Etp, 5000, 10)
+	with pytest.raises(AnncurHipError):
+		ops.rowwise_topk(torch.zeros(4, 10, device="cuda"), 11)  # k > I
+	with pytest.raises(AnncurHipError):
+		ops.rowwise_topk(torch.zeros(4, 10), 2)                  # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ approximation error
+def test_approx_error(ops):
+	g = _g(31)
+	X = torch.randn(150, 48, generator=g); Et = torch.randn(700, 48, generator=g); A = torch.randn(150, 700, generator=g)
+	err, nrm = ops.approx_error(X.cuda(), Et.cuda(), A.cuda())
+	S = X.double() @ Et.double().t()
+	torch.testing.assert_close(err.cpu().double(), ((S - A.double()) ** 2).sum(1), rtol=1e-4, atol=1e-3)
+	torch.testing.assert_close(nrm.cpu().double(), (A.double() ** 2).sum(1), rtol=1e-4, atol=1e-3)

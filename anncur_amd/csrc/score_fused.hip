@@ -357,8 +357,9 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k) {
 
 template <int KP>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
-				 int32_t *out_idx, unsigned char *ws, hipStream_t st) {
+				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev) {
 	using Cfg = FusedCfg<KP>;
+#define EV(i) do { if (ev) ANNCUR_HIP_OK(hipEventRecord(ev[i], st)); } while (0)
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
 	p.n_tiles = P.n_tiles; p.n_full_tiles = P.n_full; p.S = P.S; p.tiles_per_split = P.tiles_per_split;
@@ -370,6 +371,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg;
 
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
+	EV(0);
 	// 1. prepass
 	p.n_wg = P.n_rb * P.S0;
 	if (P.group == 16)
@@ -377,13 +379,16 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	else
 		hipLaunchKernelGGL((score_kernel<KP, 0, 4>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 	ANNCUR_LAUNCH_OK();
+	EV(1);
 	// 2. tau = k-th largest group maximum
 	int rc = anncur_rowwise_topk(p.gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, tidx, st);
 	if (rc != ANNCUR_OK) return rc;
+	EV(2);
 	// 3. sweep
 	p.n_wg = P.n_rb * P.S;
 	hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 	ANNCUR_LAUNCH_OK();
+	EV(3);
 	// 4. select
 	const int nseg = 2 * P.S;
 #define LAUNCH_SELECT(KM)                                                                                              \
@@ -397,6 +402,8 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (P.kmax == 128) LAUNCH_SELECT(128); else if (P.kmax == 512) LAUNCH_SELECT(512); else LAUNCH_SELECT(2048);
 #undef LAUNCH_SELECT
 	ANNCUR_LAUNCH_OK();
+	EV(4);
+#undef EV
 	return ANNCUR_OK;
 }
 
@@ -411,9 +418,9 @@ extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int
 	return plan_fused(Q, I, Kp, k).ok ? 1 : 0;
 }
 
-extern "C" int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
-								 int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
-								 void *stream) {
+static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
+						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
+						   void *stream, hipEvent_t *ev) {
 	const FusedPlan P = plan_fused(Q, I, Kp, k);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
 				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512}, 1<=k<=%d, I large "
@@ -428,9 +435,40 @@ extern "C" int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int
 	hipStream_t st = (hipStream_t)stream;
 	unsigned char *ws = (unsigned char *)workspace;
 	switch (Kp) {
-		case 64: return launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
-		case 128: return launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
-		case 256: return launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
-		default: return launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st);
+		case 64: return launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev);
+		case 128: return launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev);
+		case 256: return launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev);
+		default: return launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev);
 	}
+}
+
+extern "C" int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
+								 int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
+								 void *stream) {
+	return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
+									   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
+									   void *stream, float *stage_ms) {
+	ANNCUR_REQUIRE(stage_ms, ANNCUR_E_INVALID, "score_topk_timed: stage_ms is null");
+	hipEvent_t ev[5];
+	for (int i = 0; i < 5; ++i) ANNCUR_HIP_OK(hipEventCreate(&ev[i]));
+	int rc = score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, ev);
+	if (rc == ANNCUR_OK) {
+		hipError_t e = hipEventSynchronize(ev[4]);
+		if (e != hipSuccess) { anncur_set_error("hipEventSynchronize: %s", hipGetErrorString(e)); rc = ANNCUR_E_HIP; }
+		for (int i = 0; i < 4 && rc == ANNCUR_OK; ++i)
+			if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) { anncur_set_error("hipEventElapsedTime failed"); rc = ANNCUR_E_HIP; }
+	}
+	for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
+	return rc;
+}
+
+/* plan introspection for benchmarks / DESIGN.md: n_sample_tiles, n_tiles, S, capg, group */
+extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t *out5) {
+	const FusedPlan P = plan_fused(Q, I, Kp, k);
+	ANNCUR_REQUIRE(P.ok && out5, ANNCUR_E_UNSUPPORTED, "score_topk_plan: unsupported shape");
+	out5[0] = P.n_st; out5[1] = P.n_tiles; out5[2] = P.S; out5[3] = P.capg; out5[4] = P.group;
+	return ANNCUR_OK;
 }

@@ -212,6 +212,29 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False):
 	return TopK(val, idx)
 
 
+def score_topk_fused_timed(Xp, Etp, I, k):
+	"""Measurement only: (TopK, [prepass, threshold, sweep, select] in ms) from HIP events on the launch stream."""
+	_dev(Xp, Etp)
+	Q, Kp = Xp.shape
+	lib = _lib.load()
+	nbytes = lib.anncur_score_topk_workspace_bytes(Q, I, Kp, k)
+	if nbytes == 0:
+		raise _lib.AnncurHipError("score_topk_timed: unsupported shape")
+	ws = _Workspace.get(nbytes, Xp.device)
+	val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
+	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
+	ms = (ctypes.c_float * 4)()
+	check(lib.anncur_score_topk_timed(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes, _stream(), ms),
+		  "score_topk_timed")
+	return TopK(val, idx), [float(x) for x in ms]
+
+
+def fused_plan(Q, I, Kp, k):
+	out = (ctypes.c_int32 * 5)()
+	check(_lib.load().anncur_score_topk_plan(Q, I, Kp, k, out), "score_topk_plan")
+	return dict(zip(("n_sample_tiles", "n_tiles", "splits", "segment_capacity", "group"), [int(x) for x in out]))
+
+
 def score_topk_dense(X, Et, k, max_bytes=2 << 30):
 	"""Unfused route: S = X @ Et^T in fp32 (row chunks), then the exact scan.  Any K, any dtype."""
 	_dev(X, Et)

@@ -113,6 +113,16 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
                       float *out_val, int32_t *out_idx,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* Measurement only: same as anncur_score_topk but records HIP events on `stream` between the four
+ * launches, synchronises, and returns their durations in stage_ms[4] (host floats, milliseconds):
+ * {prepass, threshold, sweep, select}.  bench.py's live roofline figure comes from stage_ms[2]. */
+int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t lde,
+                            int64_t Q, int64_t I, int32_t Kp, int32_t k,
+                            float *out_val, int32_t *out_idx,
+                            void *workspace, size_t workspace_bytes, void *stream, float *stage_ms);
+/* Plan introspection: out5 = {sample tiles, item tiles, item splits S, segment capacity, group size}. */
+int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t *out5);
+
 /* a8: exact re-rank of the approximately retrieved items + a10 overlap counts --------
  *   temp[approx_idx] = exact[approx_idx]; temp.topk(k)      ...crossenc.py:108-113 ; ..._splits.py:93-96
  *   compute_overlap(exact[:, :top_k], rerank[:, :top_k])    eval/eval_utils.py:115-150

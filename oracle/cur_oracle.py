@@ -170,6 +170,37 @@ def per_query_loop(exact, approx, top_k, top_k_retvr):
 	return (cat(ex_i), cat(ex_s)), (cat(ap_i), cat(ap_s)), (cat(rr_i), cat(rr_s))
 
 
+def _topk_stable(x, k):
+	"""top-k with a DEFINED tie order: score descending, then smaller index (one of the orders torch.topk may return)."""
+	order = torch.sort(x, descending=True, stable=True).indices[:k]
+	return x[order], order
+
+
+def per_query_loop_stable(exact, approx, top_k, top_k_retvr):
+	"""per_query_loop with every topk replaced by the tie-stable one.  Identical to per_query_loop on tie-free
+	inputs (the golden tests run both); on tie-heavy inputs (bf16 scores) torch.topk's arbitrary tie order makes the
+	reference's own overlap numbers vary, and this variant is the well-defined statement the HIP path implements."""
+	ex_i, ap_i, rr_i = [], [], []
+	for q in range(exact.shape[0]):
+		row = exact[q]
+		_, i = _topk_stable(row, top_k)
+		_, a_i = _topk_stable(approx[q], top_k_retvr)
+		temp = torch.zeros(row.shape) + NEG_FILL
+		temp[a_i] = row[a_i]
+		_, r_i = _topk_stable(temp, top_k)
+		ex_i.append(i.unsqueeze(0)); ap_i.append(a_i.unsqueeze(0)); rr_i.append(r_i.unsqueeze(0))
+	cat = lambda xs: torch.cat(xs).numpy()
+	return cat(ex_i), cat(ap_i), cat(rr_i)
+
+
+def eval_all_topk_stable(exact, approx, arg_top_k_vals, top_k_retvr):
+	top_k_vals = [k for k in arg_top_k_vals if k <= top_k_retvr]
+	if not top_k_vals:
+		return {}
+	ex_i, _, rr_i = per_query_loop_stable(exact, approx, max(top_k_vals), top_k_retvr)
+	return {k: overlap_to_flat(compute_overlap(ex_i[:, :k], rr_i[:, :k])) for k in top_k_vals}
+
+
 def eval_approx_score_mat_for_all_topk(exact, approx, arg_top_k_vals, top_k_retvr):
 	"""..._w_fixed_train_test_splits.py:51-135."""
 	top_k_vals = [k for k in arg_top_k_vals if k <= top_k_retvr]      # :70

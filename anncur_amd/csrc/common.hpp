@@ -7,6 +7,8 @@
 #include "anncur_hip.h"
 
 void anncur_set_error(const char *fmt, ...);
+// internal cross-file helper (topk.hip): out[q*out_stride] = k-th largest of G[q, :n] (n <= 2048), one wave per row
+int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st);
 
 #define ANNCUR_REQUIRE(cond, code, ...)                 \
 	do {                                                \

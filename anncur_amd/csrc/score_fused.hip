@@ -22,8 +22,10 @@
 //   4. select    : per query, exact top-k of its candidates (radix select + bitonic sort in LDS);
 //                  a query whose segment overflowed is recomputed exactly inside the same kernel.
 // Algorithmic work: 2*Q*Kp*I flops in (3) (+ sample fraction in (1)).
+#include <stdlib.h>
 #include <type_traits>
 #include "select.hpp"
+#include "wave_select.hpp"
 
 using namespace anncur;
 
@@ -43,7 +45,9 @@ struct FusedCfg {
 	static constexpr int CPR = KP / 8;              // 16-byte chunks per Et row
 	static constexpr int TILE_BYTES = TILE_I * KP * 2;
 	static constexpr int PASSES = TILE_BYTES / (256 * 16);
-	static constexpr int LDS_BYTES = 2 * TILE_BYTES;
+	static constexpr int QDEPTH = 8;                 // lane-private LDS hit queue: entries per (lane, sub-tile)
+	static constexpr int QUEUE_BYTES = QT * QDEPTH * 256 * 8;
+	static constexpr int LDS_BYTES = 2 * TILE_BYTES + QUEUE_BYTES;   // the prepass kernel uses only the tile part
 };
 
 template <int CPR>
@@ -62,6 +66,8 @@ struct FusedParams {
 	float *gmax; int n_groups;        // prepass output [Q x n_groups]
 	const float *tau; int tau_stride; // threshold per query: tau[q * tau_stride]
 	uint2 *cand; uint32_t *seg_cnt; int capg;
+	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
+	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
 	int n_wg;                         // grid size (for the XCD remap)
 };
 
@@ -72,29 +78,64 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 
+// One 32-item tile of E^T (contiguous 64*KP bytes in HBM) -> LDS by direct-to-LDS loads (global_load_lds_dwordx4: 1 KiB per
+// wave-instruction, LDS destination = wave-uniform base + lane*16, no staging VGPRs, no ds_write).  The bank-conflict
+// swizzle is applied on the per-lane SOURCE address (LDS chunk position p holds source chunk (row, c ^ f(row)));
+// readers apply the same involution.
 template <int KP>
-__device__ __forceinline__ void tile_load(const uint16_t *__restrict__ Et, int tile, u32x4 (&stage)[FusedCfg<KP>::PASSES]) {
-	const u32x4 *src = reinterpret_cast<const u32x4 *>(Et + (int64_t)tile * TILE_I * KP);
-#pragma unroll
-	for (int ps = 0; ps < FusedCfg<KP>::PASSES; ++ps) stage[ps] = src[ps * 256 + threadIdx.x];
-}
-template <int KP>
-__device__ __forceinline__ void tile_store(unsigned char *buf, const u32x4 (&stage)[FusedCfg<KP>::PASSES]) {
+__device__ __forceinline__ void tile_dma(const uint16_t *__restrict__ Et, int tile, unsigned char *buf, int wave, int lane) {
 	constexpr int CPR = FusedCfg<KP>::CPR;
-	u32x4 *dst = reinterpret_cast<u32x4 *>(buf);
+	constexpr int PER_WAVE = FusedCfg<KP>::TILE_BYTES / 1024 / 4;
+	const unsigned char *src = reinterpret_cast<const unsigned char *>(Et + (int64_t)tile * TILE_I * KP);
 #pragma unroll
-	for (int ps = 0; ps < FusedCfg<KP>::PASSES; ++ps) {
-		const int g = ps * 256 + threadIdx.x;
-		const int row = g / CPR, c = g % CPR;
-		dst[row * CPR + swz<CPR>(row, c)] = stage[ps];
+	for (int i = 0; i < PER_WAVE; ++i) {
+		const int piece = wave * PER_WAVE + i;  // wave-uniform
+		const int pch = piece * 64 + lane;
+		const int row = pch / CPR, cs = pch % CPR;
+		const int c = swz<CPR>(row, cs);
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (row * CPR + c) * 16),
+										 (__attribute__((address_space(3))) void *)(buf + piece * 1024), 16, 0, 0);
 	}
+}
+
+// Threshold filter of one 32x32 accumulator tile: lane = query, register e = item row (e & 3) + 8 (e >> 2) (+ 4 h in item0).
+// Survivors go to the lane's private LDS queue (slot i of lane tid at lq[i * 256]: conflict-free, no atomics); the queues
+// are drained to the lane's HBM candidate segment by flush_queue() every FLUSH_TILES tiles with ONE store instruction per
+// queue slot for the whole wave (a store per hit made the kernel store-issue bound: ~20 sparse stores per tile per wave).
+template <bool TAIL, int D>
+__device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint32_t item0, uint32_t n_items, uint2 *lq,
+											  uint32_t &qcnt, uint32_t &ncand) {
+#pragma unroll
+	for (int e = 0; e < 16; ++e) {
+		const float v = acc[e];
+		if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
+			if (v >= tau) {
+				const uint32_t item = item0 + (uint32_t)((e & 3) + 8 * (e >> 2));
+				if (!TAIL || item < n_items) {
+					if (qcnt < (uint32_t)D) { lq[qcnt * 256] = make_uint2(__float_as_uint(v), item); qcnt++; }
+					else ncand = 0x80000000u;  // queue full between two flushes (p ~ 1e-9 per window): poison the segment
+											   // count -> the select kernel recomputes this query exactly
+				}
+			}
+		}
+	}
+}
+__device__ __forceinline__ void flush_queue(uint2 *lq, uint32_t &qcnt, uint2 *__restrict__ seg, uint32_t &ncand, uint32_t capg) {
+	for (uint32_t i = 0; __ballot(i < qcnt) != 0ull; ++i) {
+		if (i < qcnt) {
+			const uint2 e = lq[i * 256];
+			if (ncand < capg) seg[ncand] = e;
+			ncand++;  // (a poisoned count stays > capg)
+		}
+	}
+	qcnt = 0;
 }
 
 // MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep.
 template <int KP, int MODE, int GROUP>
 __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	using Cfg = FusedCfg<KP>;
-	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR, PASSES = Cfg::PASSES;
+	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r = lane & 31, h = lane >> 5;
@@ -120,6 +161,11 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		}
 	}
 
+	// The X fragments must be complete before the tile loop: otherwise hipcc's wait-count merge at the loop header
+	// (fragment loads possibly pending + an unknown number of candidate stores on the back edge) makes it wait
+	// vmcnt(0) in front of the first MFMA of EVERY tile, i.e. right after issuing the next tile's loads.
+	__builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+
 	// ---- work range
 	int j_begin, j_end;  // tile iterations
 	if (MODE == 0) { j_begin = split * p.st_per_split; j_end = min(j_begin + p.st_per_split, p.n_st); }
@@ -127,31 +173,35 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 #define tile_of(j) ((MODE == 0) ? (int)(((int64_t)(j) * p.n_full_tiles) / p.n_st) : (j))
 
 	float tau[QT];
-	uint2 *seg[QT];
-	uint32_t ncand[QT];
+	uint32_t ncand[QT], qcnt[QT];
 #pragma unroll
 	for (int t = 0; t < QT; ++t) {
-		const bool ok = qv[t] < p.Q;
-		tau[t] = INFINITY; seg[t] = nullptr; ncand[t] = 0;
-		if (MODE == 1) {
-			if (ok) tau[t] = p.tau[qv[t] * p.tau_stride];
-			seg[t] = p.cand + ((qv[t] * 2 + h) * (int64_t)p.S + split) * (int64_t)p.capg;
-		}
+		tau[t] = (MODE == 1 && qv[t] < p.Q) ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
+		ncand[t] = 0; qcnt[t] = 0;
 	}
+	// candidate segment of (query, lane half, split); sub-tile t adds a wave-uniform stride
+	uint2 *seg0 = p.cand + ((qv[0] * 2 + h) * (int64_t)p.S + split) * (int64_t)p.capg;
+	const int64_t seg_dt = (int64_t)32 * 2 * p.S * p.capg;
+	uint2 *lq0 = reinterpret_cast<uint2 *>(smem + 2 * Cfg::TILE_BYTES) + tid;  // slot i of sub-tile t at lq0[(t*QDEPTH + i)*256]
 
-	// ---- staging: thread t moves chunk g = pass*256 + tid of the contiguous tile (registers -> swizzled LDS)
-	u32x4 stage[PASSES];
-	if (j_begin < j_end) {
-		tile_load<KP>(p.Et, tile_of(j_begin), stage);
-		tile_store<KP>(smem, stage);
-	}
+	if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
+	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
 
+	int flush_in = p.flush_tiles;
 	for (int j = j_begin; j < j_end; ++j) {
 		const int cur = (j - j_begin) & 1;
 		const int tile = tile_of(j);
 		const bool more = j + 1 < j_end;
-		if (more) tile_load<KP>(p.Et, tile_of(j + 1), stage);
+		if (more) tile_dma<KP>(p.Et, tile_of(j + 1), smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
+		if (MODE == 1) {
+			// drain the hit queues of the previous tiles right behind the DMA: the stores get the whole MFMA phase to retire
+			if (--flush_in == 0) {
+				flush_in = p.flush_tiles;
+#pragma unroll
+				for (int t = 0; t < QT; ++t) flush_queue(lq0 + t * Cfg::QDEPTH * 256, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
+			}
+		}
 
 		f32x16 acc[QT];
 #pragma unroll
@@ -187,31 +237,24 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 			}
 		} else {
 			const uint32_t item0 = (uint32_t)tile * TILE_I + 4 * h;
+			const bool tail = (tile == p.n_tiles - 1) && ((p.I & (TILE_I - 1)) != 0);  // uniform
 #pragma unroll
 			for (int t = 0; t < QT; ++t) {
-#pragma unroll
-				for (int e = 0; e < 16; ++e) {
-					const float v = acc[t][e];
-					if (v >= tau[t]) {
-						const uint32_t item = item0 + (e & 3) + 8 * (e >> 2);
-						if ((int64_t)item < p.I) {
-							if (ncand[t] < (uint32_t)p.capg) seg[t][ncand[t]] = make_uint2(__float_as_uint(v), item);
-							ncand[t]++;
-						}
-					}
-				}
+				if (tail) filter_queue<true, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 256, qcnt[t], ncand[t]);
+				else filter_queue<false, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 256, qcnt[t], ncand[t]);
 			}
 		}
-
-		if (more) tile_store<KP>(smem + (cur ^ 1) * Cfg::TILE_BYTES, stage);
+		__builtin_amdgcn_s_waitcnt(0x0F70);  // the DMA of tile j+1 (and the queue stores issued with it) have landed
 		__syncthreads();
 	}
 
 #undef tile_of
 	if (MODE == 1) {
 #pragma unroll
-		for (int t = 0; t < QT; ++t)
+		for (int t = 0; t < QT; ++t) {
+			flush_queue(lq0 + t * Cfg::QDEPTH * 256, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
 			if (qv[t] < p.Q) p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] = ncand[t];
+		}
 	}
 }
 
@@ -222,13 +265,18 @@ template <int KMAX>
 __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 	const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg, int capg, const uint16_t *__restrict__ X,
 	int64_t ldx, const uint16_t *__restrict__ Et, int64_t I, int KP, uint32_t k, float *__restrict__ out_val,
-	int32_t *__restrict__ out_idx, uint32_t *__restrict__ n_fallback) {
+	int32_t *__restrict__ out_idx, uint32_t *__restrict__ n_fallback, const int32_t *__restrict__ hard_list,
+	const uint32_t *__restrict__ hard_cnt) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const SelState s = sel_carve<KMAX>(smem);
 	float *xq = reinterpret_cast<float *>(smem + SelCfg<KMAX>::LDS_BYTES);  // [KP], fallback only
-	sel_init(s);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int64_t q = blockIdx.x;
+	// either one query per workgroup (hard_list == nullptr) or a grid-stride walk over the queries the wave kernel deferred
+	const uint32_t n_work = hard_list ? *hard_cnt : gridDim.x;
+	for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+	__syncthreads();
+	sel_init(s);
+	const int64_t q = hard_list ? (int64_t)hard_list[wi] : (int64_t)wi;
 	const uint32_t *cnts = seg_cnt + q * nseg;
 	for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
 		const uint32_t c = cnts[sg];
@@ -281,13 +329,62 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 		}
 	}
 	sel_finish<KMAX>(s, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	}
+}
+
+// One WAVE per query (k <= 128, <= 64 segments): the query's candidate segments are streamed through the wave-level
+// selector of wave_select.hpp (wave-private LDS buffer, ballot/popcount radix select, in-register bitonic sort).
+// No workgroup barrier.  Queries whose segments overflowed or that collected fewer than k candidates are appended to
+// hard_list for the workgroup-level kernel (which recomputes them exactly).
+constexpr int WQ_CAP = 1024;
+constexpr int WQ_TRIGGER = WQ_CAP - WAVE;
+
+__global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg,
+														   int capg, int64_t Q, uint32_t k, float *__restrict__ out_val,
+														   int32_t *__restrict__ out_idx, uint32_t *__restrict__ hard_cnt,
+														   int32_t *__restrict__ hard_list) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id(), wave = threadIdx.x >> 6;
+	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+	if (q >= Q) return;
+	const uint32_t c = (lane < nseg) ? seg_cnt[q * nseg + lane] : 0u;
+	uint32_t inc = c;
+#pragma unroll
+	for (int d = 1; d < WAVE; d <<= 1) {
+		const uint32_t t = __shfl_up(inc, d);
+		if (lane >= d) inc += t;
+	}
+	const uint32_t total = __shfl(inc, WAVE - 1), pre = inc - c;
+	if (__ballot(c > (uint32_t)capg) != 0ull || total < k) {
+		if (lane == 0) hard_list[atomicAdd(hard_cnt, 1u)] = (int32_t)q;
+		return;
+	}
+	WaveSel w = wsel_init<WQ_CAP>(smem + wave * WaveSelLayout<WQ_CAP>::BYTES);
+	const uint2 *qc = cand + q * nseg * (int64_t)capg;
+#pragma unroll 4
+	for (uint32_t j0 = 0; j0 < total; j0 += WAVE) {
+		const uint32_t j = j0 + (uint32_t)lane;
+		int sg = 0;  // last segment whose exclusive prefix is <= j (skips empty segments)
+#pragma unroll
+		for (int step = 32; step >= 1; step >>= 1) {
+			const int cs = sg + step;
+			const uint32_t pv = __shfl(pre, cs & 63);
+			if (cs < nseg && pv <= j) sg = cs;
+		}
+		const uint32_t ps = __shfl(pre, sg);
+		const bool in = j < total;
+		const uint2 e = in ? qc[(int64_t)sg * capg + (j - ps)] : make_uint2(0u, 0u);
+		wsel_offer(w, in, __uint_as_float(e.x), e.y);
+		if (w.cnt > (uint32_t)WQ_TRIGGER) wsel_compact<4, false>(w, k);
+	}
+	wsel_finish(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
 
 // ------------------------------------------------------------------ host-side plan
 struct FusedPlan {
 	bool ok;
-	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax;
-	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, total;
+	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
+	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, total;
 };
 
 int g_num_cu = 0;
@@ -343,12 +440,18 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k) {
 	if (capg < 64) capg = 64;
 	if (capg > 16384) capg = 16384;
 	P.capg = capg;
+	// queue window: keep the expected hits per (lane, sub-tile) window near 0.5 so that 8 slots overflow with p ~ 1e-9
+	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
+	int ft = (int)(0.5 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
+	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
 	P.off_tval = off;   off = align256(off + (size_t)Q * k * 4);
 	P.off_tidx = off;   off = align256(off + (size_t)Q * k * 4);
 	P.off_segcnt = off; off = align256(off + (size_t)Q * 2 * P.S * 4);
+	P.off_tau = off;    off = align256(off + (size_t)Q * 4);
+	P.off_hard = off;   off = align256(off + (size_t)Q * 4);
 	P.off_cand = off;   off = align256(off + (size_t)Q * 2 * P.S * (size_t)P.capg * 8);
 	P.total = off;
 	P.ok = true;
@@ -368,24 +471,39 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	float *tval = (float *)(ws + P.off_tval);
 	int32_t *tidx = (int32_t *)(ws + P.off_tidx);
 	p.tau = tval + (k - 1); p.tau_stride = k;
-	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg;
+	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
+	{ const char *dbg = getenv("ANNCUR_DEBUG_TAU_BIAS"); p.tau_bias = dbg ? (float)atof(dbg) : 0.f; }
 
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
 	EV(0);
 	// 1. prepass
 	p.n_wg = P.n_rb * P.S0;
 	if (P.group == 16)
-		hipLaunchKernelGGL((score_kernel<KP, 0, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+		hipLaunchKernelGGL((score_kernel<KP, 0, 16>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
 	else
-		hipLaunchKernelGGL((score_kernel<KP, 0, 4>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+		hipLaunchKernelGGL((score_kernel<KP, 0, 4>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
 	ANNCUR_LAUNCH_OK();
 	EV(1);
 	// 2. tau = k-th largest group maximum
-	int rc = anncur_rowwise_topk(p.gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, tidx, st);
+	int rc;
+	if (P.n_groups <= 2048) {  // one wave per query, keys in registers
+		float *tau = (float *)(ws + P.off_tau);
+		rc = anncur_internal_kth_value(p.gmax, Q, P.n_groups, P.n_groups, k, tau, 1, st);
+		p.tau = tau; p.tau_stride = 1;
+	} else {
+		rc = anncur_rowwise_topk(p.gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, tidx, st);
+	}
 	if (rc != ANNCUR_OK) return rc;
 	EV(2);
 	// 3. sweep
 	p.n_wg = P.n_rb * P.S;
+	{
+		static bool attr_set = false;
+		if (!attr_set) {
+			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)score_kernel<KP, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+			attr_set = true;
+		}
+	}
 	hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 	ANNCUR_LAUNCH_OK();
 	EV(3);
@@ -394,11 +512,33 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 #define LAUNCH_SELECT(KM)                                                                                              \
 	do {                                                                                                               \
 		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)KP * 4;                                                     \
-		ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_candidates_kernel<KM>,                                  \
-										  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3((unsigned)Q), dim3(SEL_THREADS), lds, st, p.cand, p.seg_cnt, nseg, \
-						   P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws);                \
+		static size_t attr_lds = 0;                                                                                    \
+		if (attr_lds < lds) {                                                                                          \
+			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_candidates_kernel<KM>,                              \
+											  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+			attr_lds = lds;                                                                                            \
+		}                                                                                                              \
+		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, p.cand, p.seg_cnt, nseg, \
+						   P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt);  \
 	} while (0)
+	// fast path: one wave per query; what it cannot take lands in hard_list for the workgroup-level kernel
+	const int32_t *hard_list = nullptr;
+	const uint32_t *hard_cnt = nullptr;
+	unsigned sel_grid = (unsigned)Q;
+	if (k <= 128 && nseg <= WAVE) {
+		int32_t *hl = (int32_t *)(ws + P.off_hard);
+		uint32_t *hc = (uint32_t *)(ws + 4);
+		static bool wsel_attr = false;
+		if (!wsel_attr) {
+			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WaveSelLayout<WQ_CAP>::BYTES));
+			wsel_attr = true;
+		}
+		hipLaunchKernelGGL(select_wave_kernel, dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand, p.seg_cnt, nseg,
+						   P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl);
+		ANNCUR_LAUNCH_OK();
+		hard_list = hl; hard_cnt = hc;
+		sel_grid = (unsigned)(Q < 1024 ? Q : 1024);
+	}
 	if (P.kmax == 128) LAUNCH_SELECT(128); else if (P.kmax == 512) LAUNCH_SELECT(512); else LAUNCH_SELECT(2048);
 #undef LAUNCH_SELECT
 	ANNCUR_LAUNCH_OK();

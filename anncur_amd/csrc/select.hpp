@@ -15,10 +15,11 @@ namespace anncur {
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_PASS = 4096;  // upper bound on pushes between two trigger checks
 
-template <int KMAX>
+// PASS = upper bound on pushes between two trigger checks of the kernel that uses the state
+template <int KMAX, int PASS = SEL_PASS>
 struct SelCfg {
 	static constexpr int TRIGGER = 2 * KMAX;
-	static constexpr int CAP = SEL_PASS + 2 * KMAX;
+	static constexpr int CAP = PASS + 2 * KMAX;
 	static constexpr size_t LDS_BYTES = (size_t)CAP * 8 + (size_t)KMAX * 8 + 256 * 4 + 16 * 4;
 };
 
@@ -29,11 +30,11 @@ struct SelState {
 	uint32_t *scal;  // [16]: 0 cnt, 1 newcnt, 2 bin, 3 above, 4 bincount, 6..7 min key (u64), 8.. caller scratch
 };
 
-template <int KMAX>
+template <int KMAX, int PASS = SEL_PASS>
 __device__ __forceinline__ SelState sel_carve(unsigned char *smem) {
 	SelState s;
 	s.buf = reinterpret_cast<uint64_t *>(smem);
-	s.keep = s.buf + SelCfg<KMAX>::CAP;
+	s.keep = s.buf + SelCfg<KMAX, PASS>::CAP;
 	s.hist = reinterpret_cast<uint32_t *>(s.keep + KMAX);
 	s.scal = s.hist + 256;
 	return s;

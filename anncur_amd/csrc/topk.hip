@@ -1,42 +1,49 @@
 // Exact row-wise top-k (HBM-streaming scan), re-rank, overlap counts, gathers, dtype conversion.
+#include <stdlib.h>
 #include "select.hpp"
+#include "wave_select.hpp"
 
 using namespace anncur;
 
 namespace {
 
+constexpr int SCAN_PASS = 2048;  // elements per trigger check of the scan kernel (LDS: 20.5 KB at k <= 128 -> 7 workgroups per CU)
+
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int N = 4; };
 template <> struct VecOf<uint16_t> { static constexpr int N = 8; };
 
+// native 16-byte vector: HIP's uint4 struct gets scalarised into four branched dword loads when used conditionally
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T>
-__device__ __forceinline__ float vec_elem(const uint4 &r, int e);
+__device__ __forceinline__ float vec_elem(const u32x4 &r, int e);
 template <>
-__device__ __forceinline__ float vec_elem<float>(const uint4 &r, int e) {
-	const uint32_t w = e == 0 ? r.x : e == 1 ? r.y : e == 2 ? r.z : r.w;
-	return __uint_as_float(w);
-}
+__device__ __forceinline__ float vec_elem<float>(const u32x4 &r, int e) { return __uint_as_float(r[e]); }
 template <>
-__device__ __forceinline__ float vec_elem<uint16_t>(const uint4 &r, int e) {
-	const uint32_t w = (e >> 1) == 0 ? r.x : (e >> 1) == 1 ? r.y : (e >> 1) == 2 ? r.z : r.w;
+__device__ __forceinline__ float vec_elem<uint16_t>(const u32x4 &r, int e) {
+	const uint32_t w = r[e >> 1];
 	return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
 }
 
 // ------------------------------------------------------------------ a7/a8: exact scan
-// One workgroup per row; the row is read once with 16-byte coalesced loads.
+// One workgroup per row; the row is read once with 16-byte coalesced loads (one vector per thread per
+// iteration, the next one prefetched into registers before the current one is filtered).
+// SEED (k <= 128): the first two vectors of every thread give 512 group maxima; their k-th largest is a
+// valid lower bound on the row's k-th best, so the stream starts with a tight threshold instead of
+// pushing (and then radix-selecting) the first 4096 elements.
 // Algorithmic HBM traffic: I*sizeof(T) bytes per row (+ 8*k bytes written).
-template <typename T, int KMAX>
+template <typename T, int KMAX, bool SEED>
 __global__ __launch_bounds__(SEL_THREADS) void rowwise_topk_kernel(const T *__restrict__ A, int64_t I, int64_t lda,
 																	uint32_t k, float *__restrict__ out_val,
 																	int32_t *__restrict__ out_idx) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const SelState s = sel_carve<KMAX>(smem);
+	const SelState s = sel_carve<KMAX, SCAN_PASS>(smem);
 	sel_init(s);
 	const int tid = threadIdx.x;
 	const int64_t q = blockIdx.x;
 	const T *row = A + q * lda;
 	constexpr int VEC = VecOf<T>::N;
-	constexpr int U = SEL_PASS / (SEL_THREADS * VEC);
 	float tau = -INFINITY;
 	uint64_t tau_key = 0;
 
@@ -45,6 +52,39 @@ __global__ __launch_bounds__(SEL_THREADS) void rowwise_topk_kernel(const T *__re
 	if (head > I) head = I;
 	const int64_t nvec = (I - head) / VEC;
 	const int64_t tail0 = head + nvec * VEC;
+	const u32x4 *vp = reinterpret_cast<const u32x4 *>(row + head);
+	const int64_t vlast = nvec > 0 ? nvec - 1 : 0;  // loads are unconditional on a clamped index (one dwordx4 each); `ok` masks the offers
+	int64_t base = 0;
+
+	if (SEED && nvec >= 2 * SEL_THREADS) {
+		// ---- threshold seed from 512 group maxima (group = one 16-byte vector)
+		const u32x4 r0 = vp[tid], r1 = vp[SEL_THREADS + tid];
+		float m0 = vec_elem<T>(r0, 0), m1 = vec_elem<T>(r1, 0);
+		int a0 = 0, a1 = 0;
+#pragma unroll
+		for (int e = 1; e < VEC; ++e) {
+			const float x0 = vec_elem<T>(r0, e), x1 = vec_elem<T>(r1, e);
+			if (x0 > m0) { m0 = x0; a0 = e; }
+			if (x1 > m1) { m1 = x1; a1 = e; }
+		}
+		// NaN-free maxima as composite keys (value, argmax index): real elements of the row
+		s.buf[tid] = make_key(m0, (uint32_t)(head + (int64_t)tid * VEC + a0));
+		s.buf[SEL_THREADS + tid] = make_key(m1, (uint32_t)(head + ((int64_t)SEL_THREADS + tid) * VEC + a1));
+		if (tid == 0) s.scal[0] = 2 * SEL_THREADS;
+		__syncthreads();
+		const uint64_t kth = sel_compact<KMAX>(s, k);  // k <= 128 < 512 groups
+		tau_key = kth - 1;                              // admit the k-th group maximum itself again below
+		tau = key_val(kth);
+		if (tid == 0) s.scal[0] = 0;                    // drop the maxima: the two vectors are re-offered in full
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < VEC; ++e) sel_offer(s, true, vec_elem<T>(r0, e), (uint32_t)(head + (int64_t)tid * VEC + e), tau, tau_key);
+#pragma unroll
+		for (int e = 0; e < VEC; ++e)
+			sel_offer(s, true, vec_elem<T>(r1, e), (uint32_t)(head + ((int64_t)SEL_THREADS + tid) * VEC + e), tau, tau_key);
+		// at most k groups * VEC elements can pass: <= 1024 < CAP
+		base = 2 * SEL_THREADS;
+	}
 	{  // unaligned head and the tail: fewer than 2*VEC elements in total
 		int64_t i = -1;
 		if (tid < head) i = tid;
@@ -53,25 +93,185 @@ __global__ __launch_bounds__(SEL_THREADS) void rowwise_topk_kernel(const T *__re
 		const float v = in ? load_as_f32<T>(row + i) : 0.f;
 		sel_offer(s, in, v, (uint32_t)i, tau, tau_key);
 	}
-	const uint4 *vp = reinterpret_cast<const uint4 *>(row + head);
-	for (int64_t base = 0; base < nvec; base += (int64_t)SEL_THREADS * U) {
-		uint4 reg[U];
-		bool ok[U];
+	// ---- stream: SCAN_PASS elements per step (U vectors per thread), PF steps of loads kept in flight per thread
+	// (the scan is latency-bound otherwise: one 16-byte load per thread in flight gave 2.6 TB/s)
+	constexpr int U = SCAN_PASS / (SEL_THREADS * VEC);
+	constexpr int PF = 4;
+	constexpr int64_t STEP = (int64_t)SEL_THREADS * U;
+	u32x4 pf[PF][U];
+#pragma unroll
+	for (int d = 0; d < PF; ++d)
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
-			const int64_t iv = base + (int64_t)u * SEL_THREADS + tid;
-			ok[u] = iv < nvec;
-			reg[u] = ok[u] ? vp[iv] : make_uint4(0, 0, 0, 0);
+			const int64_t iv = base + d * STEP + (int64_t)u * SEL_THREADS + tid;
+			pf[d][u] = vp[iv < nvec ? iv : vlast];
 		}
+	for (; base < nvec; base += PF * STEP) {
 #pragma unroll
-		for (int u = 0; u < U; ++u) {
-			const int64_t i0 = head + (base + (int64_t)u * SEL_THREADS + tid) * VEC;
+		for (int d = 0; d < PF; ++d) {  // statically indexed rotation over the PF register sets; steps past the row are masked
+			const int64_t sb = base + d * STEP;  // (no branch around a step: a PHI copy of the prefetch registers would force vmcnt(0))
 #pragma unroll
-			for (int e = 0; e < VEC; ++e) sel_offer(s, ok[u], vec_elem<T>(reg[u], e), (uint32_t)(i0 + e), tau, tau_key);
+			for (int u = 0; u < U; ++u) {
+				const int64_t iv = sb + (int64_t)u * SEL_THREADS + tid;
+				const bool ok = iv < nvec;
+				const int64_t i0 = head + iv * VEC;
+				const u32x4 cur = pf[d][u];
+				const int64_t ivn = iv + PF * STEP;
+				pf[d][u] = vp[ivn < nvec ? ivn : vlast];
+#pragma unroll
+				for (int e = 0; e < VEC; ++e) sel_offer(s, ok, vec_elem<T>(cur, e), (uint32_t)(i0 + e), tau, tau_key);
+			}
+			sel_maybe_compact<KMAX>(s, k, tau, tau_key);
 		}
-		sel_maybe_compact<KMAX>(s, k, tau, tau_key);
 	}
 	sel_finish<KMAX>(s, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+}
+
+// ------------------------------------------------------------------ a7/a8: exact scan, ONE WAVE PER ROW (k <= 128)
+// Barrier-free variant of the scan: each wave streams its own row with 16-byte loads (WS_PF loads in flight per lane),
+// filters against its running threshold and keeps candidates in a wave-private LDS buffer (wave_select.hpp).  The
+// threshold is seeded from the group maxima of the first 512 vectors so that only ~k (1 + ln(I/4096)) elements are ever
+// pushed.  4 rows per 256-thread workgroup, 11 KB LDS per wave.
+constexpr int WS_CAP = 1152;  // trigger at 640 candidates + at most 512 pushes per step (typical rows never compact mid-stream)
+constexpr int WS_TRIGGER = 640;
+constexpr int WS_TIE_LIMIT = 384;
+constexpr int WS_PF = 8;
+constexpr int WS_SEED = 8;    // seed vectors per lane (512 groups)
+
+template <typename T>
+__global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
+																 float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id(), wave = threadIdx.x >> 6;
+	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+	if (q >= Q) return;
+	WaveSel w = wsel_init<WS_CAP>(smem + wave * WaveSelLayout<WS_CAP>::BYTES);
+	const T *row = A + q * lda;
+	constexpr int VEC = VecOf<T>::N;
+	constexpr int HP = sizeof(T) == 2 ? 2 : 4;  // radix passes over the score key: bf16 scores carry 16 key bits
+	const uintptr_t addr = reinterpret_cast<uintptr_t>(row);
+	int64_t head = (int64_t)(((16 - (addr & 15)) & 15) / sizeof(T));
+	if (head > I) head = I;
+	const int64_t nvec = (I - head) / VEC;
+	const int64_t tail0 = head + nvec * VEC;
+	const u32x4 *vp = reinterpret_cast<const u32x4 *>(row + head);
+	const int64_t vlast = nvec > 0 ? nvec - 1 : 0;
+	const int64_t nsteps = (nvec + WAVE - 1) / WAVE;
+	int64_t s0 = 0;
+
+	if (nvec >= (int64_t)WS_SEED * WAVE) {
+		// ---- seed: the maxima of the first 512 vectors are real elements; their k best give the first threshold
+		u32x4 sv[WS_SEED];
+		int am[WS_SEED];
+#pragma unroll
+		for (int v = 0; v < WS_SEED; ++v) sv[v] = vp[v * WAVE + lane];
+#pragma unroll
+		for (int v = 0; v < WS_SEED; ++v) {
+			float m = vec_elem<T>(sv[v], 0);
+			int a = 0;
+#pragma unroll
+			for (int e = 1; e < VEC; ++e) {
+				const float x = vec_elem<T>(sv[v], e);
+				if (x > m) { m = x; a = e; }
+			}
+			am[v] = a;
+			wsel_push(w, m == m, f32_sortable(m), 0xffffffffu - (uint32_t)(head + ((int64_t)v * WAVE + lane) * VEC + a));
+		}
+		if (w.cnt > k) wsel_compact<HP, false>(w, k);
+#pragma unroll
+		for (int v = 0; v < WS_SEED; ++v) {  // the other elements of those vectors (the maxima are already in)
+#pragma unroll
+			for (int e = 0; e < VEC; ++e)
+				wsel_offer(w, e != am[v], vec_elem<T>(sv[v], e), (uint32_t)(head + ((int64_t)v * WAVE + lane) * VEC + e));
+			if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, false>(w, k);
+		}
+		s0 = WS_SEED;
+	}
+	{  // unaligned head (fewer than VEC elements); exact composite compare: the seed broke the index order
+		const bool in = lane < head;
+		wsel_offer(w, in, in ? load_as_f32<T>(row + lane) : 0.f, (uint32_t)lane);
+		if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, false>(w, k);
+	}
+	// ---- stream (strictly increasing indices from here on: one float compare per element is exact)
+	u32x4 pf[WS_PF];
+#pragma unroll
+	for (int d = 0; d < WS_PF; ++d) {
+		const int64_t iv = (s0 + d) * WAVE + lane;
+		pf[d] = vp[iv < nvec ? iv : vlast];
+	}
+	for (; s0 < nsteps; s0 += WS_PF) {
+#pragma unroll
+		for (int d = 0; d < WS_PF; ++d) {  // steps past the row are masked, never branched around (keeps the prefetch registers PHI-free)
+			const int64_t iv = (s0 + d) * WAVE + lane;
+			const bool ok = iv < nvec;
+			const int64_t i0 = head + iv * VEC;
+			const u32x4 cur = pf[d];
+			const int64_t ivn = iv + (int64_t)WS_PF * WAVE;
+			pf[d] = vp[ivn < nvec ? ivn : vlast];
+#pragma unroll
+			for (int e = 0; e < VEC; ++e) wsel_offer_inorder(w, ok, vec_elem<T>(cur, e), (uint32_t)(i0 + e));
+			if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, true>(w, k, WS_TIE_LIMIT);
+		}
+	}
+	{  // the tail (fewer than VEC elements), still in index order
+		const bool in = lane < I - tail0;
+		wsel_offer_inorder(w, in, in ? load_as_f32<T>(row + tail0 + lane) : 0.f, (uint32_t)(tail0 + lane));
+	}
+	wsel_finish(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+}
+
+// ------------------------------------------------------------------ k-th largest VALUE of short fp32 rows, one wave per row
+// (the fused path's threshold step: rows of a few hundred group maxima).  No LDS, no barriers.
+template <int NR>
+__global__ __launch_bounds__(256) void kth_value_wave_kernel(const float *__restrict__ G, int64_t Q, int n, int64_t ldg, uint32_t k,
+															  float *__restrict__ out, int64_t out_stride) {
+	const int lane = lane_id();
+	const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (q >= Q) return;
+	uint32_t key[NR];
+	const float *g = G + q * ldg;
+	const int nr = (n + WAVE - 1) / WAVE;
+#pragma unroll
+	for (int r = 0; r < NR; ++r) {
+		const int j = r * WAVE + lane;
+		float v = (r < nr && j < n) ? g[j] : 0.f;
+		key[r] = (r < nr && j < n && v == v) ? f32_sortable(v) : 0u;  // NaN never selected
+	}
+	const uint32_t kk = wave_kth_largest_regs<NR>(key, nr, k);
+	if (lane == 0) out[q * out_stride] = f32_unsortable(kk);
+}
+
+// Same for rows of up to 2048 values: keys in a wave-private LDS region, runtime loops.
+__global__ __launch_bounds__(256) void kth_value_wave_lds_kernel(const float *__restrict__ G, int64_t Q, int n, int64_t ldg, uint32_t k,
+																  float *__restrict__ out, int64_t out_stride) {
+	__shared__ uint32_t keys[4][2048];
+	const uint32_t lane = (uint32_t)lane_id();
+	const int wave = threadIdx.x >> 6;
+	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+	if (q >= Q) return;
+	const float *g = G + q * ldg;
+	for (uint32_t j = lane; j < (uint32_t)n; j += WAVE) {
+		const float v = g[j];
+		keys[wave][j] = (v == v) ? f32_sortable(v) : 0u;
+	}
+	__builtin_amdgcn_wave_barrier();
+	uint32_t prefix = 0, need = k;
+	for (int bit = 31; bit >= 0; --bit) {
+		const uint32_t himask = (bit == 31) ? 0u : ~((2u << bit) - 1u);
+		uint32_t cnt = 0;
+		for (uint32_t j0 = 0; j0 < (uint32_t)n; j0 += WAVE) {
+			const uint32_t j = j0 + lane;
+			bool c = false;
+			if (j < (uint32_t)n) {
+				const uint32_t x = keys[wave][j];
+				c = ((x & himask) == prefix) && ((x >> bit) & 1u);
+			}
+			cnt += (uint32_t)__popcll(__ballot(c));
+		}
+		if (cnt >= need) prefix |= (1u << bit);
+		else need -= cnt;
+	}
+	if (lane == 0) out[q * out_stride] = f32_unsortable(prefix);
 }
 
 // ------------------------------------------------------------------ a8: exact re-rank
@@ -140,6 +340,39 @@ __global__ __launch_bounds__(256) void overlap_kernel(const int32_t *__restrict_
 	for (int p = tid; p < n_pairs; p += 256) common[(int64_t)p * Q + q] = scnt[p];
 }
 
+// Wave-per-row variant for short lists (la <= 128, lb <= 128): b in registers, broadcast with readlane.
+__global__ __launch_bounds__(256) void overlap_wave_kernel(const int32_t *__restrict__ a, int32_t la, const int32_t *__restrict__ b,
+															int32_t lb, int64_t Q, OvlPairs pairs, int32_t n_pairs,
+															int32_t *__restrict__ common) {
+	const int lane = lane_id();
+	const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (q >= Q) return;
+	int32_t av[2], bv[2], pos[2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		const int j = e * WAVE + lane;
+		av[e] = j < la ? a[q * la + j] : -1;
+		bv[e] = j < lb ? b[q * lb + j] : -2;
+		pos[e] = 0x7fffffff;
+	}
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		const int lim = min(WAVE, lb - e * WAVE);
+		for (int t = 0; t < lim; ++t) {
+			const int32_t x = __builtin_amdgcn_readlane(bv[e], t);
+			const int p = e * WAVE + t;
+			if (av[0] == x && p < pos[0]) pos[0] = p;
+			if (av[1] == x && p < pos[1]) pos[1] = p;
+		}
+	}
+	for (int p = 0; p < n_pairs; ++p) {
+		const int ka = pairs.ka[p], kb = pairs.kb[p];
+		const int c = __popcll(__ballot(lane < ka && av[0] >= 0 && pos[0] < kb)) +
+					  __popcll(__ballot(WAVE + lane < ka && av[1] >= 0 && pos[1] < kb));
+		if (lane == 0) common[(int64_t)p * Q + q] = c;
+	}
+}
+
 // ------------------------------------------------------------------ a2: gathers, conversion
 template <typename TS, typename TD>
 __device__ __forceinline__ TD cvt(TS x);
@@ -193,6 +426,16 @@ int kmax_class(int k) { return k <= 128 ? 128 : (k <= 512 ? 512 : 2048); }
 
 }  // namespace
 
+// internal (not part of the C ABI): tau[q] = k-th largest of G[q, :n], n <= 2048
+int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st) {
+	ANNCUR_REQUIRE(n >= 1 && n <= 2048 && k >= 1 && k <= n, ANNCUR_E_INVALID, "kth_value: need 1 <= k <= n <= 2048");
+	const unsigned grid = (unsigned)ceil_div64(Q, 4);
+	if (n <= 512) hipLaunchKernelGGL((kth_value_wave_kernel<8>), dim3(grid), dim3(256), 0, st, G, Q, n, ldg, (uint32_t)k, out, out_stride);
+	else hipLaunchKernelGGL(kth_value_wave_lds_kernel, dim3(grid), dim3(256), 0, st, G, Q, n, ldg, (uint32_t)k, out, out_stride);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
 // =================================================================== C ABI
 extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k,
 								   float *out_val, int32_t *out_idx, void *stream) {
@@ -209,12 +452,26 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 	const int kc = kmax_class(k);
 #define LAUNCH_ROWTOPK(T, KM)                                                                                   \
 	do {                                                                                                        \
-		ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)rowwise_topk_kernel<T, KM>,                             \
-										  hipFuncAttributeMaxDynamicSharedMemorySize, (int)SelCfg<KM>::LDS_BYTES)); \
-		hipLaunchKernelGGL((rowwise_topk_kernel<T, KM>), dim3((unsigned)Q), dim3(SEL_THREADS), SelCfg<KM>::LDS_BYTES, st, \
+		static bool attr_done = false;                                                                          \
+		if (!attr_done) {                                                                                       \
+			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)rowwise_topk_kernel<T, KM, (KM == 128)>,            \
+											  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SelCfg<KM, SCAN_PASS>::LDS_BYTES))); \
+			attr_done = true;                                                                                   \
+		}                                                                                                       \
+		hipLaunchKernelGGL((rowwise_topk_kernel<T, KM, (KM == 128)>), dim3((unsigned)Q), dim3(SEL_THREADS), (SelCfg<KM, SCAN_PASS>::LDS_BYTES), st, \
 						   (const T *)A, I, lda, (uint32_t)k, out_val, out_idx);                                \
 	} while (0)
 	ANNCUR_REQUIRE(Q < (int64_t)0x7fffffff, ANNCUR_E_INVALID, "rowwise_topk: Q too large");
+	if (k <= WSEL_K && !getenv("ANNCUR_DEBUG_BLOCK_SCAN")) {  // barrier-free path: one wave per row
+		const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
+		const unsigned grid = (unsigned)ceil_div64(Q, 4);
+		if (dtype == ANNCUR_F32)
+			hipLaunchKernelGGL((rowwise_topk_wave_kernel<float>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, out_val, out_idx);
+		else
+			hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, out_val, out_idx);
+		ANNCUR_LAUNCH_OK();
+		return ANNCUR_OK;
+	}
 	if (dtype == ANNCUR_F32) {
 		if (kc == 128) LAUNCH_ROWTOPK(float, 128); else if (kc == 512) LAUNCH_ROWTOPK(float, 512); else LAUNCH_ROWTOPK(float, 2048);
 	} else {
@@ -238,8 +495,12 @@ extern "C" int anncur_rerank(const void *A, int dtype, int64_t Q, int64_t I, int
 	const int kc = kmax_class(k_out);
 #define LAUNCH_RERANK(T, KM)                                                                                    \
 	do {                                                                                                        \
-		ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)rerank_kernel<T, KM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-										  (int)SelCfg<KM>::LDS_BYTES));                                         \
+		static bool attr_done = false;                                                                          \
+		if (!attr_done) {                                                                                       \
+			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)rerank_kernel<T, KM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+											  (int)SelCfg<KM>::LDS_BYTES));                                     \
+			attr_done = true;                                                                                   \
+		}                                                                                                       \
 		hipLaunchKernelGGL((rerank_kernel<T, KM>), dim3((unsigned)Q), dim3(SEL_THREADS), SelCfg<KM>::LDS_BYTES, st, \
 						   (const T *)A, I, lda, approx_idx, ld_idx, (uint32_t)k_retvr, (uint32_t)k_out, rerank_val, rerank_idx); \
 	} while (0)
@@ -267,6 +528,12 @@ extern "C" int anncur_overlap_counts(const int32_t *a, int32_t la, const int32_t
 		pairs.kb[p] = kb[p];
 	}
 	if (Q == 0) return ANNCUR_OK;
+	if (la <= 2 * WAVE && lb <= 2 * WAVE) {
+		hipLaunchKernelGGL(overlap_wave_kernel, dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 0, (hipStream_t)stream, a, la, b, lb, Q, pairs,
+						   n_pairs, common);
+		ANNCUR_LAUNCH_OK();
+		return ANNCUR_OK;
+	}
 	const size_t lds = (size_t)(la + lb + n_pairs) * 4;
 	hipLaunchKernelGGL(overlap_kernel, dim3((unsigned)Q), dim3(256), lds, (hipStream_t)stream, a, la, b, lb, Q, pairs, n_pairs, common);
 	ANNCUR_LAUNCH_OK();

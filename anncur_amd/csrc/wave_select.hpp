@@ -1,0 +1,260 @@
+// Wave-level exact top-k selection (k <= 128): ONE wave owns one row / one query.  No workgroup barrier, no atomics
+// that return: the wave's candidate buffer, digit histogram and sort scratch live in a wave-private LDS region, the
+// candidate count in a (wave-uniform) register, counting is ballot + popcount.  Same-wave LDS accesses execute in
+// program order, so the only synchronisation needed is keeping the compiler from reordering them (wave_barrier).
+//
+// Candidate = 64-bit composite key split in two 32-bit halves: hi = order-preserving map of the fp32 score,
+// lo = 0xffffffff - index  (larger key = better score, ties -> smaller index).  Keys of one row are distinct.
+#pragma once
+#include "common.hpp"
+
+namespace anncur {
+
+constexpr int WSEL_K = 128;  // largest k of the wave-level path
+
+template <int CAP>
+struct WaveSelLayout {
+	static constexpr int BYTES = CAP * 8 + 128 * 8 + 256 * 4;
+};
+
+struct WaveSel {
+	uint32_t *whi, *wlo;  // [CAP]
+	uint2 *sort_buf;      // [128]
+	uint32_t *hist;       // [256]
+	uint32_t cnt;         // wave-uniform
+	uint32_t tau_hi, tau_lo;  // running threshold key (k-th best so far); 0 = none yet
+	float tau;                // its score
+};
+
+template <int CAP>
+__device__ __forceinline__ WaveSel wsel_init(unsigned char *wave_lds) {
+	WaveSel w;
+	w.whi = reinterpret_cast<uint32_t *>(wave_lds);
+	w.wlo = w.whi + CAP;
+	w.sort_buf = reinterpret_cast<uint2 *>(w.wlo + CAP);
+	w.hist = reinterpret_cast<uint32_t *>(w.sort_buf + 128);
+	w.cnt = 0; w.tau_hi = 0; w.tau_lo = 0; w.tau = -INFINITY;
+	return w;
+}
+
+// Append the lanes with `hit` (wave-uniform call; caller guarantees room).
+__device__ __forceinline__ void wsel_push(WaveSel &w, bool hit, uint32_t hi, uint32_t lo) {
+	const unsigned long long m = __ballot(hit);
+	if (m == 0ull) return;
+	if (hit) {
+		const uint32_t pos = w.cnt + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+		w.whi[pos] = hi;
+		w.wlo[pos] = lo;
+	}
+	w.cnt += (uint32_t)__popcll(m);
+}
+
+// Offer one element per lane: cheap float filter first, exact composite-key comparison only when some lane passes.
+__device__ __forceinline__ void wsel_offer(WaveSel &w, bool valid, float v, uint32_t idx) {
+	const bool maybe = valid && (v >= w.tau);
+	if (__ballot(maybe) == 0ull) return;
+	const uint32_t hi = f32_sortable(v), lo = 0xffffffffu - idx;
+	wsel_push(w, maybe && (hi > w.tau_hi || (hi == w.tau_hi && lo > w.tau_lo)), hi, lo);
+}
+
+// In-order stream variant: every candidate already in the buffer has a smaller index than this element, so a score tie
+// with the threshold loses and one strict float compare is exact.
+__device__ __forceinline__ void wsel_offer_inorder(WaveSel &w, bool valid, float v, uint32_t idx) {
+	const bool hit = valid && (v > w.tau);
+	if (__ballot(hit) == 0ull) return;
+	wsel_push(w, hit, f32_sortable(v), 0xffffffffu - idx);
+}
+
+// k-th largest among key[0..n) (optionally only where gate[j] == gate_val): MSB-first radix select, 8-bit digits,
+// histogram filled with non-returning LDS atomics.  Returns the key; need_out = copies of it that belong to the top-k.
+// PASSES < 4: the keys are known to be zero below bit 32 - 8*PASSES (bf16 scores: 2 passes).
+template <bool GATED, int PASSES = 4>
+__device__ __forceinline__ uint32_t wsel_kth(const WaveSel &w, const uint32_t *key, uint32_t n, uint32_t k, uint32_t &need_out,
+											  const uint32_t *gate, uint32_t gate_val) {
+	const uint32_t lane = (uint32_t)lane_id();
+	uint32_t prefix = 0, need = k;
+	for (int pass = 0; pass < PASSES; ++pass) {
+		const int shift = 24 - 8 * pass;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) w.hist[lane * 4 + i] = 0;
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+		for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+			const uint32_t j = j0 + lane;
+			if (j < n) {
+				const uint32_t x = key[j];
+				bool c = (pass == 0) || ((x >> (shift + 8)) == prefix);
+				if (GATED) c = c && (gate[j] == gate_val);
+				if (c) atomicAdd(&w.hist[(x >> shift) & 255u], 1u);
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t h0 = w.hist[lane * 4], h1 = w.hist[lane * 4 + 1], h2 = w.hist[lane * 4 + 2], h3 = w.hist[lane * 4 + 3];
+		const uint32_t c4 = h0 + h1 + h2 + h3;
+		uint32_t suf = c4;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+		for (int d = 1; d < WAVE; d <<= 1) {
+			const uint32_t t = __shfl_down(suf, d);
+			if (lane + d < WAVE) suf += t;
+		}
+		uint32_t a = suf - c4, bin = 0;
+		const bool mine = a < need && suf >= need;
+		if (mine) {
+			if (a + h3 >= need) { bin = lane * 4 + 3; }
+			else { a += h3;
+				if (a + h2 >= need) { bin = lane * 4 + 2; }
+				else { a += h2;
+					if (a + h1 >= need) { bin = lane * 4 + 1; }
+					else { a += h1; bin = lane * 4; } } }
+		}
+		const int src = __ffsll((long long)__ballot(mine)) - 1;  // exactly one lane
+		bin = __shfl(bin, src);
+		a = __shfl(a, src);
+		need -= a;
+		prefix = (prefix << 8) | bin;
+		__builtin_amdgcn_wave_barrier();
+	}
+	need_out = need;
+	return prefix << (32 - 8 * PASSES);
+}
+
+// Cut the buffer down to its k best candidates (cnt > k), in place; the k-th best becomes the threshold.
+// KEEP_TIES (mid-stream use only): keep every candidate that ties with the k-th score instead of resolving the tie by
+// index, as long as they fit below `tie_limit`; the buffer then holds >= k entries and the threshold is the k-th SCORE,
+// which is all an in-order stream needs (later elements lose score ties).  The final call must be exact.
+template <int HI_PASSES = 4, bool KEEP_TIES = false>
+__device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t tie_limit = 0) {
+	const uint32_t lane = (uint32_t)lane_id();
+	const uint32_t n = w.cnt;
+	__builtin_amdgcn_wave_barrier();
+	uint32_t need, need2;
+	// with HI_PASSES < 4 only the top 8*HI_PASSES key bits are significant (and the low bits of all keys of one sign agree)
+	constexpr uint32_t M = HI_PASSES >= 4 ? 0xffffffffu : (0xffffffffu << (32 - 8 * HI_PASSES));
+	const uint32_t T = wsel_kth<false, HI_PASSES>(w, w.whi, n, k, need, w.whi, 0u);
+	uint32_t cnt_eq = 0;
+#pragma unroll 4
+	for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+		const uint32_t j = j0 + lane;
+		cnt_eq += (uint32_t)__popcll(__ballot(j < n && (w.whi[j] & M) == T));
+	}
+	uint32_t Tlo = 0;  // ties at the k-th score: the `need` smallest indices (largest lo) win
+	if (cnt_eq > need && !(KEEP_TIES && (k - need) + cnt_eq <= tie_limit)) {
+		// gate on the full key of the tie group: all its members share one score, hence one full hi key
+		uint32_t tie_hi = 0;
+		for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+			const uint32_t j = j0 + lane;
+			const uint32_t x = j < n ? w.whi[j] : 0u;
+			const unsigned long long m = __ballot(j < n && (x & M) == T);
+			if (m) { tie_hi = __shfl(x, __ffsll((long long)m) - 1); break; }
+		}
+		Tlo = wsel_kth<true>(w, w.wlo, n, need, need2, w.whi, tie_hi);
+	}
+	// in-place forward compaction: chunk j0 is read into registers before anything at or below it is overwritten
+	uint32_t base = 0;
+	uint64_t kmin = ~0ull;
+	for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+		const uint32_t j = j0 + lane;
+		uint32_t h = 0, l = 0;
+		if (j < n) { h = w.whi[j]; l = w.wlo[j]; }
+		const bool sel = (j < n) && ((h & M) > T || ((h & M) == T && l >= Tlo));
+		const unsigned long long m = __ballot(sel);
+		__builtin_amdgcn_wave_barrier();
+		if (sel) {
+			const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			w.whi[pos] = h;
+			w.wlo[pos] = l;
+			const uint64_t key = ((uint64_t)h << 32) | l;
+			if (key < kmin) kmin = key;
+		}
+		base += (uint32_t)__popcll(m);
+	}
+#pragma unroll
+	for (int d = WAVE / 2; d > 0; d >>= 1) {
+		const uint64_t o = __shfl_xor(kmin, d);
+		if (o < kmin) kmin = o;
+	}
+	w.cnt = base;  // == k (or k + extra score ties under KEEP_TIES)
+	w.tau_hi = (uint32_t)(kmin >> 32);  // the smallest kept key: exactly the k-th best in exact mode
+	w.tau_lo = (uint32_t)kmin;
+	w.tau = f32_unsortable(w.tau_hi);
+	__builtin_amdgcn_wave_barrier();
+}
+
+// Bitonic sort (descending) of 128 64-bit keys held as (hi, lo) pairs, two per lane: element i = e*64 + lane.
+__device__ __forceinline__ void wave_sort128_desc(uint32_t (&hi)[2], uint32_t (&lo)[2]) {
+	const int lane = lane_id();
+#pragma unroll
+	for (int size = 2; size <= 128; size <<= 1) {
+#pragma unroll
+		for (int stride = size >> 1; stride > 0; stride >>= 1) {
+			if (stride == 64) {
+				// partner is the other register of this lane; size == 128 here -> whole sequence descending
+				const uint64_t a = ((uint64_t)hi[0] << 32) | lo[0], b = ((uint64_t)hi[1] << 32) | lo[1];
+				if (a < b) {
+					const uint32_t th = hi[0], tl = lo[0];
+					hi[0] = hi[1]; lo[0] = lo[1]; hi[1] = th; lo[1] = tl;
+				}
+			} else {
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					const uint32_t oh = __shfl_xor(hi[e], stride), ol = __shfl_xor(lo[e], stride);
+					const uint64_t mine = ((uint64_t)hi[e] << 32) | lo[e], other = ((uint64_t)oh << 32) | ol;
+					const int i = e * 64 + lane;
+					const bool desc = (i & size) == 0;
+					const bool lower = (lane & stride) == 0;
+					const bool keep_max = (desc == lower);
+					const bool take_other = keep_max ? (other > mine) : (other < mine);
+					if (take_other) { hi[e] = oh; lo[e] = ol; }
+				}
+			}
+		}
+	}
+}
+
+// Reduce to the k best, sort them, write the output row.  Fewer than k candidates -> (-inf, -1) padding.
+__device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx) {
+	const int lane = lane_id();
+	if (w.cnt > k) wsel_compact<4, false>(w, k);
+	__builtin_amdgcn_wave_barrier();
+	uint32_t sh[2], sl[2];
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		const uint32_t i = (uint32_t)(e * WAVE + lane);
+		const bool in = i < w.cnt;
+		sh[e] = in ? w.whi[i] : 0u;
+		sl[e] = in ? w.wlo[i] : 0u;
+	}
+	wave_sort128_desc(sh, sl);
+#pragma unroll
+	for (int e = 0; e < 2; ++e) {
+		const uint32_t i = (uint32_t)(e * WAVE + lane);
+		if (i < k) {
+			const bool real = i < w.cnt;
+			out_val[i] = real ? f32_unsortable(sh[e]) : -INFINITY;
+			out_idx[i] = real ? (int32_t)(0xffffffffu - sl[e]) : -1;
+		}
+	}
+}
+
+// k-th largest of the 64*NR keys held one-per-(lane, register) (short rows kept entirely in registers).
+template <int NR>
+__device__ __forceinline__ uint32_t wave_kth_largest_regs(const uint32_t (&key)[NR], int nr, uint32_t k) {
+	uint32_t prefix = 0, need = k;
+#pragma unroll 1
+	for (int bit = 31; bit >= 0; --bit) {
+		const uint32_t himask = (bit == 31) ? 0u : ~((2u << bit) - 1u);
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			if (r < nr) {
+				const bool c = ((key[r] & himask) == prefix) && ((key[r] >> bit) & 1u);
+				cnt += (uint32_t)__popcll(__ballot(c));
+			}
+		}
+		if (cnt >= need) prefix |= (1u << bit);
+		else need -= cnt;
+	}
+	return prefix;
+}
+
+}  // namespace anncur

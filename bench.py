@@ -103,27 +103,47 @@ def main():
 	top_k_vals = [t for t in (1, 10, 50, 100) if t <= min(k, kr)]
 	cells = [(t, kr) for t in top_k_vals]
 
-	def step():
+	# Host statistics of step i (the reference's mean/std/median formatting over 4 x Q counts) run while the GPU already
+	# executes step i+1: counts go D2H into one of two pinned buffers, an event marks their arrival.
+	pinned = [torch.empty((len(cells), Q), dtype=torch.int32, pin_memory=True) for _ in range(2)]
+	events = [torch.cuda.Event() for _ in range(2)]
+
+	def launch(slot):
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
 		approx = ops.score_topk_fused(Xq, cur._Etp, I, kr)             # a6 + a7 fused
 		exact = ops.rowwise_topk(A_test, k)                            # a8 exact scan
 		counts = ops.overlap_counts(exact.indices, approx.indices, cells)  # a8 rerank (closed form) + a10
-		c = counts.cpu().numpy()                                       # D2H of 4*Q ints, then the reference's statistics
+		pinned[slot].copy_(counts, non_blocking=True)
+		events[slot].record()
+		return slot
+
+	def finish(slot):
+		events[slot].synchronize()
+		c = pinned[slot].numpy()
 		return {t: flatten_overlap(overlap_stats_from_counts(c[j], t)) for j, (t, _) in enumerate(cells)}
+
+	def run_steps(n):
+		res, pending = None, None
+		for i in range(n):
+			cur_slot = launch(i & 1)
+			if pending is not None:
+				res = finish(pending)
+			pending = cur_slot
+		if pending is not None:
+			res = finish(pending)
+		return res
 
 	def barrier():
 		if world > 1:
 			torch.distributed.barrier()
 		torch.cuda.synchronize()
 
-	for _ in range(args.warmup):
-		res = step()
+	res = run_steps(args.warmup)
 	barrier()
 	t0 = time.perf_counter()
-	for _ in range(args.steps):
-		res = step()
+	res = run_steps(args.steps)      # every one of the K steps is launched AND its statistics finished inside the timed region
 	barrier()
 	elapsed = time.perf_counter() - t0
 	if world > 1:

@@ -213,3 +213,32 @@ def test_approx_error(ops):
 	S = X.double() @ Et.double().t()
 	torch.testing.assert_close(err.cpu().double(), ((S - A.double()) ** 2).sum(1), rtol=1e-4, atol=1e-3)
 	torch.testing.assert_close(nrm.cpu().double(), (A.double() ** 2).sum(1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rowwise_topk_negative_ties_and_kth_negative(ops, dtype):
+	# all-negative rows with heavy ties (bf16 keys of negative scores have all-ones low bits): exercises the masked radix compare
+	g = _g(77)
+	A = (-(torch.rand(12, 20000, generator=g) * 4).round() / 4 - 1.0).to(dtype)
+	for k in (1, 50, 128):
+		v, i = ops.rowwise_topk(A.cuda(), k)
+		rv, _ = torch.topk(A.float(), k, dim=1)
+		assert torch.equal(v.cpu(), rv)
+		i = i.cpu().long()
+		assert torch.equal(torch.gather(A.float(), 1, i), rv)
+		assert ((v.cpu()[:, :-1] > v.cpu()[:, 1:]) | ((v.cpu()[:, :-1] == v.cpu()[:, 1:]) & (i[:, :-1] < i[:, 1:]))).all() or k == 1
+	# top-k of a short row that reaches into the negative part
+	B = torch.cat([torch.full((3, 10), 2.0), -torch.arange(1, 301, dtype=torch.float32).repeat(3, 1) / 64], dim=1).to(dtype)
+	v, i = ops.rowwise_topk(B.cuda(), 100)
+	rv, _ = torch.topk(B.float(), 100, dim=1)
+	assert torch.equal(v.cpu(), rv) and torch.equal(i.cpu()[:, :10].long(), torch.arange(10).repeat(3, 1))
+
+
+def test_overlap_counts_long_lists(ops):
+	g = np.random.default_rng(5)
+	a = np.stack([g.permutation(5000)[:300] for _ in range(20)]).astype(np.int32)
+	b = np.stack([g.permutation(5000)[:700] for _ in range(20)]).astype(np.int32)
+	pairs = [(300, 700), (100, 700), (300, 10), (1, 1)]
+	got = ops.overlap_counts(torch.tensor(a).cuda(), torch.tensor(b).cuda(), pairs).cpu().numpy()
+	for p, (ka, kb) in enumerate(pairs):
+		assert got[p].tolist() == [len(set(a[q, :ka]) & set(b[q, :kb])) for q in range(20)]

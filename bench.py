@@ -54,12 +54,13 @@ def synth_device(cfg, device, seed):
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
-	ap.add_argument("--steps", type=int, default=20)
-	ap.add_argument("--warmup", type=int, default=3)
+	ap.add_argument("--steps", type=int, default=30)
+	ap.add_argument("--warmup", type=int, default=5)
 	ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
 	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
 	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
 	ap.add_argument("--seed", type=int, default=0)
+	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
 	cfg = CONFIGS[args.config]
 
@@ -105,31 +106,56 @@ def main():
 
 	# Host statistics of step i (the reference's mean/std/median formatting over 4 x Q counts) run while the GPU already
 	# executes step i+1: counts go D2H into one of two pinned buffers, an event marks their arrival.
+	prof = {"launch": 0.0, "finish": 0.0}
 	pinned = [torch.empty((len(cells), Q), dtype=torch.int32, pin_memory=True) for _ in range(2)]
 	events = [torch.cuda.Event() for _ in range(2)]
 
-	def launch(slot):
+	def gpu_step():
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
 		approx = ops.score_topk_fused(Xq, cur._Etp, I, kr)             # a6 + a7 fused
 		exact = ops.rowwise_topk(A_test, k)                            # a8 exact scan
-		counts = ops.overlap_counts(exact.indices, approx.indices, cells)  # a8 rerank (closed form) + a10
+		return ops.overlap_counts(exact.indices, approx.indices, cells)   # a8 rerank (closed form) + a10
+
+	# The ten launches of a step are captured once into a HIP graph and replayed: per-dispatch latency on a busy host
+	# otherwise dominates (the kernels of a step total ~1.6 ms).  --no-graph keeps the eager launches.
+	graph, static_counts = None, None
+	if not args.no_graph:
+		gpu_step(); torch.cuda.synchronize()                           # allocate the workspace / load code objects outside capture
+		static_counts = torch.empty((len(cells), Q), dtype=torch.int32, device=device)
+		graph = torch.cuda.CUDAGraph()
+		with torch.cuda.graph(graph):
+			static_counts.copy_(gpu_step())
+
+	def launch(slot):
+		if graph is not None:
+			graph.replay()
+			counts = static_counts
+		else:
+			counts = gpu_step()
 		pinned[slot].copy_(counts, non_blocking=True)
 		events[slot].record()
 		return slot
 
 	def finish(slot):
-		events[slot].synchronize()
-		c = pinned[slot].numpy()
+		t_a = time.perf_counter()
+		while not events[slot].query():  # spin: a blocking wait can add milliseconds of wake-up latency on a busy host
+			pass
+		prof["wait"] = prof.get("wait", 0.0) + time.perf_counter() - t_a
+		c = np.array(pinned[slot].numpy())  # one memcpy out of the pinned (uncached-for-the-CPU) buffer, then the statistics
 		return {t: flatten_overlap(overlap_stats_from_counts(c[j], t)) for j, (t, _) in enumerate(cells)}
 
 	def run_steps(n):
 		res, pending = None, None
 		for i in range(n):
+			t_a = time.perf_counter()
 			cur_slot = launch(i & 1)
+			t_b = time.perf_counter()
 			if pending is not None:
 				res = finish(pending)
+			prof["launch"] += t_b - t_a
+			prof["finish"] += time.perf_counter() - t_b
 			pending = cur_slot
 		if pending is not None:
 			res = finish(pending)
@@ -146,6 +172,9 @@ def main():
 	res = run_steps(args.steps)      # every one of the K steps is launched AND its statistics finished inside the timed region
 	barrier()
 	elapsed = time.perf_counter() - t0
+	if os.environ.get("ANNCUR_BENCH_DEBUG"):
+		print(f"[bench debug] per step: launch {1e3 * prof['launch'] / (args.steps + args.warmup):.3f} ms, "
+			  f"finish {1e3 * prof['finish'] / (args.steps + args.warmup):.3f} ms (of which event wait {1e3 * prof.get('wait', 0) / (args.steps + args.warmup):.3f} ms)", file=sys.stderr)
 	if world > 1:
 		t = torch.tensor([elapsed], device=device, dtype=torch.float64)
 		torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -206,6 +235,7 @@ def main():
 			"index_build_s": index_build_s,
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
 			"fused_plan": ops.fused_plan(Q, I, Kp, kr),
+			"launch_mode": "eager" if graph is None else "hipGraph replay (10 launches per step captured once)",
 		}
 
 	# ------------------------------------------------------------------ CPU baseline: the oracle (reference-faithful loop) on a bounded sample

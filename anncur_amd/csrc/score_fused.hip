@@ -61,7 +61,9 @@ struct FusedParams {
 	const uint16_t *Et;
 	int64_t Q, I;
 	int n_tiles, n_full_tiles;
-	int S, tiles_per_split;           // sweep partition of the item tiles
+	int S, tiles_per_split;           // sweep partition of the item tiles (of the current stage)
+	int tile_begin, tile_end;         // item-tile range of the current sweep stage
+	int carry;                        // 1: segment counts continue from the previous stage
 	int n_st, S0, st_per_split;       // prepass: sample tiles and their partition
 	float *gmax; int n_groups;        // prepass output [Q x n_groups]
 	const float *tau; int tau_stride; // threshold per query: tau[q * tau_stride]
@@ -102,8 +104,29 @@ __device__ __forceinline__ void tile_dma(const uint16_t *__restrict__ Et, int ti
 // Survivors go to the lane's private LDS queue (slot i of lane tid at lq[i * 256]: conflict-free, no atomics); the queues
 // are drained to the lane's HBM candidate segment by flush_queue() every FLUSH_TILES tiles with ONE store instruction per
 // queue slot for the whole wave (a store per hit made the kernel store-issue bound: ~20 sparse stores per tile per wave).
+// The queue's LDS accesses are inline asm: with a direct-to-LDS load in flight hipcc cannot prove that an ordinary LDS
+// store does not alias the DMA destination and puts s_waitcnt vmcnt(0) in front of EVERY push (measured: it serialised the
+// pushes behind the next tile's DMA and the flush stores).  The queue region is disjoint from the tile buffers; LDS
+// executes one wave's instructions in order, so a slot written by ds_write_b64 is seen by the later ds_read_b64.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+	return (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+__device__ __forceinline__ void lds_store_u64(uint32_t addr, uint32_t lo, uint32_t hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const unsigned long long d = ((unsigned long long)hi << 32) | lo;
+	asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(d) : "memory");
+#endif
+}
+__device__ __forceinline__ uint2 lds_load_u64(uint32_t addr) {
+	unsigned long long d = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d) : "v"(addr) : "memory");
+#endif
+	return make_uint2((uint32_t)d, (uint32_t)(d >> 32));
+}
+
 template <bool TAIL, int D>
-__device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint32_t item0, uint32_t n_items, uint2 *lq,
+__device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint32_t item0, uint32_t n_items, uint32_t lq,
 											  uint32_t &qcnt, uint32_t &ncand) {
 #pragma unroll
 	for (int e = 0; e < 16; ++e) {
@@ -112,7 +135,7 @@ __device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint3
 			if (v >= tau) {
 				const uint32_t item = item0 + (uint32_t)((e & 3) + 8 * (e >> 2));
 				if (!TAIL || item < n_items) {
-					if (qcnt < (uint32_t)D) { lq[qcnt * 256] = make_uint2(__float_as_uint(v), item); qcnt++; }
+					if (qcnt < (uint32_t)D) { lds_store_u64(lq + qcnt * 2048u, __float_as_uint(v), item); qcnt++; }
 					else ncand = 0x80000000u;  // queue full between two flushes (p ~ 1e-9 per window): poison the segment
 											   // count -> the select kernel recomputes this query exactly
 				}
@@ -120,10 +143,11 @@ __device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint3
 		}
 	}
 }
-__device__ __forceinline__ void flush_queue(uint2 *lq, uint32_t &qcnt, uint2 *__restrict__ seg, uint32_t &ncand, uint32_t capg) {
-	for (uint32_t i = 0; __ballot(i < qcnt) != 0ull; ++i) {
+template <int D>
+__device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *__restrict__ seg, uint32_t &ncand, uint32_t capg) {
+	for (uint32_t i = 0; __ballot(i < qcnt) != 0ull; ++i) {  // one store instruction per queue slot for the whole wave
 		if (i < qcnt) {
-			const uint2 e = lq[i * 256];
+			const uint2 e = lds_load_u64(lq + i * 2048u);
 			if (ncand < capg) seg[ncand] = e;
 			ncand++;  // (a poisoned count stays > capg)
 		}
@@ -140,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r = lane & 31, h = lane >> 5;
 	const int wid = xcd_remap(blockIdx.x, p.n_wg);
-	const int nsplit = (MODE == 0) ? p.S0 : p.S;
+	const int nsplit = (MODE == 0) ? p.S0 : p.S;  // MODE 2 = MODE 1 without the filter (debug timing)
 	const int split = wid / (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ) ;
 	const int rb = wid - split * (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ);
 	(void)nsplit;
@@ -169,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	// ---- work range
 	int j_begin, j_end;  // tile iterations
 	if (MODE == 0) { j_begin = split * p.st_per_split; j_end = min(j_begin + p.st_per_split, p.n_st); }
-	else { j_begin = split * p.tiles_per_split; j_end = min(j_begin + p.tiles_per_split, p.n_tiles); }
+	else { j_begin = p.tile_begin + split * p.tiles_per_split; j_end = min(j_begin + p.tiles_per_split, p.tile_end); }  // MODE 1 and 2
 #define tile_of(j) ((MODE == 0) ? (int)(((int64_t)(j) * p.n_full_tiles) / p.n_st) : (j))
 
 	float tau[QT];
@@ -177,12 +201,13 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 #pragma unroll
 	for (int t = 0; t < QT; ++t) {
 		tau[t] = (MODE == 1 && qv[t] < p.Q) ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
-		ncand[t] = 0; qcnt[t] = 0;
+		ncand[t] = (MODE == 1 && p.carry && qv[t] < p.Q) ? p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] : 0u;
+		qcnt[t] = 0;
 	}
 	// candidate segment of (query, lane half, split); sub-tile t adds a wave-uniform stride
 	uint2 *seg0 = p.cand + ((qv[0] * 2 + h) * (int64_t)p.S + split) * (int64_t)p.capg;
 	const int64_t seg_dt = (int64_t)32 * 2 * p.S * p.capg;
-	uint2 *lq0 = reinterpret_cast<uint2 *>(smem + 2 * Cfg::TILE_BYTES) + tid;  // slot i of sub-tile t at lq0[(t*QDEPTH + i)*256]
+	const uint32_t lq0 = lds_addr(smem + 2 * Cfg::TILE_BYTES) + (uint32_t)tid * 8u;  // slot i of sub-tile t at byte lq0 + (t*QDEPTH + i)*2048
 
 	if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 			if (--flush_in == 0) {
 				flush_in = p.flush_tiles;
 #pragma unroll
-				for (int t = 0; t < QT; ++t) flush_queue(lq0 + t * Cfg::QDEPTH * 256, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
+				for (int t = 0; t < QT; ++t) flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
 			}
 		}
 
@@ -235,13 +260,18 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 					if (qv[t] < p.Q) *reinterpret_cast<float4 *>(p.gmax + qv[t] * p.n_groups + ((int64_t)j * 2 + h) * 4) = m;
 				}
 			}
+		} else if (MODE == 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+			for (int t = 0; t < QT; ++t) asm volatile("" ::"v"(acc[t]));  // timing experiment: GEMM + staging only
+#endif
 		} else {
 			const uint32_t item0 = (uint32_t)tile * TILE_I + 4 * h;
 			const bool tail = (tile == p.n_tiles - 1) && ((p.I & (TILE_I - 1)) != 0);  // uniform
 #pragma unroll
 			for (int t = 0; t < QT; ++t) {
-				if (tail) filter_queue<true, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 256, qcnt[t], ncand[t]);
-				else filter_queue<false, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 256, qcnt[t], ncand[t]);
+				if (tail) filter_queue<true, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], ncand[t]);
+				else filter_queue<false, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], ncand[t]);
 			}
 		}
 		__builtin_amdgcn_s_waitcnt(0x0F70);  // the DMA of tile j+1 (and the queue stores issued with it) have landed
@@ -252,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	if (MODE == 1) {
 #pragma unroll
 		for (int t = 0; t < QT; ++t) {
-			flush_queue(lq0 + t * Cfg::QDEPTH * 256, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
+			flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
 			if (qv[t] < p.Q) p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] = ncand[t];
 		}
 	}
@@ -339,10 +369,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 constexpr int WQ_CAP = 1024;
 constexpr int WQ_TRIGGER = WQ_CAP - WAVE;
 
+// TAU_ONLY (between sweep stages): no output, the query's threshold is raised to the k-th best candidate collected so far.
+template <bool TAU_ONLY>
 __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg,
 														   int capg, int64_t Q, uint32_t k, float *__restrict__ out_val,
 														   int32_t *__restrict__ out_idx, uint32_t *__restrict__ hard_cnt,
-														   int32_t *__restrict__ hard_list) {
+														   int32_t *__restrict__ hard_list, float *__restrict__ tau, int tau_stride) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id(), wave = threadIdx.x >> 6;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -356,8 +388,8 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 	}
 	const uint32_t total = __shfl(inc, WAVE - 1), pre = inc - c;
 	if (__ballot(c > (uint32_t)capg) != 0ull || total < k) {
-		if (lane == 0) hard_list[atomicAdd(hard_cnt, 1u)] = (int32_t)q;
-		return;
+		if (!TAU_ONLY && lane == 0) hard_list[atomicAdd(hard_cnt, 1u)] = (int32_t)q;
+		return;  // TAU_ONLY: keep the old (still valid) threshold
 	}
 	WaveSel w = wsel_init<WQ_CAP>(smem + wave * WaveSelLayout<WQ_CAP>::BYTES);
 	const uint2 *qc = cand + q * nseg * (int64_t)capg;
@@ -377,6 +409,11 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 		wsel_offer(w, in, __uint_as_float(e.x), e.y);
 		if (w.cnt > (uint32_t)WQ_TRIGGER) wsel_compact<4, false>(w, k);
 	}
+	if (TAU_ONLY) {
+		if (w.cnt > k) wsel_compact<4, false>(w, k);
+		if (lane == 0 && w.cnt >= k) tau[q * tau_stride] = fmaxf(tau[q * tau_stride], w.tau);
+		return;
+	}
 	wsel_finish(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
 
@@ -384,6 +421,7 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 struct FusedPlan {
 	bool ok;
 	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
+	int n_stages, stage_end[3], stage_tps[3], stage_flush[3];
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, total;
 };
 
@@ -444,6 +482,26 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k) {
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
 	int ft = (int)(0.5 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
+	// sweep stages: after the first 10 % and 40 % of the item tiles the threshold is raised to the k-th best candidate seen
+	// so far (wave-level kernel), which cuts the survivors ~2.6x.  Needs the wave-level selector (k <= 128, <= 64 segments).
+	{
+		const double frac[3] = {0.10, 0.40, 1.0};
+		const bool staged = k <= WSEL_K && 2 * P.S <= WAVE && P.n_tiles >= 24 * P.S;
+		P.n_stages = staged ? 3 : 1;
+		double rate = exp_hits / ((double)P.n_tiles * 2.0);  // expected hits per (query half, tile) in the first stage
+		int prev = 0;
+		for (int i = 0; i < P.n_stages; ++i) {
+			int end = staged ? (int)(frac[i] * P.n_tiles + 0.5) : P.n_tiles;
+			if (i == P.n_stages - 1) end = P.n_tiles;
+			P.stage_end[i] = end;
+			P.stage_tps[i] = (end - prev + P.S - 1) / P.S;
+			int ft = (int)(0.5 / (rate > 1e-9 ? rate : 1e-9));
+			P.stage_flush[i] = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
+			// next stage: threshold = k-th best of the fraction seen so far
+			rate = (double)k / ((double)end * TILE_I) * 16.0 * 1.2;
+			prev = end;
+		}
+	}
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
@@ -466,6 +524,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
 	p.n_tiles = P.n_tiles; p.n_full_tiles = P.n_full; p.S = P.S; p.tiles_per_split = P.tiles_per_split;
+	p.tile_begin = 0; p.tile_end = P.n_tiles; p.carry = 0;
 	p.n_st = P.n_st; p.S0 = P.S0; p.st_per_split = P.st_per_split;
 	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
 	float *tval = (float *)(ws + P.off_tval);
@@ -495,17 +554,34 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	}
 	if (rc != ANNCUR_OK) return rc;
 	EV(2);
-	// 3. sweep
+	// 3. sweep, in stages; between stages the thresholds are raised from the candidates collected so far
 	p.n_wg = P.n_rb * P.S;
 	{
 		static bool attr_set = false;
 		if (!attr_set) {
 			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)score_kernel<KP, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WaveSelLayout<WQ_CAP>::BYTES));
+			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WaveSelLayout<WQ_CAP>::BYTES));
 			attr_set = true;
 		}
 	}
-	hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
-	ANNCUR_LAUNCH_OK();
+	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
+		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
+		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
+		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
+		if (getenv("ANNCUR_DEBUG_GEMM_ONLY")) {  // timing experiment only (no candidates are produced)
+			hipLaunchKernelGGL((score_kernel<KP, 2, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+		} else {
+			hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+		}
+		ANNCUR_LAUNCH_OK();
+		if (stg + 1 < P.n_stages) {
+			hipLaunchKernelGGL((select_wave_kernel<true>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
+							   p.seg_cnt, 2 * P.S, P.capg, Q, (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
+							   (int32_t *)nullptr, const_cast<float *>(p.tau), p.tau_stride);
+			ANNCUR_LAUNCH_OK();
+		}
+	}
 	EV(3);
 	// 4. select
 	const int nseg = 2 * P.S;
@@ -528,13 +604,8 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (k <= 128 && nseg <= WAVE) {
 		int32_t *hl = (int32_t *)(ws + P.off_hard);
 		uint32_t *hc = (uint32_t *)(ws + 4);
-		static bool wsel_attr = false;
-		if (!wsel_attr) {
-			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WaveSelLayout<WQ_CAP>::BYTES));
-			wsel_attr = true;
-		}
-		hipLaunchKernelGGL(select_wave_kernel, dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand, p.seg_cnt, nseg,
-						   P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl);
+		hipLaunchKernelGGL((select_wave_kernel<false>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
+						   p.seg_cnt, nseg, P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl, (float *)nullptr, 0);
 		ANNCUR_LAUNCH_OK();
 		hard_list = hl; hard_cnt = hc;
 		sel_grid = (unsigned)(Q < 1024 ? Q : 1024);

@@ -1,0 +1,139 @@
+"""CPU-only checks: the C-ABI library exports exactly what include/anncur_hip.h declares, host logic against the oracle,
+row-sharding over gloo (world_size 2), error behaviour without a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+	src = open(os.path.join(ROOT, "include", "anncur_hip.h")).read()
+	src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+	return sorted(set(re.findall(r"\b(anncur_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+	from anncur_amd import _lib
+	lib = _lib.load()                       # loads without a GPU
+	declared = _header_functions()
+	assert len(declared) >= 15
+	for name in declared:
+		assert hasattr(lib, name), f"{name} declared in include/anncur_hip.h but not exported"
+	assert sorted(_lib.SIGNATURES) == declared, "ctypes SIGNATURES and the header disagree"
+	out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+	exported = sorted(set(re.findall(r" T (anncur_[a-z0-9_]+)", out)))
+	assert set(declared) <= set(exported)
+	assert lib.anncur_version() >= 1 and lib.anncur_last_error() is not None
+
+
+def test_no_compute_without_gpu_and_plan_queries_work():
+	from anncur_amd import _lib, ops
+	lib = _lib.load()
+	assert lib.anncur_score_topk_supported(10000, 100000, 256, 100) == 1
+	assert lib.anncur_score_topk_supported(1000, 5000, 64, 10) == 0          # too small for a sampled threshold
+	assert lib.anncur_score_topk_supported(10000, 100000, 300, 100) == 0     # Kp must be 64/128/256/512
+	assert lib.anncur_score_topk_workspace_bytes(10000, 100000, 256, 100) > 0
+	with pytest.raises(_lib.AnncurHipError):
+		ops.rowwise_topk(torch.zeros(4, 10), 2)                               # CPU tensor: there is no CPU fallback
+	with pytest.raises(_lib.AnncurHipError):
+		ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+	assert ops.padded_k(200) == 256 and ops.padded_k(513) is None
+
+
+def test_product_never_imports_the_oracle():
+	pkg = os.path.join(ROOT, "anncur_amd")
+	offenders = []
+	for dirpath, _, files in os.walk(pkg):
+		for f in files:
+			if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dirpath, f)).read(), flags=re.M):
+				offenders.append(f)
+	for f in ("eval/run_retrieval_eval_wrt_exact_crossenc.py", "eval/run_retrieval_eval_wrt_exact_crossenc_w_fixed_train_test_splits.py",
+			  "eval/matrix_approx_zeshel.py", "models/nearest_nbr.py"):
+		if re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(ROOT, f)).read(), flags=re.M):
+			offenders.append(f)
+	assert not offenders, offenders
+
+
+def test_overlap_statistics_match_reference_format():
+	from anncur_amd.eval_utils import compute_overlap, flatten_overlap, overlap_stats_from_counts
+	from oracle import cur_oracle as O
+	rng = np.random.default_rng(0)
+	for n in (1, 7, 10, 100):
+		for Q in (1, 2, 3, 10, 1001):
+			c = rng.integers(0, n + 1, size=Q)
+			a = [list(range(n)) for _ in range(Q)]
+			b = [list(range(n - ci, 2 * n - ci)) for ci in c]
+			want = {k: tuple(v) for k, v in O.compute_overlap(a, b).items()}
+			assert overlap_stats_from_counts(c, n) == want
+			assert compute_overlap(a, b) == want
+			assert flatten_overlap(want) == O.overlap_to_flat(want)
+	assert compute_overlap([], []) == {k: tuple(v) for k, v in O.compute_overlap([], []).items()}
+	with pytest.raises(AssertionError):
+		compute_overlap([[1, 2]], [[1]])
+
+
+def test_zeshel_constants_and_filenames():
+	from utils import zeshel_utils as z
+	assert z.N_ENTS_ZESHEL["yugioh"] == 10031 and z.N_MENTS_ZESHEL["yugioh"] == 3374 and z.N_ENTS_ZESHEL["military"] == 104520
+	assert sum(z.N_MENTS_ZESHEL[w] for s, w in z.get_zeshel_world_info() if s == "test") == 10000
+	assert len(z.get_zeshel_world_info()) == 16
+	d = z.get_dataset_info("D", "R", z.get_zeshel_world_info(), n_ment=100)
+	assert d["lego"]["crossenc_ment_to_ent_scores"] == "R/lego/ment_to_ent_scores_n_m_100_n_e_10076_all_layers_False.pkl"
+	assert d["lego"]["ent_tokens_file"] == "D/tokenized_entities/lego_128_bert_base_uncased.npy"
+
+
+def test_cli_flags_match_the_reference():
+	for script, flags in (("eval/run_retrieval_eval_wrt_exact_crossenc.py",
+						   ["--data_name", "--bi_model_file", "--res_dir", "--n_seeds", "--plot_only", "--n_ment", "--batch_size", "--misc", "--disable_wandb"]),
+						  ("eval/run_retrieval_eval_wrt_exact_crossenc_w_fixed_train_test_splits.py",
+						   ["--data_name", "--eval_method", "--res_dir", "--test_data_file", "--train_data_file", "--n_seeds", "--bi_model_file", "--batch_size",
+							"--e2e_fname", "--n_fixed_anc_ent", "--mention_file", "--entity_file", "--mode", "--misc", "--use_wandb"])):
+		out = subprocess.run([sys.executable, os.path.join(ROOT, script), "--help"], capture_output=True, text=True, check=True).stdout
+		for f in flags:
+			assert f in out, (script, f)
+
+
+# ------------------------------------------------------------------ row sharding over gloo, world_size 2
+def _shard_worker(rank, world, port, n_rows, row_idxs, q):
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from anncur_amd.dist import ShardedScoreMatrix, gather_rows_to_rank0, shard_bounds
+	g = torch.Generator().manual_seed(0)
+	A = torch.randn(n_rows, 40, generator=g)
+	s, e = shard_bounds(n_rows, rank, world)
+	sm = ShardedScoreMatrix(A[s:e].clone(), n_rows, pack=lambda local, idx: local[torch.as_tensor(np.asarray(idx), dtype=torch.long)])
+	R = sm.anchor_rows(row_idxs)                                   # the single collective of the path
+	ok = torch.equal(R, A[row_idxs])
+	local_result = A[s:e, :3] * 2                                   # stands for per-query results of this rank's rows
+	full = gather_rows_to_rank0(local_result.contiguous(), n_rows)
+	if rank == 0:
+		ok = ok and torch.equal(full, A[:, :3] * 2)
+	q.put((rank, bool(ok)))
+	dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows,row_idxs", [(11, [0, 3, 4, 9, 10]), (8, [5, 6, 7]), (9, [])])
+def test_row_sharding_allgather_world2(n_rows, row_idxs):
+	import torch.multiprocessing as mp
+	ctx = mp.get_context("spawn")
+	q = ctx.Queue()
+	port = 29500 + (os.getpid() % 500) + n_rows
+	procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, n_rows, row_idxs, q)) for r in range(2)]
+	for p in procs: p.start()
+	res = [q.get(timeout=120) for _ in procs]
+	for p in procs: p.join(timeout=60)
+	assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_bounds_and_split():
+	from anncur_amd.dist import shard_bounds, split_sorted_indices
+	assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+	parts = split_sorted_indices([0, 2, 3, 7, 9], 10, 4)
+	assert [p.tolist() for p in parts] == [[0, 2], [0], [1], [1]]

@@ -71,7 +71,8 @@ def main():
 		raise SystemExit("bench.py needs an MI355X: anncur_amd has no CPU path")
 	torch.cuda.set_device(local_rank)
 	device = torch.device("cuda", local_rank)
-	if world > 1:
+	use_dist = world > 1 or (os.environ.get("RANK") is not None and os.environ.get("ANNCUR_BENCH_FORCE_DIST"))
+	if use_dist:
 		import torch.distributed as dist
 		dist.init_process_group("nccl", device_id=device)  # RCCL
 	if args.gpus != world and rank == 0:
@@ -87,7 +88,7 @@ def main():
 	# Every rank owns Q queries; the index matrix (anchor queries' rows) is the same on every rank.  With N > 1 it is
 	# assembled the way a row-sharded score matrix delivers it: each rank contributes Kq/N anchor rows, one all-gather.
 	A_train, A_test = synth_device(cfg, device, args.seed * 1000 + rank)
-	if world > 1:
+	if use_dist:
 		A_train = allgather_anchor_rows(A_train, cfg["Kq"], rank, world)
 	rng = np.random.default_rng(args.seed)
 	anc = sorted(rng.choice(cfg["I"], size=cfg["Ki"], replace=False))
@@ -162,7 +163,7 @@ def main():
 		return res
 
 	def barrier():
-		if world > 1:
+		if use_dist:
 			torch.distributed.barrier()
 		torch.cuda.synchronize()
 
@@ -175,7 +176,7 @@ def main():
 	if os.environ.get("ANNCUR_BENCH_DEBUG"):
 		print(f"[bench debug] per step: launch {1e3 * prof['launch'] / (args.steps + args.warmup):.3f} ms, "
 			  f"finish {1e3 * prof['finish'] / (args.steps + args.warmup):.3f} ms (of which event wait {1e3 * prof.get('wait', 0) / (args.steps + args.warmup):.3f} ms)", file=sys.stderr)
-	if world > 1:
+	if use_dist:
 		t = torch.tensor([elapsed], device=device, dtype=torch.float64)
 		torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
 		elapsed = t.item()
@@ -268,7 +269,7 @@ def main():
 		out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
 	if rank == 0:
 		print(json.dumps(out))
-	if world > 1:
+	if use_dist:
 		torch.distributed.destroy_process_group()
 
 

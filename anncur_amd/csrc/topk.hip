@@ -132,11 +132,10 @@ __global__ __launch_bounds__(SEL_THREADS) void rowwise_topk_kernel(const T *__re
 // filters against its running threshold and keeps candidates in a wave-private LDS buffer (wave_select.hpp).  The
 // threshold is seeded from the group maxima of the first 512 vectors so that only ~k (1 + ln(I/4096)) elements are ever
 // pushed.  4 rows per 256-thread workgroup, 11 KB LDS per wave.
-constexpr int WS_CAP = 1152;  // trigger at 640 candidates + at most 512 pushes per step (typical rows never compact mid-stream)
-constexpr int WS_TRIGGER = 640;
-constexpr int WS_TIE_LIMIT = 384;
+constexpr int WS_CAP = 1024;  // trigger at 512 candidates + at most 512 pushes per step (typical rows never compact mid-stream)
+constexpr int WS_TRIGGER = 512;
+constexpr int WS_TIE_LIMIT = 320;
 constexpr int WS_PF = 8;
-constexpr int WS_SEED = 8;    // seed vectors per lane (512 groups)
 
 template <typename T>
 __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
@@ -159,33 +158,45 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	const int64_t nsteps = (nvec + WAVE - 1) / WAVE;
 	int64_t s0 = 0;
 
-	if (nvec >= (int64_t)WS_SEED * WAVE) {
-		// ---- seed: the maxima of the first 512 vectors are real elements; their k best give the first threshold
-		u32x4 sv[WS_SEED];
-		int am[WS_SEED];
+	// the first WS_PF vectors of every lane: they seed the threshold AND are the first prefetch set of the stream
+	u32x4 pf[WS_PF];
 #pragma unroll
-		for (int v = 0; v < WS_SEED; ++v) sv[v] = vp[v * WAVE + lane];
+	for (int d = 0; d < WS_PF; ++d) {
+		const int64_t iv = (int64_t)d * WAVE + lane;
+		pf[d] = vp[iv < nvec ? iv : vlast];
+	}
+	const bool seeded = nvec >= (int64_t)WS_PF * WAVE;
+	if (seeded) {
+		// ---- seed: the maxima of the first 512 vectors are real elements; their k best give the first threshold.
+		// Each prefetch register is refilled with the stream's next vector as soon as it has been reduced, so the loads
+		// of the stream are in flight during the compaction below.
+		uint32_t am_packed = 0;
 #pragma unroll
-		for (int v = 0; v < WS_SEED; ++v) {
-			float m = vec_elem<T>(sv[v], 0);
-			int a = 0;
+		for (int d = 0; d < WS_PF; ++d) {
+			const u32x4 sv = pf[d];
+			const int64_t ivn = (int64_t)(WS_PF + d) * WAVE + lane;
+			pf[d] = vp[ivn < nvec ? ivn : vlast];
+			float m = vec_elem<T>(sv, 0);
+			uint32_t a = 0;
 #pragma unroll
 			for (int e = 1; e < VEC; ++e) {
-				const float x = vec_elem<T>(sv[v], e);
-				if (x > m) { m = x; a = e; }
+				const float x = vec_elem<T>(sv, e);
+				if (x > m) { m = x; a = (uint32_t)e; }
 			}
-			am[v] = a;
-			wsel_push(w, m == m, f32_sortable(m), 0xffffffffu - (uint32_t)(head + ((int64_t)v * WAVE + lane) * VEC + a));
+			am_packed |= a << (3 * d);
+			wsel_push(w, m == m, f32_sortable(m), 0xffffffffu - (uint32_t)(head + ((int64_t)d * WAVE + lane) * VEC + a));
 		}
 		if (w.cnt > k) wsel_compact<HP, false>(w, k);
 #pragma unroll
-		for (int v = 0; v < WS_SEED; ++v) {  // the other elements of those vectors (the maxima are already in)
+		for (int d = 0; d < WS_PF; ++d) {  // the other elements of those vectors (re-read: L2 hits; the maxima are already in)
+			const u32x4 sv = vp[(int64_t)d * WAVE + lane];
+			const int a = (int)((am_packed >> (3 * d)) & 7u);
 #pragma unroll
 			for (int e = 0; e < VEC; ++e)
-				wsel_offer(w, e != am[v], vec_elem<T>(sv[v], e), (uint32_t)(head + ((int64_t)v * WAVE + lane) * VEC + e));
+				wsel_offer(w, e != a, vec_elem<T>(sv, e), (uint32_t)(head + ((int64_t)d * WAVE + lane) * VEC + e));
 			if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, false>(w, k);
 		}
-		s0 = WS_SEED;
+		s0 = WS_PF;
 	}
 	{  // unaligned head (fewer than VEC elements); exact composite compare: the seed broke the index order
 		const bool in = lane < head;
@@ -193,12 +204,6 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, false>(w, k);
 	}
 	// ---- stream (strictly increasing indices from here on: one float compare per element is exact)
-	u32x4 pf[WS_PF];
-#pragma unroll
-	for (int d = 0; d < WS_PF; ++d) {
-		const int64_t iv = (s0 + d) * WAVE + lane;
-		pf[d] = vp[iv < nvec ? iv : vlast];
-	}
 	for (; s0 < nsteps; s0 += WS_PF) {
 #pragma unroll
 		for (int d = 0; d < WS_PF; ++d) {  // steps past the row are masked, never branched around (keeps the prefetch registers PHI-free)

@@ -69,6 +69,7 @@ struct FusedParams {
 	const float *tau; int tau_stride; // threshold per query: tau[q * tau_stride]
 	uint2 *cand; uint32_t *seg_cnt; int capg;
 	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
+	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
 	int n_wg;                         // grid size (for the XCD remap)
 };
@@ -125,6 +126,23 @@ __device__ __forceinline__ uint2 lds_load_u64(uint32_t addr) {
 	return make_uint2((uint32_t)d, (uint32_t)(d >> 32));
 }
 
+// One accumulator element of the filter (element index e is a compile-time constant after unrolling).  item_lim = number of
+// items for the matrix' last, partial tile and 0xffffffff otherwise: the bound check sits in the (rare) hit path only.
+template <int D>
+__device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t item0, uint32_t item_lim, uint32_t lq, uint32_t &qcnt,
+											uint32_t &ncand) {
+	if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
+		if (v >= tau) {
+			const uint32_t item = item0 + (uint32_t)((e & 3) + 8 * (e >> 2));
+			if (item < item_lim) {
+				if (qcnt < (uint32_t)D) { lds_store_u64(lq + qcnt * 2048u, __float_as_uint(v), item); qcnt++; }
+				else ncand = 0x80000000u;  // queue full between two flushes (p ~ 1e-9 per window): poison the segment count
+										   // -> the select kernel recomputes this query exactly
+			}
+		}
+	}
+}
+
 template <bool TAIL, int D>
 __device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint32_t item0, uint32_t n_items, uint32_t lq,
 											  uint32_t &qcnt, uint32_t &ncand) {
@@ -148,7 +166,7 @@ __device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *
 	for (uint32_t i = 0; __ballot(i < qcnt) != 0ull; ++i) {  // one store instruction per queue slot for the whole wave
 		if (i < qcnt) {
 			const uint2 e = lds_load_u64(lq + i * 2048u);
-			if (ncand < capg) seg[ncand] = e;
+			if (ncand < capg) seg[ncand] = e;  // (capg = 0 in the no-store timing experiment)
 			ncand++;  // (a poisoned count stays > capg)
 		}
 	}
@@ -213,6 +231,71 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
 
+	if constexpr (MODE == 1 && QT == 2) {
+		// ---- staggered sweep: the wave's two 32-query sub-tiles run half a tile apart.  While the MFMA chain of one sub-tile
+		// executes on the matrix pipe, the threshold filter of the OTHER sub-tile's finished accumulator is issued element by
+		// element in the MFMA shadow (one accumulator register per k-step at Kp = 256).  Same registers as the plain loop.
+		constexpr int EPS = 16 / KSTEPS > 0 ? 16 / KSTEPS : 1;      // filter elements per k-step (Kp = 64: 4, 128: 2, 256: 1)
+		static_assert(KSTEPS <= 16, "staggered path needs at most 16 k-steps");
+		f32x16 acc0, acc1;
+#pragma unroll
+		for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+		float tau1_prev = INFINITY;  // no previous tile yet: the filter of acc1 never fires
+		uint32_t item0_prev = 0, lim_prev = 0xffffffffu;
+		const uint32_t lq1 = lq0 + Cfg::QDEPTH * 2048;
+		int flush_in2 = p.flush_tiles;
+		for (int j = j_begin; j < j_end; ++j) {
+			const int cur = (j - j_begin) & 1;
+			const int tile = tile_of(j);
+			const bool more = j + 1 < j_end;
+			if (more) tile_dma<KP>(p.Et, tile_of(j + 1), smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
+			if (--flush_in2 == 0) {
+				flush_in2 = p.flush_tiles;
+				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg);
+				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg);
+			}
+			const uint32_t item0 = (uint32_t)tile * TILE_I + 4 * h;
+			const uint32_t lim = ((tile == p.n_tiles - 1) && ((p.I & (TILE_I - 1)) != 0)) ? (uint32_t)p.I : 0xffffffffu;
+			const u32x4 *tb = reinterpret_cast<const u32x4 *>(smem + cur * Cfg::TILE_BYTES);
+			// phase A: sub-tile 0 of this tile  ||  filter of sub-tile 1 of the previous tile
+			{
+				f32x16 acc = {0};
+				u32x4 an = tb[r * CPR + swz<CPR>(r, h)];
+#pragma unroll
+				for (int s = 0; s < KSTEPS; ++s) {
+					const bf16x8 a = __builtin_bit_cast(bf16x8, an);
+					if (s + 1 < KSTEPS) an = tb[r * CPR + swz<CPR>(r, 2 * (s + 1) + h)];
+					acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][s], acc, 0, 0, 0);
+#pragma unroll
+					for (int e = s * EPS; e < (s + 1) * EPS; ++e)
+						filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lim_prev, lq1, qcnt[1], ncand[1]);
+				}
+				acc0 = acc;
+			}
+			// phase B: sub-tile 1 of this tile  ||  filter of sub-tile 0 of this tile
+			{
+				f32x16 acc = {0};
+				u32x4 an = tb[r * CPR + swz<CPR>(r, h)];
+#pragma unroll
+				for (int s = 0; s < KSTEPS; ++s) {
+					const bf16x8 a = __builtin_bit_cast(bf16x8, an);
+					if (s + 1 < KSTEPS) an = tb[r * CPR + swz<CPR>(r, 2 * (s + 1) + h)];
+					acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[1][s], acc, 0, 0, 0);
+#pragma unroll
+					for (int e = s * EPS; e < (s + 1) * EPS; ++e)
+						filter_one<Cfg::QDEPTH>(acc0[e], e, tau[0], item0, lim, lq0, qcnt[0], ncand[0]);
+				}
+				acc1 = acc;
+			}
+			tau1_prev = tau[1]; item0_prev = item0; lim_prev = lim;
+			__builtin_amdgcn_s_waitcnt(0x0F70);
+			__syncthreads();
+		}
+		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg);  // keep one tile's hits per queue window
+#pragma unroll
+		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
+			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lim_prev, lq1, qcnt[1], ncand[1]);
+	} else {
 	int flush_in = p.flush_tiles;
 	for (int j = j_begin; j < j_end; ++j) {
 		const int cur = (j - j_begin) & 1;
@@ -277,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		__builtin_amdgcn_s_waitcnt(0x0F70);  // the DMA of tile j+1 (and the queue stores issued with it) have landed
 		__syncthreads();
 	}
+	}  // plain loop
 
 #undef tile_of
 	if (MODE == 1) {
@@ -532,6 +616,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.tau = tval + (k - 1); p.tau_stride = k;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	{ const char *dbg = getenv("ANNCUR_DEBUG_TAU_BIAS"); p.tau_bias = dbg ? (float)atof(dbg) : 0.f; }
+	if (getenv("ANNCUR_DEBUG_NOSTORE")) p.capg = 0;  // timing experiment: every candidate is dropped at the store (results invalid)
 
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
 	EV(0);

@@ -17,31 +17,44 @@ def _fmt(mean, std, p50):
 
 def overlap_stats_from_counts(common, n):
 	"""`common`: per-query |set1 & set2| (array-like), `n`: the common list length.  Returns the
-	reference's dict {metric: ("mean x", "std x", "p50 x")} (np.mean / population np.std / np.percentile 50).
+	reference's dict {metric: ("mean x", "std x", "p50 x")} (np.mean / population np.std / np.percentile 50)."""
+	return overlap_stats_batch(np.asarray(common, dtype=np.int64)[None, :], [n])[0]
 
-	diff = n - common and total = n are affine in `common`, so their statistics follow exactly (integer sums are
-	exact in float64); the two *_frac metrics are computed on common / n directly, as the reference does."""
-	common = np.asarray(common, dtype=np.int64)
-	if common.size == 0:
-		return {m: ("mean 0.0", "std 0.0", "p50 0.0") for m in _METRICS}
-	c = common.astype(np.float64)
-	mean_c, std_c = float(np.mean(c)), float(np.std(c))
-	half = c.size // 2                       # median = the reference's np.percentile(..., 50) (linear interpolation)
-	part = np.partition(c, [half - 1, half] if c.size > 1 else [0])
-	lo, hi = (part[half - 1], part[half]) if c.size % 2 == 0 else (part[half], part[half])
-	lo, hi = float(lo), float(hi)
-	p50_c = _median_pair(lo, hi)
-	cf, df = c / n, (n - c) / n
-	nc = n - c
-	p50_cf = _median_pair(lo / n, hi / n)
-	p50_df = _median_pair((n - hi) / n, (n - lo) / n)
-	return {
-		"common": _fmt(mean_c, std_c, p50_c),
-		"diff": _fmt(float(np.mean(nc)), float(np.std(nc)), _median_pair(n - hi, n - lo)),
-		"total": _fmt(float(n), 0.0, float(n)),
-		"common_frac": _fmt(float(np.mean(cf)), float(np.std(cf)), p50_cf),
-		"diff_frac": _fmt(float(np.mean(df)), float(np.std(df)), p50_df),
-	}
+
+def overlap_stats_batch(counts, ns):
+	"""Statistics for several (top_k, k_retvr) cells at once: counts [n_cells, Q] ints, ns[j] = list length of cell j.
+
+	All five metrics are affine in `common` (diff = n - c, total = n, *_frac = ./n), so one mean / std / median of `common`
+	per cell gives every number: mean and median transform exactly; std is invariant under c -> n - c and scales by 1/n.
+	(In floating point the derived values can differ from a direct np.std on the transformed array in the last ulp; after the
+	reference's 4-decimal formatting that is invisible -- tests/test_cpu_host.py checks equality with the reference-faithful
+	oracle on random inputs.)"""
+	counts = np.asarray(counts, dtype=np.int64)
+	n_cells, Q = counts.shape
+	if Q == 0:
+		return [{m: ("mean 0.0", "std 0.0", "p50 0.0") for m in _METRICS} for _ in range(n_cells)]
+	out = []
+	for j in range(n_cells):
+		n = float(ns[j])
+		# counts are small integers (0..n): everything follows from their histogram -- exact integer sums for the mean, the
+		# two middle order statistics for numpy's linearly interpolated median, sum h[v] (v - mean)^2 for the population std
+		h = np.bincount(counts[j], minlength=int(ns[j]) + 1)
+		v = np.arange(h.size, dtype=np.float64)
+		m = float((h * v).sum() / Q)
+		sd = float(np.sqrt((h * (v - m) ** 2).sum() / Q))
+		cum = np.cumsum(h)
+		hi_rank = Q // 2                          # 0-based ranks of the two middle order statistics
+		lo_rank = hi_rank - 1 if Q % 2 == 0 else hi_rank
+		l = float(np.searchsorted(cum, lo_rank + 1))
+		hh = float(np.searchsorted(cum, hi_rank + 1))
+		out.append({
+			"common": _fmt(m, sd, _median_pair(l, hh)),
+			"diff": _fmt(n - m, sd, _median_pair(n - hh, n - l)),
+			"total": _fmt(n, 0.0, n),
+			"common_frac": _fmt(m / n, sd / n, _median_pair(l / n, hh / n)),
+			"diff_frac": _fmt((n - m) / n, sd / n, _median_pair((n - hh) / n, (n - l) / n)),
+		})
+	return out
 
 
 def compute_overlap(indices_list1, indices_list2):

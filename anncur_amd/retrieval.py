@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .eval_utils import flatten_overlap, overlap_stats_from_counts
+from .eval_utils import flatten_overlap, overlap_stats_batch, overlap_stats_from_counts
 
 
 def exact_topk(A_dev, k):

@@ -80,7 +80,7 @@ def main():
 
 	from anncur_amd import _lib, ops
 	from anncur_amd.cur import CURApprox
-	from anncur_amd.eval_utils import flatten_overlap, overlap_stats_from_counts
+	from anncur_amd.eval_utils import flatten_overlap, overlap_stats_batch, overlap_stats_from_counts
 	from anncur_amd.dist import allgather_anchor_rows
 	_lib.load()
 
@@ -145,7 +145,8 @@ def main():
 			pass
 		prof["wait"] = prof.get("wait", 0.0) + time.perf_counter() - t_a
 		c = np.array(pinned[slot].numpy())  # one memcpy out of the pinned (uncached-for-the-CPU) buffer, then the statistics
-		return {t: flatten_overlap(overlap_stats_from_counts(c[j], t)) for j, (t, _) in enumerate(cells)}
+		stats = overlap_stats_batch(c, [t for t, _ in cells])
+		return {t: flatten_overlap(stats[j]) for j, (t, _) in enumerate(cells)}
 
 	def run_steps(n):
 		res, pending = None, None

@@ -419,6 +419,14 @@ __global__ __launch_bounds__(256) void convert_kernel(const TS *__restrict__ src
 	if (c < n_cols) dst[r * ldd + c] = cvt<TS, TD>(src[r * lds_ + c]);
 }
 
+// dst may be mapped (pinned) host memory: 16-byte coalesced writes over the host link, no copy engine involved
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+														  const unsigned char *__restrict__ src_tail, unsigned char *__restrict__ dst_tail, int n_tail) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n16) dst[i] = src[i];
+	if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 template <typename F>
 int dispatch2(int sd, int dd, F &&f) {
 	if (sd == ANNCUR_F32 && dd == ANNCUR_F32) return f((const float *)nullptr, (float *)nullptr);
@@ -602,6 +610,20 @@ extern "C" int anncur_convert(const void *src, int src_dtype, int64_t lds_, void
 			return 0;
 		});
 	}
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_copy_bytes(const void *src, void *dst, size_t nbytes, void *stream) {
+	ANNCUR_REQUIRE(src && dst, ANNCUR_E_INVALID, "copy_bytes: null pointer");
+	ANNCUR_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, ANNCUR_E_INVALID, "copy_bytes: pointers must be 16-byte aligned");
+	if (nbytes == 0) return ANNCUR_OK;
+	const size_t n16 = nbytes / 16;
+	const int n_tail = (int)(nbytes % 16);
+	const size_t blocks = (n16 + 255) / 256;
+	ANNCUR_REQUIRE(blocks < (size_t)0x7fffffff, ANNCUR_E_INVALID, "copy_bytes: too large");
+	hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16,
+					   (const unsigned char *)src + n16 * 16, (unsigned char *)dst + n16 * 16, n_tail);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -279,3 +279,16 @@ def overlap_counts(a, b, pairs):
 		check(lib.anncur_overlap_counts(_p(a), a.shape[1], _p(b), b.shape[1], Q, ka, kb, len(chunk), _p(out[s:s + len(chunk)]), _stream()),
 			  "overlap_counts")
 	return out
+
+
+def copy_to_mapped_host(src, pinned_host):
+	"""Device kernel copy of `src` (CUDA tensor) into a PINNED host tensor (mapped into the device address space by the HIP
+	runtime): graph-capturable, no copy engine.  The caller synchronises (event) before reading `pinned_host`."""
+	_dev(src)
+	if pinned_host.is_cuda or not pinned_host.is_pinned() or not pinned_host.is_contiguous():
+		raise ValueError("copy_to_mapped_host needs a contiguous pinned host tensor")
+	src = src.contiguous()
+	nbytes = src.numel() * src.element_size()
+	if nbytes != pinned_host.numel() * pinned_host.element_size():
+		raise ValueError("size mismatch")
+	check(_lib.load().anncur_copy_bytes(_p(src), ctypes.c_void_p(pinned_host.data_ptr()), nbytes, _stream()), "copy_bytes")

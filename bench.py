@@ -17,6 +17,11 @@ import os
 import sys
 import time
 
+# The GPU box gives this process a CPU quota of ~16 cores on a 256-core host: BLAS / OpenMP pools sized for 256 threads
+# (numpy.linalg.pinv in the index build, torch CPU ops) spin inside that quota and get the launching thread throttled.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+	os.environ.setdefault(_v, "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
@@ -69,6 +74,7 @@ def main():
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	if not torch.cuda.is_available():
 		raise SystemExit("bench.py needs an MI355X: anncur_amd has no CPU path")
+	torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
 	torch.cuda.set_device(local_rank)
 	device = torch.device("cuda", local_rank)
 	use_dist = world > 1 or (os.environ.get("RANK") is not None and os.environ.get("ANNCUR_BENCH_FORCE_DIST"))
@@ -121,21 +127,23 @@ def main():
 
 	# The ten launches of a step are captured once into a HIP graph and replayed: per-dispatch latency on a busy host
 	# otherwise dominates (the kernels of a step total ~1.6 ms).  --no-graph keeps the eager launches.
-	graph, static_counts = None, None
+	# The counts reach the host through a copy kernel that writes into mapped pinned memory (inside the graph): a step is ONE
+	# graph replay, with no copy-engine hop whose cross-queue dependency a busy host would have to resolve.
+	graphs = None
 	if not args.no_graph:
-		gpu_step(); torch.cuda.synchronize()                           # allocate the workspace / load code objects outside capture
-		static_counts = torch.empty((len(cells), Q), dtype=torch.int32, device=device)
-		graph = torch.cuda.CUDAGraph()
-		with torch.cuda.graph(graph):
-			static_counts.copy_(gpu_step())
+		ops.copy_to_mapped_host(gpu_step(), pinned[0]); torch.cuda.synchronize()   # workspace / code objects loaded outside capture
+		graphs = []
+		for slot in range(2):
+			g = torch.cuda.CUDAGraph()
+			with torch.cuda.graph(g):
+				ops.copy_to_mapped_host(gpu_step(), pinned[slot])
+			graphs.append(g)
 
 	def launch(slot):
-		if graph is not None:
-			graph.replay()
-			counts = static_counts
+		if graphs is not None:
+			graphs[slot].replay()
 		else:
-			counts = gpu_step()
-		pinned[slot].copy_(counts, non_blocking=True)
+			ops.copy_to_mapped_host(gpu_step(), pinned[slot])
 		events[slot].record()
 		return slot
 
@@ -143,8 +151,10 @@ def main():
 		t_a = time.perf_counter()
 		while not events[slot].query():  # spin: a blocking wait can add milliseconds of wake-up latency on a busy host
 			pass
-		prof["wait"] = prof.get("wait", 0.0) + time.perf_counter() - t_a
+		t_b = time.perf_counter()
+		prof["wait"] = prof.get("wait", 0.0) + t_b - t_a
 		c = np.array(pinned[slot].numpy())  # one memcpy out of the pinned (uncached-for-the-CPU) buffer, then the statistics
+		prof["memcpy"] = prof.get("memcpy", 0.0) + time.perf_counter() - t_b
 		stats = overlap_stats_batch(c, [t for t, _ in cells])
 		return {t: flatten_overlap(stats[j]) for j, (t, _) in enumerate(cells)}
 
@@ -176,7 +186,7 @@ def main():
 	elapsed = time.perf_counter() - t0
 	if os.environ.get("ANNCUR_BENCH_DEBUG"):
 		print(f"[bench debug] per step: launch {1e3 * prof['launch'] / (args.steps + args.warmup):.3f} ms, "
-			  f"finish {1e3 * prof['finish'] / (args.steps + args.warmup):.3f} ms (of which event wait {1e3 * prof.get('wait', 0) / (args.steps + args.warmup):.3f} ms)", file=sys.stderr)
+			  f"finish {1e3 * prof['finish'] / (args.steps + args.warmup):.3f} ms (of which event wait {1e3 * prof.get('wait', 0) / (args.steps + args.warmup):.3f} ms, pinned memcpy {1e3 * prof.get('memcpy', 0) / (args.steps + args.warmup):.3f} ms)", file=sys.stderr)
 	if use_dist:
 		t = torch.tensor([elapsed], device=device, dtype=torch.float64)
 		torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -237,7 +247,7 @@ def main():
 			"index_build_s": index_build_s,
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
 			"fused_plan": ops.fused_plan(Q, I, Kp, kr),
-			"launch_mode": "eager" if graph is None else "hipGraph replay (10 launches per step captured once)",
+			"launch_mode": "eager" if graphs is None else "hipGraph replay (the step's launches captured once per result slot)",
 		}
 
 	# ------------------------------------------------------------------ CPU baseline: the oracle (reference-faithful loop) on a bounded sample

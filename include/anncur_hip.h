@@ -143,6 +143,11 @@ int anncur_overlap_counts(const int32_t *a, int32_t la, const int32_t *b, int32_
 int anncur_convert(const void *src, int src_dtype, int64_t lds_, void *dst, int dst_dtype, int64_t ldd,
                    int64_t n_rows, int64_t n_cols, void *stream);
 
+/* Device-side byte copy (16-byte vector stores); `dst` may be mapped pinned HOST memory, so small per-step results
+ * (the 4*Q overlap counts the reference's statistics are computed from, eval/eval_utils.py:131-136) reach the host from inside a
+ * captured graph without a copy-engine hop.  src / dst 16-byte aligned. */
+int anncur_copy_bytes(const void *src, void *dst, size_t nbytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

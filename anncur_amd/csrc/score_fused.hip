@@ -651,6 +651,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		}
 	}
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
+		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
@@ -660,6 +661,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		}
 		ANNCUR_LAUNCH_OK();
+		EV(6 + 2 * stg);
 		if (stg + 1 < P.n_stages) {
 			hipLaunchKernelGGL((select_wave_kernel<true>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
 							   p.seg_cnt, 2 * P.S, P.capg, Q, (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
@@ -748,16 +750,25 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 									   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 									   void *stream, float *stage_ms) {
 	ANNCUR_REQUIRE(stage_ms, ANNCUR_E_INVALID, "score_topk_timed: stage_ms is null");
-	hipEvent_t ev[5];
-	for (int i = 0; i < 5; ++i) ANNCUR_HIP_OK(hipEventCreate(&ev[i]));
+	constexpr int NEV = 11;  // 0..4 stage boundaries, 5..10 begin/end of up to three sweep launches
+	hipEvent_t ev[NEV];
+	for (int i = 0; i < NEV; ++i) ANNCUR_HIP_OK(hipEventCreate(&ev[i]));
+	const FusedPlan P = plan_fused(Q, I, Kp, k);
 	int rc = score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, ev);
 	if (rc == ANNCUR_OK) {
 		hipError_t e = hipEventSynchronize(ev[4]);
 		if (e != hipSuccess) { anncur_set_error("hipEventSynchronize: %s", hipGetErrorString(e)); rc = ANNCUR_E_HIP; }
 		for (int i = 0; i < 4 && rc == ANNCUR_OK; ++i)
 			if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) { anncur_set_error("hipEventElapsedTime failed"); rc = ANNCUR_E_HIP; }
+		stage_ms[4] = 0.f;
+		for (int g = 0; g < P.n_stages && rc == ANNCUR_OK; ++g) {
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, ev[5 + 2 * g], ev[6 + 2 * g]) != hipSuccess) { anncur_set_error("hipEventElapsedTime failed"); rc = ANNCUR_E_HIP; }
+			stage_ms[4] += ms;
+		}
+		stage_ms[5] = (float)P.n_stages;
 	}
-	for (int i = 0; i < 5; ++i) (void)hipEventDestroy(ev[i]);
+	for (int i = 0; i < NEV; ++i) (void)hipEventDestroy(ev[i]);
 	return rc;
 }
 

@@ -213,7 +213,8 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False):
 
 
 def score_topk_fused_timed(Xp, Etp, I, k):
-	"""Measurement only: (TopK, [prepass, threshold, sweep, select] in ms) from HIP events on the launch stream."""
+	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches]) in ms,
+	from HIP events on the launch stream."""
 	_dev(Xp, Etp)
 	Q, Kp = Xp.shape
 	lib = _lib.load()
@@ -223,7 +224,7 @@ def score_topk_fused_timed(Xp, Etp, I, k):
 	ws = _Workspace.get(nbytes, Xp.device)
 	val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
-	ms = (ctypes.c_float * 4)()
+	ms = (ctypes.c_float * 6)()
 	check(lib.anncur_score_topk_timed(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes, _stream(), ms),
 		  "score_topk_timed")
 	return TopK(val, idx), [float(x) for x in ms]

@@ -195,7 +195,7 @@ def main():
 	value = world * Q * args.steps / elapsed
 
 	# ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
-	stage = np.zeros(4)
+	stage = np.zeros(6)
 	Xq = ops.gather_cols(A_test, anc_dev)
 	if Xq.shape[1] != Kp:
 		Xq = ops.pack_bf16(Xq, Kp)
@@ -212,8 +212,10 @@ def main():
 		torch.cuda.synchronize()
 		gath_ms += ev[0].elapsed_time(ev[1]) / n_prof
 		scan_ms += ev[2].elapsed_time(ev[3]) / n_prof
-	sweep_flops = 2.0 * Q * Kp * I
-	sweep_tflops = sweep_flops / (stage[2] * 1e-3) / 1e12
+	n_sweep = max(1, int(round(stage[5])))                 # the sweep runs as n_sweep launches of the same kernel (threshold refined in between)
+	sweep_flops = 2.0 * Q * Kp * I / n_sweep               # algorithmic flops per launch (average over the stages)
+	sweep_ms = stage[4] / n_sweep                          # average launch duration of score_kernel<Kp,sweep>
+	sweep_tflops = sweep_flops / (sweep_ms * 1e-3) / 1e12
 	scan_bytes = Q * I * 2 + Q * k * 8
 	traffic = None
 	tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -238,11 +240,11 @@ def main():
 			"recall": recall,
 			"roofline": {"bound": "mfma", "kernel": f"score_kernel<{Kp},sweep> (fused S_hat GEMM + threshold filter)",
 						 "achieved": sweep_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": sweep_tflops / PEAK_BF16_TFLOPS,
-						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(stage[2])},
+						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(sweep_ms), "launches_per_step": n_sweep},
 			"roofline_scan": {"bound": "hbm", "kernel": "rowwise_topk_kernel<bf16,128> (exact top-k scan)",
 							  "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
 							  "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
-			"stage_ms": {"gather_cols": gath_ms, "prepass": float(stage[0]), "threshold": float(stage[1]), "sweep": float(stage[2]),
+			"stage_ms": {"gather_cols": gath_ms, "prepass": float(stage[0]), "threshold": float(stage[1]), "sweep": float(stage[2]), "sweep_kernels_only": float(stage[4]),
 						 "select": float(stage[3]), "exact_scan": scan_ms},
 			"index_build_s": index_build_s,
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),

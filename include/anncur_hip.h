@@ -114,8 +114,10 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* Measurement only: same as anncur_score_topk but records HIP events on `stream` between the four
- * launches, synchronises, and returns their durations in stage_ms[4] (host floats, milliseconds):
- * {prepass, threshold, sweep, select}.  bench.py's live roofline figure comes from stage_ms[2]. */
+ * launches, synchronises, and returns their durations in stage_ms[6] (host floats, milliseconds):
+ * {prepass, threshold, sweep stage (sweep launches + the threshold refinements between them), select,
+ *  sum of the sweep-kernel launches alone, number of sweep launches}.  bench.py's live roofline figure is
+ *  (2*Q*Kp*I / launches) / (stage_ms[4] / launches). */
 int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t lde,
                             int64_t Q, int64_t I, int32_t Kp, int32_t k,
                             float *out_val, int32_t *out_idx,

@@ -16,12 +16,12 @@ E = (torch.randn(a.K, 64, generator=g, device=dev) @ Z / 8 / 16 + 0.003 * torch.
 Kp = ops.padded_k(a.K)
 Xp = ops.pack_bf16(X, Kp); Etp = ops.pack_bf16(E.t().contiguous(), Kp, row_multiple=32)
 print("plan", ops.fused_plan(a.Q, a.I, Kp, a.k))
-acc = np.zeros(4)
+acc = np.zeros(6)
 for i in range(a.iters + 2):
 	(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, a.I, a.k)
 	if i >= 2: acc += np.array(ms)
 acc /= a.iters
-print("stage_ms prepass/threshold/sweep/select:", [round(x, 4) for x in acc], "sweep TFLOP/s: %.1f" % (2.0 * a.Q * Kp * a.I / (acc[2] * 1e-3) / 1e12))
+print("stage_ms prepass/threshold/sweep-stage/select/sweep-kernels/n:", [round(float(x), 4) for x in acc], "sweep kernels TFLOP/s: %.1f" % (2.0 * a.Q * Kp * a.I / (acc[4] * 1e-3) / 1e12))
 print("fallbacks:", int(ops._Workspace._bufs[("cuda", 0)][(-ops._Workspace._bufs[("cuda", 0)].data_ptr()) % 256:][:4].view(torch.int32).item()))
 if a.scan:
 	A = torch.randn(a.Q, a.I, generator=g, device=dev).bfloat16()

@@ -177,3 +177,36 @@ class CURApprox(object):
 	def approx_error_rows(self, sparse_rows, exact_rows):
 		"""Per-row sum (S_hat - A)^2 and sum A^2 (a11) without materialising S_hat."""
 		return ops.approx_error(self._to_dev(sparse_rows), self._Et, self._to_dev(exact_rows))
+
+
+class CURRowIndex(object):
+	"""The "rows"-preference index alone: built from the anchor rows R [kr x m] and the anchor columns' ids, without the
+	(n x kc) matrix of every query's anchor scores.  This is what a rank of a row-sharded evaluation holds: R assembled by one
+	all-gather, U = pinv(R[:, col_idxs]) and E = U.R replicated, its own queries' anchor scores gathered locally.
+	Same arithmetic as CURApprox(rows=R, cols=A[:, col_idxs], ...) (eval/matrix_approx_zeshel.py:42-65)."""
+
+	def __init__(self, rows, col_idxs, compute_dtype=None):
+		self.R = rows
+		self.m = rows.shape[1]
+		self.col_idxs = col_idxs
+		if compute_dtype is None:
+			compute_dtype = "bf16" if rows.dtype == torch.bfloat16 else "fp32"
+		self.compute_dtype = compute_dtype
+		W = ops.gather_cols(rows, col_idxs)                      # kr x kc
+		self.U = _pinv_host(W).to(rows.device)                   # kc x kr
+		self._Et = ops.gemm(rows.t(), self.U.t())                # m x kc
+		kp = ops.padded_k(self._Et.shape[1])
+		self._Etp = ops.pack_bf16(self._Et, kp, row_multiple=32) if (compute_dtype == "bf16" and kp is not None) else None
+
+	def topk(self, X, k):
+		"""X [q x kc]: the queries' exact scores against the anchor items -> (values f32, indices int32) on the GPU."""
+		Q = X.shape[0]
+		if self._Etp is not None and ops.fused_supported(Q, self.m, self._Etp.shape[1], k):
+			return ops.score_topk_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, self.m, k)
+		Et = self._Et if self.compute_dtype == "fp32" or self._Etp is None else self._Etp[:self.m, :X.shape[1]]
+		if self.compute_dtype == "bf16" and X.dtype != torch.bfloat16:
+			X = ops.convert(X, torch.bfloat16)
+		return ops.score_topk_dense(X, Et, k)
+
+	def approx_error_rows(self, X, exact_rows):
+		return ops.approx_error(X, self._Et, exact_rows)

@@ -48,8 +48,19 @@ def allgather_rows(local_block, counts, group=None):
 		return local_block.new_empty((0, I))
 	send = local_block.new_zeros((cmax, I))
 	send[:counts[rank]] = local_block
-	recv = local_block.new_empty((world * cmax, I))
+	# RCCL ("nccl") moves device tensors directly over xGMI.  The gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal)
+	# cannot: stage through the host there.
+	staged = local_block.is_cuda and dist.get_backend(group) == "gloo"
+	if staged:
+		send = send.cpu()
+		if send.dtype == torch.bfloat16:
+			send = send.view(torch.int16)
+	recv = send.new_empty((world * cmax, I))
 	dist.all_gather_into_tensor(recv, send, group=group)
+	if staged:
+		if local_block.dtype == torch.bfloat16:
+			recv = recv.view(torch.bfloat16)
+		recv = recv.to(local_block.device)
 	if all(c == cmax for c in counts):
 		return recv
 	return torch.cat([recv[r * cmax: r * cmax + counts[r]] for r in range(world)], dim=0)

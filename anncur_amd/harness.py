@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .cur import CURApprox
+from .cur import CURApprox, CURRowIndex
 from .eval_utils import flatten_overlap, overlap_stats_from_counts
 
 LOGGER = logging.getLogger(__name__)
@@ -94,6 +94,72 @@ def run_approx_eval(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, 
 			for metric, val in d.items():
 				acc[ment_type][metric].append(float(val))
 	return {t: {m: float(np.mean(v)) for m, v in d.items()} for t, d in acc.items()}
+
+
+def run_approx_eval_w_seed_sharded(sharded, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed):
+	"""Method "cur" of entry point A on a ROW-SHARDED score matrix (anncur_amd.dist.ShardedScoreMatrix): every rank holds a
+	contiguous block of query rows.  One all-gather assembles the anchor rows; the index is replicated; each rank retrieves,
+	scans and counts for its own rows; rank 0 receives the ordered per-query counts / error terms and returns the same dict as
+	run_approx_eval_w_seed (None on the other ranks).  No collective on the per-query path."""
+	from .dist import gather_rows_to_rank0
+	A_loc, n_ments = sharded.local, sharded.n_rows
+	n_ents = A_loc.shape[1]
+	rng = np.random.default_rng(seed=seed)
+	row_idxs = _select(rng, n_ments, n_ment_anchors)
+	col_idxs = _select(rng, n_ents, n_ent_anchors)
+	R = sharded.anchor_rows(row_idxs)                                  # the one exchange: [Kq x I] on every rank
+	index = CURRowIndex(R, col_idxs)
+	X_loc = ops.gather_cols(A_loc, col_idxs)
+	approx = index.topk(X_loc, top_k_retvr)
+	exact = ops.rowwise_topk(A_loc, top_k)
+	counts = ops.overlap_counts(exact.indices, approx.indices, [(top_k, top_k_retvr)])[0]
+	err_sq, norm_sq = index.approx_error_rows(X_loc, A_loc)
+	packed = torch.stack([counts.float(), err_sq, norm_sq], dim=1).contiguous()      # [n_loc x 3]
+	full = gather_rows_to_rank0(packed, n_ments, sharded.group)
+	if full is None:
+		return None
+	full = full.double().cpu().numpy()
+	counts_all, err_all, norm_all = full[:, 0].round().astype(np.int64), full[:, 1], full[:, 2]
+	non_anchor = sorted(set(range(n_ments)) - set(int(i) for i in row_idxs))
+
+	def score(idxs):
+		res = _subset_metrics(counts_all, idxs, top_k) if len(idxs) else flatten_overlap(overlap_stats_from_counts([], top_k))
+		ii = np.asarray(idxs, dtype=np.int64)
+		err = np.float32(np.sqrt(err_all[ii].sum()))
+		with np.errstate(invalid="ignore", divide="ignore"):
+			res["approx_error"] = err
+			res["approx_error_relative"] = err / np.float32(np.sqrt(norm_all[ii].sum()))
+		return res
+
+	return {"anchor": score(row_idxs), "non_anchor": score(non_anchor), "all": score(list(range(n_ments)))}
+
+
+def run_entry_A_sharded(sharded, grids, n_seeds, progress=None):
+	"""run_entry_A for a row-sharded matrix (method "cur" only: "cur_oracle" needs the whole matrix on one device).
+	Rank 0 returns the result dict, the other ranks None."""
+	from .dist import dist
+	is_root = dist.get_rank(sharded.group) == 0
+	n_ment, n_ent = sharded.n_rows, sharded.local.shape[1]
+	res = defaultdict(lambda: defaultdict(lambda: defaultdict(dict)))
+	cells = list(itertools.product(grids["top_k_vals"], grids["top_k_retr_vals"], grids["n_ment_anchors_vals"], grids["n_ent_anchors_vals"]))
+	for ctr, (top_k, kr, nm, ne) in enumerate(cells):
+		if kr < top_k or kr > n_ent or nm > n_ment or ne > n_ent:
+			continue
+		if progress and is_root:
+			progress("cur", ctr, len(cells))
+		acc = defaultdict(lambda: defaultdict(list))
+		for seed in range(n_seeds):
+			out = run_approx_eval_w_seed_sharded(sharded, nm, ne, top_k, kr, seed)
+			if is_root:
+				for ment_type, d in out.items():
+					for metric, val in d.items():
+						acc[ment_type][metric].append(float(val))
+		if is_root:
+			res["cur"][f"top_k={top_k}"][f"k_retvr={kr}"][f"anc_n_m={nm}~anc_n_e={ne}"] = \
+				{t: {m: float(np.mean(v)) for m, v in d.items()} for t, d in acc.items()}
+	if not is_root:
+		return None
+	return {m: {a: {b: dict(c) for b, c in d.items()} for a, d in v.items()} for m, v in res.items()}
 
 
 def default_grids_A(total_n_ment, total_n_ent):

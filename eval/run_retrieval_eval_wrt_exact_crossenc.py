@@ -70,12 +70,31 @@ def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overri
 	Path(res_dir).mkdir(exist_ok=True, parents=True)
 	other_args = {"arg_dict": arg_dict, "top_k_vals": grids["top_k_vals"], "top_k_retr_vals": grids["top_k_retr_vals"],
 				  "n_ent_anchors_vals": grids["n_ent_anchors_vals"], "n_ment_anchors_vals": grids["n_ment_anchors_vals"]}
+	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if not plot_only:
-		A_dev = harness.to_device_matrix(scores, device, dtype)
 		def progress(method, ctr, n):
 			if ctr % max(1, n // 10) == 0:
 				LOGGER.info(f"method={method}: cell {ctr}/{n}")
-		eval_res = harness.run_entry_A(A_dev, grids, n_seeds, progress)
+		if world > 1:
+			# launched with torchrun: one process per GPU, the matrix row-sharded, one RCCL all-gather of the anchor rows per index
+			import torch.distributed as dist
+			from anncur_amd.dist import ShardedScoreMatrix, shard_bounds
+			local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+			device = torch.device("cuda", local_rank)
+			torch.cuda.set_device(device)
+			if not dist.is_initialized():
+				dist.init_process_group(os.environ.get("ANNCUR_DIST_BACKEND", "nccl"))
+			s, e = shard_bounds(total_n_ment, dist.get_rank(), world)
+			sharded = ShardedScoreMatrix(harness.to_device_matrix(scores[s:e], device, dtype), total_n_ment)
+			if "cur_oracle" in grids["eval_methods"]:
+				LOGGER.info("row-sharded run: only method=cur is evaluated (cur_oracle needs the whole matrix on one device)")
+			grids["eval_methods"] = ["cur"]
+			eval_res = harness.run_entry_A_sharded(sharded, grids, n_seeds, progress)
+			if eval_res is None:          # ranks > 0 are done
+				return res_dir
+		else:
+			A_dev = harness.to_device_matrix(scores, device, dtype)
+			eval_res = harness.run_entry_A(A_dev, grids, n_seeds, progress)
 		eval_res["other_args"] = other_args
 		with open(f"{res_dir}/retrieval_wrt_exact_crossenc.json", "w") as fout:
 			json.dump(obj=eval_res, fp=fout, indent=4)

@@ -130,3 +130,39 @@ def test_flat_ip_index_matches_exact_search(gpu, n, d, nq, k, dtype):
 	assert common > 0.999
 	if k > n:
 		assert (I[:, n:] == -1).all() and np.isinf(D[:, n:]).all()
+
+
+# ------------------------------------------------------------------ row-sharded evaluation: 2 ranks sharing the one GPU, gloo
+def _sharded_worker(rank, world, port, q):
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from anncur_amd import harness
+	from anncur_amd.dist import ShardedScoreMatrix, shard_bounds
+	torch.manual_seed(0)
+	A = torch.randn(1000, 32) @ torch.randn(32, 5000) / (32 ** 0.5) + 0.1 * torch.randn(1000, 5000)
+	s, e = shard_bounds(1000, rank, world)
+	sm = ShardedScoreMatrix(A[s:e].cuda(), 1000)
+	res = harness.run_approx_eval_w_seed_sharded(sm, 128, 64, 10, 100, seed=1)
+	if rank == 0:
+		single = harness.run_approx_eval_w_seed("cur", A.cuda(), 128, 64, 10, 100, seed=1)
+		q.put({t: {m: (float(res[t][m]), float(single[t][m])) for m in res[t]} for t in res})
+	else:
+		assert res is None
+		q.put(None)
+	dist.destroy_process_group()
+
+
+def test_row_sharded_entry_A_equals_single_process(gpu):
+	import torch.multiprocessing as mp
+	ctx = mp.get_context("spawn")
+	q = ctx.Queue()
+	port = 29700 + os.getpid() % 200
+	procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+	for p in procs: p.start()
+	outs = [q.get(timeout=300) for _ in procs]
+	for p in procs: p.join(timeout=60)
+	res = [o for o in outs if o is not None][0]
+	for t in ("anchor", "non_anchor", "all"):
+		for m, (sharded, single) in res[t].items():
+			assert sharded == pytest.approx(single, rel=1e-5, abs=1e-6), (t, m)

@@ -41,19 +41,8 @@ PEAK_HBM_GBS = 8000.0
 
 def synth_device(cfg, device, seed):
 	"""Protocol-B synthetic matrices on the device: shared item factors, low rank + noise, bf16 storage."""
-	g = torch.Generator(device=device).manual_seed(seed)
-	r = 64
-	Z = torch.randn(r, cfg["I"], generator=g, device=device)
-	def make(n, chunk=2048):
-		out = torch.empty(n, cfg["I"], dtype=torch.bfloat16, device=device)
-		for s in range(0, n, chunk):
-			e = min(n, s + chunk)
-			out[s:e] = (torch.randn(e - s, r, generator=g, device=device) @ Z / r ** 0.5
-						+ 0.05 * torch.randn(e - s, cfg["I"], generator=g, device=device)).to(torch.bfloat16)
-		return out
-	A_train = make(cfg["Kq"])
-	A_test = make(cfg["Q"])
-	return A_train, A_test
+	from anncur_amd.synth import protocol_b
+	return protocol_b(cfg["Kq"], cfg["Q"], cfg["I"], device, seed=seed)
 
 
 def main():

@@ -137,3 +137,22 @@ def test_shard_bounds_and_split():
 	assert [shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
 	parts = split_sorted_indices([0, 2, 3, 7, 9], 10, 4)
 	assert [p.tolist() for p in parts] == [[0, 2], [0], [1], [1]]
+
+
+def test_split_producer_matches_reference_kat(tmp_path, golden_dir):
+	import json, pickle
+	from utils import split_zeshel_ment2ent_for_cur_exps as sp
+	n_m, n_e = 130, 40
+	dump = {"ment_to_ent_scores": torch.arange(n_m * n_e, dtype=torch.float32).reshape(n_m, n_e), "test_data": [{"id": i} for i in range(n_m)],
+			"mention_tokens_list": [[i, i + 1] for i in range(n_m)], "entity_id_list": [], "entity_tokens_list": [], "arg_dict": {"a": 1}}
+	with open(tmp_path / "m2e.pkl", "wb") as f:
+		pickle.dump(dump, f)
+	sp.run("yugioh", str(tmp_path / "m2e.pkl"), [50, 100, 200], 2, 7, 0.1, str(tmp_path / "out"))
+	kat = json.load(open(os.path.join(golden_dir, "split_kat.json")))["splits"]
+	for key, want in kat.items():
+		nm, si, name = key.split("/")
+		with open(tmp_path / "out" / f"nm_train={nm}" / f"split_idx={si}" / f"{name}.pkl", "rb") as f:
+			d = pickle.load(f)
+		assert [int(x) for x in d["ment_idxs"]] == want["ment_idxs"], key
+		assert float(d["ment_to_ent_scores"][0, 0]) == want["first_score"] and sorted(d.keys()) == want["keys"]
+	assert not (tmp_path / "out" / "nm_train=200").exists()     # more train mentions than there are: skipped

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		// ---- staggered sweep: the wave's two 32-query sub-tiles run half a tile apart.  While the MFMA chain of one sub-tile
 		// executes on the matrix pipe, the threshold filter of the OTHER sub-tile's finished accumulator is issued element by
 		// element in the MFMA shadow (one accumulator register per k-step at Kp = 256).  Same registers as the plain loop.
+		constexpr int AR = 3;                                       // A-fragment prefetch distance (k-steps)
 		constexpr int EPS = 16 / KSTEPS > 0 ? 16 / KSTEPS : 1;      // filter elements per k-step (Kp = 64: 4, 128: 2, 256: 1)
 		static_assert(KSTEPS <= 16, "staggered path needs at most 16 k-steps");
 		f32x16 acc0, acc1;
@@ -260,11 +261,14 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 			// phase A: sub-tile 0 of this tile  ||  filter of sub-tile 1 of the previous tile
 			{
 				f32x16 acc = {0};
-				u32x4 an = tb[r * CPR + swz<CPR>(r, h)];
+				u32x4 ring[AR];  // A fragments, AR k-steps ahead: one step of MFMA + filter does not cover the LDS latency
+#pragma unroll
+				for (int i = 0; i < AR; ++i)
+					if (i < KSTEPS) ring[i] = tb[r * CPR + swz<CPR>(r, 2 * i + h)];
 #pragma unroll
 				for (int s = 0; s < KSTEPS; ++s) {
-					const bf16x8 a = __builtin_bit_cast(bf16x8, an);
-					if (s + 1 < KSTEPS) an = tb[r * CPR + swz<CPR>(r, 2 * (s + 1) + h)];
+					const bf16x8 a = __builtin_bit_cast(bf16x8, ring[s % AR]);
+					if (s + AR < KSTEPS) ring[s % AR] = tb[r * CPR + swz<CPR>(r, 2 * (s + AR) + h)];
 					acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][s], acc, 0, 0, 0);
 #pragma unroll
 					for (int e = s * EPS; e < (s + 1) * EPS; ++e)
@@ -275,11 +279,14 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 			// phase B: sub-tile 1 of this tile  ||  filter of sub-tile 0 of this tile
 			{
 				f32x16 acc = {0};
-				u32x4 an = tb[r * CPR + swz<CPR>(r, h)];
+				u32x4 ring[AR];  // A fragments, AR k-steps ahead: one step of MFMA + filter does not cover the LDS latency
+#pragma unroll
+				for (int i = 0; i < AR; ++i)
+					if (i < KSTEPS) ring[i] = tb[r * CPR + swz<CPR>(r, 2 * i + h)];
 #pragma unroll
 				for (int s = 0; s < KSTEPS; ++s) {
-					const bf16x8 a = __builtin_bit_cast(bf16x8, an);
-					if (s + 1 < KSTEPS) an = tb[r * CPR + swz<CPR>(r, 2 * (s + 1) + h)];
+					const bf16x8 a = __builtin_bit_cast(bf16x8, ring[s % AR]);
+					if (s + AR < KSTEPS) ring[s % AR] = tb[r * CPR + swz<CPR>(r, 2 * (s + AR) + h)];
 					acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[1][s], acc, 0, 0, 0);
 #pragma unroll
 					for (int e = s * EPS; e < (s + 1) * EPS; ++e)

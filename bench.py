@@ -134,12 +134,18 @@ def main():
 	graphs = None
 	if not args.no_graph:
 		ops.copy_to_mapped_host(gpu_step(), pinned[0]); torch.cuda.synchronize()   # workspace / code objects loaded outside capture
-		graphs = []
-		for slot in range(2):
-			g = torch.cuda.CUDAGraph()
-			with torch.cuda.graph(g):
-				ops.copy_to_mapped_host(gpu_step(), pinned[slot])
-			graphs.append(g)
+		try:
+			graphs = []
+			for slot in range(2):
+				g = torch.cuda.CUDAGraph()
+				# thread_local: other threads of the process (the RCCL watchdog of a multi-rank run) may touch the runtime meanwhile
+				with torch.cuda.graph(g, capture_error_mode="thread_local"):
+					ops.copy_to_mapped_host(gpu_step(), pinned[slot])
+				graphs.append(g)
+		except Exception as exc:  # never lose the measurement to a capture problem: fall back to eager launches
+			print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
+			graphs = None
+			torch.cuda.synchronize()
 
 	def launch(slot):
 		if graphs is not None:

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		const int cur = (j - j_begin) & 1;
 		const int tile = tile_of(j);
 		const bool more = j + 1 < j_end;
-		if (more) tile_dma<KP>(p.Et, tile_of(j + 1), smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
+		if (more && MODE != 3) tile_dma<KP>(p.Et, tile_of(j + 1), smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
 		if (MODE == 1) {
 			// drain the hit queues of the previous tiles right behind the DMA: the stores get the whole MFMA phase to retire
 			if (--flush_in == 0) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 					if (qv[t] < p.Q) *reinterpret_cast<float4 *>(p.gmax + qv[t] * p.n_groups + ((int64_t)j * 2 + h) * 4) = m;
 				}
 			}
-		} else if (MODE == 2) {
+		} else if (MODE == 2 || MODE == 3) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 			for (int t = 0; t < QT; ++t) asm volatile("" ::"v"(acc[t]));  // timing experiment: GEMM + staging only
@@ -364,8 +364,10 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 				else filter_queue<false, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], ncand[t]);
 			}
 		}
-		__builtin_amdgcn_s_waitcnt(0x0F70);  // the DMA of tile j+1 (and the queue stores issued with it) have landed
-		__syncthreads();
+		if (MODE != 3) {
+			__builtin_amdgcn_s_waitcnt(0x0F70);  // the DMA of tile j+1 (and the queue stores issued with it) have landed
+			__syncthreads();
+		}
 	}
 	}  // plain loop
 
@@ -662,7 +664,9 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
-		if (getenv("ANNCUR_DEBUG_GEMM_ONLY")) {  // timing experiment only (no candidates are produced)
+		if (getenv("ANNCUR_DEBUG_GEMM_NOSYNC")) {  // timing experiment only: MFMA + LDS fragment reads, no staging, no barriers
+			hipLaunchKernelGGL((score_kernel<KP, 3, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+		} else if (getenv("ANNCUR_DEBUG_GEMM_ONLY")) {  // timing experiment only (no candidates are produced)
 			hipLaunchKernelGGL((score_kernel<KP, 2, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		} else {
 			hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);

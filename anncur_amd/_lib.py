@@ -25,6 +25,10 @@ SIGNATURES = {
 	"anncur_gather_rows": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_int, c_int64, c_void_p]),
 	"anncur_gemm": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64,
 							c_int64, c_int64, c_int64, c_void_p]),
+	"anncur_gemm_ex": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64,
+							   c_int64, c_int64, c_int64, ctypes.c_float, ctypes.c_float, c_void_p, c_int64, c_int64, c_void_p]),
+	"anncur_sumsq": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+	"anncur_scale_copy": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, ctypes.c_float, c_void_p, c_void_p]),
 	"anncur_approx_error": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64,
 									c_int64, c_void_p, c_void_p, c_void_p]),
 	"anncur_rowwise_topk": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

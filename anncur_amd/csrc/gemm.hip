@@ -59,7 +59,8 @@ template <typename TA, typename TB, typename TC, int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const TA *__restrict__ A, int64_t a_sm, int64_t a_sk,
 													const TB *__restrict__ B, int64_t b_sk, int64_t b_sn,
 													TC *__restrict__ C, int64_t c_sm, int64_t c_sn, int64_t M, int64_t N,
-													int64_t K, float *__restrict__ err_sq, float *__restrict__ norm_sq) {
+													int64_t K, float *__restrict__ err_sq, float *__restrict__ norm_sq, float alpha,
+													float beta, const float *__restrict__ Cin, int64_t i_sm, int64_t i_sn) {
 	__shared__ float As[BK * LDT];
 	__shared__ float Bs[BK * LDT];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -119,7 +120,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const TA *__restrict__ A, int
 #pragma unroll
 				for (int j = 0; j < 2; ++j) {
 					const int64_t gn = n0 + wn * 64 + j * 32 + r;
-					if (gm < M && gn < N) st_elem<TC>(C, gm * c_sm + gn * c_sn, acc[i][j][e]);
+					if (gm < M && gn < N) {
+						float v = alpha * acc[i][j][e];
+						if (Cin) v += beta * Cin[gm * i_sm + gn * i_sn];   // out = alpha * A.B + beta * Cin (Cin fp32, may alias C element-wise)
+						st_elem<TC>(C, gm * c_sm + gn * c_sn, v);
+					}
 				}
 			} else {
 				// C doubles as the exact matrix (same strides); reduce (acc - exact)^2 and exact^2 over the row segment
@@ -163,9 +168,9 @@ int dispatch3(int ad, int bd, int cd, F &&f) {
 
 }  // namespace
 
-extern "C" int anncur_gemm(const void *A, int a_dtype, int64_t a_sm, int64_t a_sk, const void *B, int b_dtype,
-						   int64_t b_sk, int64_t b_sn, void *C, int c_dtype, int64_t c_sm, int64_t c_sn, int64_t M,
-						   int64_t N, int64_t K, void *stream) {
+extern "C" int anncur_gemm_ex(const void *A, int a_dtype, int64_t a_sm, int64_t a_sk, const void *B, int b_dtype,
+							  int64_t b_sk, int64_t b_sn, void *C, int c_dtype, int64_t c_sm, int64_t c_sn, int64_t M,
+							  int64_t N, int64_t K, float alpha, float beta, const float *Cin, int64_t i_sm, int64_t i_sn, void *stream) {
 	ANNCUR_REQUIRE(dtype_ok(a_dtype) && dtype_ok(b_dtype) && dtype_ok(c_dtype), ANNCUR_E_INVALID, "gemm: bad dtype");
 	ANNCUR_REQUIRE(M >= 0 && N >= 0 && K >= 0, ANNCUR_E_INVALID, "gemm: negative dimension");
 	ANNCUR_REQUIRE(A && B && C, ANNCUR_E_INVALID, "gemm: null pointer");
@@ -178,11 +183,17 @@ extern "C" int anncur_gemm(const void *A, int a_dtype, int64_t a_sm, int64_t a_s
 		using TB = std::remove_cv_t<std::remove_pointer_t<decltype(b)>>;
 		using TC = std::remove_pointer_t<decltype(c)>;
 		hipLaunchKernelGGL((gemm_kernel<TA, TB, TC, 0>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, (const TA *)A, a_sm,
-						   a_sk, (const TB *)B, b_sk, b_sn, (TC *)C, c_sm, c_sn, M, N, K, (float *)nullptr, (float *)nullptr);
+						   a_sk, (const TB *)B, b_sk, b_sn, (TC *)C, c_sm, c_sn, M, N, K, (float *)nullptr, (float *)nullptr, alpha, beta, Cin, i_sm, i_sn);
 		return 0;
 	});
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
+}
+
+extern "C" int anncur_gemm(const void *A, int a_dtype, int64_t a_sm, int64_t a_sk, const void *B, int b_dtype,
+						   int64_t b_sk, int64_t b_sn, void *C, int c_dtype, int64_t c_sm, int64_t c_sn, int64_t M,
+						   int64_t N, int64_t K, void *stream) {
+	return anncur_gemm_ex(A, a_dtype, a_sm, a_sk, B, b_dtype, b_sk, b_sn, C, c_dtype, c_sm, c_sn, M, N, K, 1.0f, 0.0f, nullptr, 0, 0, stream);
 }
 
 extern "C" int anncur_approx_error(const void *X, int x_dtype, int64_t ldx, const void *Et, int e_dtype, int64_t lde,
@@ -204,9 +215,50 @@ extern "C" int anncur_approx_error(const void *X, int x_dtype, int64_t ldx, cons
 		// A operand = X (m = query, k), B operand: B(k, n) = Et[n][k]; "C" = exact matrix, read-only in MODE 1
 		hipLaunchKernelGGL((gemm_kernel<TA, TB, TC, 1>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, (const TA *)X, ldx,
 						   (int64_t)1, (const TB *)Et, (int64_t)1, lde, (TC *)const_cast<void *>(Aex), lda, (int64_t)1, Q, I, K, err_sq,
-						   norm_sq);
+						   norm_sq, 1.0f, 0.0f, (const float *)nullptr, (int64_t)0, (int64_t)0);
 		return 0;
 	});
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+// ------------------------------------------------------------------ small helpers for the on-device pseudo-inverse
+namespace {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ A, int64_t n_rows, int64_t n_cols, int64_t lda, float *__restrict__ out) {
+	float acc = 0.f;
+	const int64_t total = n_rows * n_cols;
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+		const float v = A[(i / n_cols) * lda + (i % n_cols)];
+		acc += v * v;
+	}
+	for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+	if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float *__restrict__ src, int64_t s0, int64_t s1, float *__restrict__ dst, int64_t d0,
+														  int64_t d1, int64_t M, int64_t N, float alpha, const float *__restrict__ inv_scale) {
+	const float a = inv_scale ? alpha / inv_scale[0] : alpha;
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < M * N) dst[(i / N) * d0 + (i % N) * d1] = a * src[(i / N) * s0 + (i % N) * s1];
+}
+}  // namespace
+
+extern "C" int anncur_sumsq(const float *A, int64_t n_rows, int64_t n_cols, int64_t lda, float *out, void *stream) {
+	ANNCUR_REQUIRE(A && out && n_rows >= 0 && n_cols >= 0 && lda >= n_cols, ANNCUR_E_INVALID, "sumsq: bad arguments");
+	hipStream_t st = (hipStream_t)stream;
+	ANNCUR_HIP_OK(hipMemsetAsync(out, 0, 4, st));
+	if (n_rows * n_cols == 0) return ANNCUR_OK;
+	const int64_t blocks = ceil_div64(n_rows * n_cols, 256 * 8);
+	hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, A, n_rows, n_cols, lda, out);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_scale_copy(const float *src, int64_t s0, int64_t s1, float *dst, int64_t d0, int64_t d1, int64_t M, int64_t N, float alpha,
+								 const float *divide_by, void *stream) {
+	ANNCUR_REQUIRE(src && dst && M >= 0 && N >= 0, ANNCUR_E_INVALID, "scale_copy: bad arguments");
+	if (M * N == 0) return ANNCUR_OK;
+	hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)ceil_div64(M * N, 256)), dim3(256), 0, (hipStream_t)stream, src, s0, s1, dst, d0, d1, M, N, alpha,
+					   divide_by);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

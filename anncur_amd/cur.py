@@ -37,14 +37,26 @@ def _pinv_host(M):
 	return torch.from_numpy(np.linalg.pinv(M.detach().float().cpu().numpy()))
 
 
+def _pinv(M, device, backend):
+	"""backend "numpy": the reference's own call on the host (U bit-identical to the reference).
+	backend "device": Newton-Schulz on the GPU (anncur_amd/pinv.py), for large anchor counts."""
+	if backend == "numpy":
+		return _pinv_host(M).to(device)
+	if backend == "device":
+		from .pinv import pinv_newton_schulz
+		return pinv_newton_schulz(M.to(device))
+	raise ValueError(f"pinv_backend = {backend} not supported")
+
+
 def _is_full_range(idx, n):
 	return len(idx) == n and n > 0 and int(idx[0]) == 0 and int(idx[-1]) == n - 1
 
 
 class CURApprox(object):
 
-	def __init__(self, rows, cols, row_idxs, col_idxs, approx_preference, A=None, compute_dtype=None, device=None):
+	def __init__(self, rows, cols, row_idxs, col_idxs, approx_preference, A=None, compute_dtype=None, device=None, pinv_backend="numpy"):
 		super(CURApprox, self).__init__()
+		self.pinv_backend = pinv_backend
 		if device is None:
 			device = rows.device if (torch.is_tensor(rows) and rows.is_cuda) else torch.device("cuda", torch.cuda.current_device())
 		self.device = torch.device(device)
@@ -74,10 +86,10 @@ class CURApprox(object):
 
 		if A is not None:  # oracle U = C^+ A R^+  (:46-47), products left to right on the GPU
 			A_dev = self._to_dev(A)
-			CpA = ops.gemm(_pinv_host(self.C).to(self.device), A_dev)            # kc x m
-			self.U = ops.gemm(CpA, _pinv_host(self.R).to(self.device))          # kc x kr
+			CpA = ops.gemm(_pinv(self.C, self.device, pinv_backend), A_dev)       # kc x m
+			self.U = ops.gemm(CpA, _pinv(self.R, self.device, pinv_backend))     # kc x kr
 		else:
-			self.U = _pinv_host(intersect_mat).to(self.device)                  # kc x kr  (:49)
+			self.U = _pinv(intersect_mat, self.device, pinv_backend)             # kc x kr  (:49)
 
 		self._Et = None   # [m x kc] fp32: latent_cols transposed ("rows" preference)
 		self._Etp = None  # bf16 packed copy for the fused kernel
@@ -185,7 +197,7 @@ class CURRowIndex(object):
 	all-gather, U = pinv(R[:, col_idxs]) and E = U.R replicated, its own queries' anchor scores gathered locally.
 	Same arithmetic as CURApprox(rows=R, cols=A[:, col_idxs], ...) (eval/matrix_approx_zeshel.py:42-65)."""
 
-	def __init__(self, rows, col_idxs, compute_dtype=None):
+	def __init__(self, rows, col_idxs, compute_dtype=None, pinv_backend="numpy"):
 		self.R = rows
 		self.m = rows.shape[1]
 		self.col_idxs = col_idxs
@@ -193,7 +205,7 @@ class CURRowIndex(object):
 			compute_dtype = "bf16" if rows.dtype == torch.bfloat16 else "fp32"
 		self.compute_dtype = compute_dtype
 		W = ops.gather_cols(rows, col_idxs)                      # kr x kc
-		self.U = _pinv_host(W).to(rows.device)                   # kc x kr
+		self.U = _pinv(W, rows.device, pinv_backend)             # kc x kr
 		self._Et = ops.gemm(rows.t(), self.U.t())                # m x kc
 		kp = ops.padded_k(self._Et.shape[1])
 		self._Etp = ops.pack_bf16(self._Et, kp, row_multiple=32) if (compute_dtype == "bf16" and kp is not None) else None

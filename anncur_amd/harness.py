@@ -47,7 +47,7 @@ def _subset_metrics(counts_row, rows, k):
 
 
 # ------------------------------------------------------------------------------------------------ entry point A
-def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed, exact_cache=None):
+def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed, exact_cache=None, pinv_backend="numpy"):
 	"""One seed of one grid cell -> {"anchor": {...}, "non_anchor": {...}, "all": {...}} (crossenc.py:47-158)."""
 	n_ments, n_ents = A_dev.shape
 	rng = np.random.default_rng(seed=seed)
@@ -57,9 +57,9 @@ def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, 
 	cols = ops.gather_cols(A_dev, col_idxs)
 	non_anchor = sorted(set(range(n_ments)) - set(int(i) for i in row_idxs))
 	if approx_method == "cur":
-		cur = CURApprox(rows=rows, cols=cols, row_idxs=row_idxs, col_idxs=col_idxs, approx_preference="rows")
+		cur = CURApprox(rows=rows, cols=cols, row_idxs=row_idxs, col_idxs=col_idxs, approx_preference="rows", pinv_backend=pinv_backend)
 	elif approx_method == "cur_oracle":
-		cur = CURApprox(rows=rows, cols=cols, row_idxs=row_idxs, col_idxs=col_idxs, approx_preference="rows", A=A_dev)
+		cur = CURApprox(rows=rows, cols=cols, row_idxs=row_idxs, col_idxs=col_idxs, approx_preference="rows", A=A_dev, pinv_backend=pinv_backend)
 	else:
 		raise NotImplementedError(f"approx_method = {approx_method} not supported")
 	approx = cur.topk_in_row_device(cols, top_k_retvr)       # approximate retrieval for EVERY query row
@@ -85,11 +85,11 @@ def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, 
 	return {"anchor": score(row_idxs), "non_anchor": score(non_anchor), "all": score(list(range(n_ments)))}
 
 
-def run_approx_eval(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, n_seeds, exact_cache=None):
+def run_approx_eval(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, n_seeds, exact_cache=None, pinv_backend="numpy"):
 	"""Mean over seeds (crossenc.py:162-200)."""
 	acc = defaultdict(lambda: defaultdict(list))
 	for seed in range(n_seeds):
-		res = run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed, exact_cache)
+		res = run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed, exact_cache, pinv_backend)
 		for ment_type, d in res.items():
 			for metric, val in d.items():
 				acc[ment_type][metric].append(float(val))
@@ -173,7 +173,7 @@ def default_grids_A(total_n_ment, total_n_ent):
 	}
 
 
-def run_entry_A(A_dev, grids, n_seeds, progress=None):
+def run_entry_A(A_dev, grids, n_seeds, progress=None, pinv_backend="numpy"):
 	"""-> res[method]["top_k=.."]["k_retvr=.."]["anc_n_m=..~anc_n_e=.."][anchor|non_anchor|all][metric]  (crossenc.py:349-383)."""
 	total_n_ment, total_n_ent = A_dev.shape
 	res = defaultdict(lambda: defaultdict(lambda: defaultdict(dict)))
@@ -188,7 +188,7 @@ def run_entry_A(A_dev, grids, n_seeds, progress=None):
 			if progress:
 				progress(method, ctr, len(cells))
 			res[method][f"top_k={top_k}"][f"k_retvr={kr}"][f"anc_n_m={nm}~anc_n_e={ne}"] = \
-				run_approx_eval(method, A_dev, nm, ne, top_k, kr, n_seeds, exact_cache)
+				run_approx_eval(method, A_dev, nm, ne, top_k, kr, n_seeds, exact_cache, pinv_backend)
 	return {m: {a: {b: dict(c) for b, c in d.items()} for a, d in v.items()} for m, v in res.items()}
 
 
@@ -212,7 +212,7 @@ def _sweep_cells(A_test_dev, approx_idx, exact, top_k_vals, top_k_retr_vals, n_e
 	return {cell: flatten_overlap(overlap_stats_from_counts(counts[j], cell[0])) for j, cell in enumerate(cells)}
 
 
-def run_eval_method_cur(A_test_dev, A_train_dev, seed, grids, compute_dtype=None, progress=None, key_n_m=None):
+def run_eval_method_cur(A_test_dev, A_train_dev, seed, grids, compute_dtype=None, progress=None, key_n_m=None, pinv_backend="numpy"):
 	"""eval_method == "cur" of entry point B for one seed (splits.py:286-303 + 399-429)."""
 	n_train, n_ent = A_train_dev.shape
 	top_k_vals, retr_vals, anc_vals = grids["top_k_vals"], grids["top_k_retr_vals"], grids["n_ent_anchors_vals"]
@@ -228,7 +228,7 @@ def run_eval_method_cur(A_test_dev, A_train_dev, seed, grids, compute_dtype=None
 		if progress:
 			progress(j, len(anc_vals))
 		cur = CURApprox(rows=A_train_dev, cols=ops.gather_cols(A_train_dev, anc), row_idxs=np.arange(n_train), col_idxs=anc,
-						approx_preference="rows", compute_dtype=compute_dtype)
+						approx_preference="rows", compute_dtype=compute_dtype, pinv_backend=pinv_backend)
 		approx = cur.topk_in_row_device(ops.gather_cols(A_test_dev, anc), kr_max)
 		for (k, kr), metrics in _sweep_cells(A_test_dev, approx.indices, exact, top_k_vals, retr_vals, n_ent).items():
 			res[f"top_k={k}"][f"k_retvr={kr}"][f"anc_n_m={n_train if key_n_m is None else key_n_m}_anc_n_e={n_anc}"] = metrics

@@ -96,9 +96,9 @@ def convert(src, dtype):
 
 
 # ------------------------------------------------------------------ a4/a5/a6
-def gemm(A, B, out=None, out_dtype=torch.float32):
-	"""C = A @ B for 2-D tensors with ARBITRARY strides (transposed views cost nothing);
-	fp32 products and sums (exact fmaf chains on the matrix cores)."""
+def gemm(A, B, out=None, out_dtype=torch.float32, alpha=1.0, beta=0.0, cin=None):
+	"""C = alpha * A @ B (+ beta * cin) for 2-D tensors with ARBITRARY strides (transposed views cost nothing);
+	fp32 products and sums (exact fmaf chains on the matrix cores).  cin: fp32 [M, N], may be `out` itself."""
 	_dev(A, B)
 	M, K = A.shape
 	K2, N = B.shape
@@ -112,9 +112,39 @@ def gemm(A, B, out=None, out_dtype=torch.float32):
 	for m0 in range(0, max(M, 1), 65535 * 128):  # grid.y limit of one launch
 		m1 = min(M, m0 + 65535 * 128)
 		a, c = A[m0:m1], out[m0:m1]
-		check(lib.anncur_gemm(_p(a), _dt(A), A.stride(0), A.stride(1), _p(B), _dt(B), B.stride(0), B.stride(1), _p(c), _dt(out),
-							  out.stride(0), out.stride(1), m1 - m0, N, K, _stream()), "gemm")
+		if cin is None and alpha == 1.0:
+			check(lib.anncur_gemm(_p(a), _dt(A), A.stride(0), A.stride(1), _p(B), _dt(B), B.stride(0), B.stride(1), _p(c), _dt(out),
+								  out.stride(0), out.stride(1), m1 - m0, N, K, _stream()), "gemm")
+		else:
+			if cin is not None and (cin.dtype != torch.float32 or tuple(cin.shape) != (M, N)):
+				raise ValueError("gemm: cin must be fp32 [M, N]")
+			ci = cin[m0:m1] if cin is not None else None
+			check(lib.anncur_gemm_ex(_p(a), _dt(A), A.stride(0), A.stride(1), _p(B), _dt(B), B.stride(0), B.stride(1), _p(c), _dt(out),
+									 out.stride(0), out.stride(1), m1 - m0, N, K, float(alpha), float(beta),
+									 _p(ci) if ci is not None else None, ci.stride(0) if ci is not None else 0, ci.stride(1) if ci is not None else 0,
+									 _stream()), "gemm_ex")
 	return out
+
+
+def sumsq(A, out=None):
+	"""Frobenius norm squared of an fp32 matrix -> 1-element device tensor (no host sync)."""
+	_dev(A)
+	A = _rowmajor(A)
+	if A.dtype != torch.float32:
+		raise TypeError("sumsq takes fp32")
+	out = torch.empty(1, dtype=torch.float32, device=A.device) if out is None else out
+	check(_lib.load().anncur_sumsq(_p(A), A.shape[0], A.shape[1], _ld(A), _p(out), _stream()), "sumsq")
+	return out
+
+
+def scale_copy(src, dst, alpha=1.0, divide_by=None):
+	"""dst[i, j] = alpha / divide_by[0] * src[i, j] for fp32 2-D tensors with arbitrary strides (e.g. a scaled transpose)."""
+	_dev(src, dst)
+	if src.dtype != torch.float32 or dst.dtype != torch.float32 or tuple(src.shape) != tuple(dst.shape):
+		raise ValueError("scale_copy: fp32 tensors of equal shape")
+	check(_lib.load().anncur_scale_copy(_p(src), src.stride(0), src.stride(1), _p(dst), dst.stride(0), dst.stride(1), src.shape[0], src.shape[1],
+										float(alpha), _p(divide_by) if divide_by is not None else None, _stream()), "scale_copy")
+	return dst
 
 
 def approx_error(X, Et, A_exact):

@@ -55,7 +55,7 @@ def plot(res_dir, method_vals):
 	return made
 
 
-def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overrides, dtype, device):
+def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overrides, dtype, device, pinv_backend="numpy"):
 	from anncur_amd import harness
 	data_name, data_fname = data_info
 	LOGGER.info("Loading precomputed ment_to_ent scores")
@@ -94,7 +94,7 @@ def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overri
 				return res_dir
 		else:
 			A_dev = harness.to_device_matrix(scores, device, dtype)
-			eval_res = harness.run_entry_A(A_dev, grids, n_seeds, progress)
+			eval_res = harness.run_entry_A(A_dev, grids, n_seeds, progress, pinv_backend)
 		eval_res["other_args"] = other_args
 		with open(f"{res_dir}/retrieval_wrt_exact_crossenc.json", "w") as fout:
 			json.dump(obj=eval_res, fp=fout, indent=4)
@@ -129,6 +129,8 @@ def main(argv=None):
 	parser.add_argument("--data_dir", type=str, default=data_dir)
 	parser.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"], help="storage/compute type of the score matrix on the GPU")
 	parser.add_argument("--device", type=str, default="cuda:0")
+	parser.add_argument("--pinv", type=str, default="numpy", choices=["numpy", "device"],
+						help="pseudo-inverse: the reference's numpy.linalg.pinv on the host (bit-identical U) or Newton-Schulz on the GPU")
 	args = parser.parse_args(argv)
 	if args.bi_model_file != "":
 		raise SystemExit("--bi_model_file: the bi-encoder baseline needs the reference's BERT models and is out of scope of this build")
@@ -139,7 +141,7 @@ def main(argv=None):
 			   n_seeds=args.n_seeds, plot_only=bool(args.plot_only), misc=misc, arg_dict=dict(args.__dict__),
 			   grid_overrides={"eval_methods": args.eval_methods, "n_ment_anchors_vals": args.n_ment_anchors_vals,
 							   "n_ent_anchors_vals": args.n_ent_anchors_vals, "top_k_vals": args.top_k_vals, "top_k_retr_vals": args.top_k_retr_vals},
-			   dtype=args.dtype, device=torch.device(args.device))
+			   dtype=args.dtype, device=torch.device(args.device), pinv_backend=args.pinv)
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@ def run_eval_method(curr_method, test_data_file, train_data_file, args, seed, de
 	if curr_method == "cur":
 		A_train_dev = harness.to_device_matrix(A_train, device, args.dtype)
 		res = harness.run_eval_method_cur(A_test_dev, A_train_dev, seed, grids,
-										  progress=lambda j, n: LOGGER.info(f"anchor count {j + 1}/{n}"))
+										  progress=lambda j, n: LOGGER.info(f"anchor count {j + 1}/{n}"), pinv_backend=args.pinv)
 	elif curr_method in ("bienc", "tfidf"):
 		if not (args.mention_embeds_file and args.entity_embeds_file):
 			raise SystemExit(f"eval_method={curr_method}: pass --mention_embeds_file and --entity_embeds_file (.npy); "
@@ -128,6 +128,8 @@ def main(argv=None):
 	parser.add_argument("--entity_embeds_file", type=str, default="")
 	parser.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
 	parser.add_argument("--device", type=str, default="cuda:0")
+	parser.add_argument("--pinv", type=str, default="numpy", choices=["numpy", "device"],
+						help="pseudo-inverse: the reference's numpy.linalg.pinv on the host (bit-identical U) or Newton-Schulz on the GPU")
 	args = parser.parse_args(argv)
 	_ = get_dataset_info(data_dir="../../data/zeshel", res_dir=args.res_dir, worlds=worlds)  # kept for parity with the reference's main()
 	LOGGER.info(f"Running inference for world = {args.data_name}")

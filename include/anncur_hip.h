@@ -74,6 +74,20 @@ int anncur_gemm(const void *A, int a_dtype, int64_t a_sm, int64_t a_sk,
                 void *C, int c_dtype, int64_t c_sm, int64_t c_sn,
                 int64_t M, int64_t N, int64_t K, void *stream);
 
+/* Same product with scaling and accumulation: C = alpha * A.B + beta * Cin (Cin fp32 with its own strides, may be NULL; it may
+ * alias C element for element).  Building block of the on-device pseudo-inverse (Newton-Schulz X <- 2X - (X W) X), the
+ * alternative to the host numpy.linalg.pinv of eval/matrix_approx_zeshel.py:47,49 for large anchor counts. */
+int anncur_gemm_ex(const void *A, int a_dtype, int64_t a_sm, int64_t a_sk,
+                   const void *B, int b_dtype, int64_t b_sk, int64_t b_sn,
+                   void *C, int c_dtype, int64_t c_sm, int64_t c_sn,
+                   int64_t M, int64_t N, int64_t K, float alpha, float beta,
+                   const float *Cin, int64_t i_sm, int64_t i_sn, void *stream);
+/* out[0] = sum of squares of an fp32 matrix (Frobenius norm squared); dst(i,j) = alpha / (divide_by ? divide_by[0] : 1) * src(i,j)
+ * with arbitrary strides (scaled transpose).  Helpers of the on-device pseudo-inverse; no host synchronisation. */
+int anncur_sumsq(const float *A, int64_t n_rows, int64_t n_cols, int64_t lda, float *out, void *stream);
+int anncur_scale_copy(const float *src, int64_t s0, int64_t s1, float *dst, int64_t d0, int64_t d1, int64_t M, int64_t N,
+                      float alpha, const float *divide_by, void *stream);
+
 /* a11: approximation error without materialising S_hat ------------------------------
  * err_sq[q] = sum_i (X[q,:].E[:,i] - A[q,i])^2 , norm_sq[q] = sum_i A[q,i]^2
  *   eval/run_retrieval_eval_wrt_exact_crossenc.py:146-147 (torch.norm over row subsets;

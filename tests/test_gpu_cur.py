@@ -127,3 +127,32 @@ def test_protocol_b_golden_fp32_and_bf16(CUR, golden_dir, golden_meta):
 	gotb = eval_topk_recall(Ab_test.to(dev), bi, [1, 10, 50, 100], [100])
 	for k in (1, 10, 50, 100):
 		assert gotb[(k, 100)][key] == pytest.approx(gold[str(k)][key], abs=5e-3), k
+
+
+@pytest.mark.parametrize("m,n,rank,noise", [(512, 256, 64, 0.05), (256, 512, 64, 0.05), (300, 120, 300, 1.0), (200, 200, 20, 0.0)])
+def test_device_pinv_newton_schulz_matches_numpy(CUR, m, n, rank, noise):
+	"""On-device pseudo-inverse vs numpy.linalg.pinv: well-conditioned tall / wide / full-rank cases to ~cond*eps, and an exactly
+	rank-deficient case (rank 20 of 200) against numpy's pinv with the matching cut-off."""
+	from anncur_amd.pinv import pinv_newton_schulz
+	g = torch.Generator().manual_seed(m + n)
+	W = torch.randn(m, min(rank, m, n), generator=g) @ torch.randn(min(rank, m, n), n, generator=g) / rank ** 0.5 + noise * torch.randn(m, n, generator=g)
+	X = pinv_newton_schulz(W.cuda()).cpu().double()
+	rc = 1e-15 if noise > 0 else 1e-5
+	ref = torch.from_numpy(np.linalg.pinv(W.double().numpy(), rcond=rc))
+	rel = ((X - ref).norm() / ref.norm()).item()
+	assert rel < 2e-3, rel
+	Wd = W.double()
+	assert ((Wd @ X @ Wd - Wd).norm() / Wd.norm()).item() < 1e-4          # Moore-Penrose condition W X W = W
+
+
+def test_device_pinv_backend_gives_same_retrieval(CUR):
+	from oracle import cur_oracle as O
+	A_train, A_test = O.synth_protocol_b(400, 300, 20000, rank=64, noise=0.05, seed=5)
+	anc = sorted(np.random.default_rng(2).choice(20000, 192, replace=False))
+	a = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(400), col_idxs=anc, approx_preference="rows")
+	b = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(400), col_idxs=anc, approx_preference="rows", pinv_backend="device")
+	assert ((a.U - b.U).norm() / a.U.norm()).item() < 1e-3
+	Sa, Sb = a.get_complete_row(A_test[:, anc]), b.get_complete_row(A_test[:, anc])
+	assert ((Sa - Sb).norm() / Sa.norm()).item() < 1e-3
+	ia = a.topk_in_row(A_test[:, anc], 50).indices.numpy(); ib = b.topk_in_row(A_test[:, anc], 50).indices.numpy()
+	assert np.mean([len(set(x) & set(y)) / 50 for x, y in zip(ia.tolist(), ib.tolist())]) > 0.995

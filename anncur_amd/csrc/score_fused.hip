@@ -47,7 +47,8 @@ struct FusedCfg {
 	static constexpr int PASSES = TILE_BYTES / (256 * 16);
 	static constexpr int QDEPTH = 8;                 // lane-private LDS hit queue: entries per (lane, sub-tile)
 	static constexpr int QUEUE_BYTES = QT * QDEPTH * 256 * 8;
-	static constexpr int LDS_BYTES = 2 * TILE_BYTES + QUEUE_BYTES;   // the prepass kernel uses only the tile part
+	static constexpr int QUEUE_OFF = (2 * TILE_BYTES + 16383) / 16384 * 16384;  // rings are 16 KiB aligned (filter_one)
+	static constexpr int LDS_BYTES = QUEUE_OFF + QUEUE_BYTES;         // the prepass kernel uses only the tile part
 };
 
 template <int CPR>
@@ -126,51 +127,113 @@ __device__ __forceinline__ uint2 lds_load_u64(uint32_t addr) {
 	return make_uint2((uint32_t)d, (uint32_t)(d >> 32));
 }
 
-// One accumulator element of the filter (element index e is a compile-time constant after unrolling).  item_lim = number of
-// items for the matrix' last, partial tile and 0xffffffff otherwise: the bound check sits in the (rare) hit path only.
+// Two dwords from two separate VGPRs (no 64-bit register pair has to be assembled in the hit path).
+__device__ __forceinline__ void lds_store_2x32(uint32_t addr, uint32_t lo, uint32_t hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(addr), "v"(lo), "v"(hi) : "memory");
+#endif
+}
+
+// One accumulator element of the filter (element index e is a compile-time constant after unrolling).  The hit path is kept
+// to the bare minimum (slot address, item id, one LDS store, count): the sweep is vector-issue bound, every instruction here is
+// paid ~0.3 times per MFMA.  The queue is a ring of D slots; what does not belong in it is sorted out at flush time
+// (items past I of the matrix' last, partial tile; a count above D = the ring wrapped = overflow).
 template <int D>
-__device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t item0, uint32_t item_lim, uint32_t lq, uint32_t &qcnt,
-											uint32_t &ncand) {
+__device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t item0, uint32_t lq, uint32_t &qcnt) {
+	static_assert((D & (D - 1)) == 0, "queue depth must be a power of two");
 	if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
 		if (v >= tau) {
-			const uint32_t item = item0 + (uint32_t)((e & 3) + 8 * (e >> 2));
-			if (item < item_lim) {
-				if (qcnt < (uint32_t)D) { lds_store_u64(lq + qcnt * 2048u, __float_as_uint(v), item); qcnt++; }
-				else ncand = 0x80000000u;  // queue full between two flushes (p ~ 1e-9 per window): poison the segment count
-										   // -> the select kernel recomputes this query exactly
-			}
+			// qcnt is kept pre-shifted (slot stride 2048 B); lq has bits 11..13 clear (16 KiB-aligned ring), so OR == ADD
+			lds_store_2x32((qcnt & (uint32_t)((D - 1) << 11)) | lq, __float_as_uint(v), item0 + (uint32_t)((e & 3) + 8 * (e >> 2)));
+			qcnt += 2048u;
 		}
 	}
 }
 
-template <bool TAIL, int D>
-__device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint32_t item0, uint32_t n_items, uint32_t lq,
-											  uint32_t &qcnt, uint32_t &ncand) {
+template <int D>
+__device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint32_t item0, uint32_t lq, uint32_t &qcnt) {
 #pragma unroll
-	for (int e = 0; e < 16; ++e) {
-		const float v = acc[e];
-		if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
-			if (v >= tau) {
-				const uint32_t item = item0 + (uint32_t)((e & 3) + 8 * (e >> 2));
-				if (!TAIL || item < n_items) {
-					if (qcnt < (uint32_t)D) { lds_store_u64(lq + qcnt * 2048u, __float_as_uint(v), item); qcnt++; }
-					else ncand = 0x80000000u;  // queue full between two flushes (p ~ 1e-9 per window): poison the segment
-											   // count -> the select kernel recomputes this query exactly
-				}
+	for (int e = 0; e < 16; ++e) filter_one<D>(acc[e], e, tau, item0, lq, qcnt);
+}
+
+// Drain the lane's ring to its HBM candidate segment: one store instruction per queue slot for the whole wave.
+template <int D>
+__device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *__restrict__ seg, uint32_t &ncand, uint32_t capg,
+											 uint32_t n_items) {
+	uint32_t n = qcnt >> 11;  // (the filter keeps the count pre-shifted by the slot stride)
+	if (__builtin_expect(__ballot(n > (uint32_t)D) != 0ull, 0)) {
+		// ring wrapped between two flushes (p ~ 1e-9 per window): poison the segment count -> the select kernel recomputes
+		// this query exactly
+		if (n > (uint32_t)D) { ncand = 0x80000000u; n = D; }
+	}
+	for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
+		if (i < n) {
+			const uint2 e = lds_load_u64(lq + i * 2048u);
+			if (e.y < n_items) {               // (items past I exist only in the matrix' last, partial tile)
+				if (ncand < capg) seg[ncand] = e;  // (capg = 0 in the no-store timing experiment)
+				ncand++;                        // (a poisoned count stays > capg)
 			}
 		}
 	}
+	qcnt = 0;
 }
-template <int D>
-__device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *__restrict__ seg, uint32_t &ncand, uint32_t capg) {
-	for (uint32_t i = 0; __ballot(i < qcnt) != 0ull; ++i) {  // one store instruction per queue slot for the whole wave
-		if (i < qcnt) {
-			const uint2 e = lds_load_u64(lq + i * 2048u);
-			if (ncand < capg) seg[ncand] = e;  // (capg = 0 in the no-store timing experiment)
-			ncand++;  // (a poisoned count stays > capg)
+
+// ---- A-fragment ring of the staggered sweep.  The LDS reads are inline asm with explicit, COUNTED s_waitcnt lgkmcnt(n):
+// hipcc's own wait insertion fell back to lgkmcnt(0) in this loop (every fourth MFMA waited for a fragment requested one
+// MFMA earlier).  The compiler does not see that the destination is still in flight after the asm statement; the wait
+// statement takes the fragment as an in/out operand so that its consumer cannot be scheduled above the wait.
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(u32x4 &dst, uint32_t addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#endif
+}
+__device__ __forceinline__ void lds_wait_frag(u32x4 &frag, int pending) {  // `pending` folds to a constant after unrolling
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (pending >= 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(frag));
+	else if (pending == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(frag));
+	else if (pending == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(frag));
+	else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(frag));
+#endif
+}
+
+// One 32-item tile of the staggered sweep (Kp <= 256): the wave's two 32-query sub-tiles run half a tile apart.  While the
+// MFMA chain of one sub-tile executes on the matrix pipe, the threshold filter of the OTHER sub-tile's finished accumulator
+// is issued element by element in the MFMA shadow (one accumulator register per k-step at Kp = 256):
+//   steps 0..K-1   : accA (sub-tile 0 of this tile)  ||  filter of acc1 = sub-tile 1 of the PREVIOUS tile
+//   steps K..2K-1  : acc1 (sub-tile 1 of this tile)  ||  filter of accA
+// The A fragments (same K fragments for both halves) stream through one ring of AR registers, AR-1 steps ahead, without a
+// break between the halves.  CUR = tile buffer parity (compile-time: an immediate offset of the LDS reads).
+template <int KP, int CUR>
+__device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>::KSTEPS], const bf16x8 (&xb)[2][FusedCfg<KP>::KSTEPS],
+											  f32x16 &acc1, float tau0, float tau1_prev, uint32_t item0, uint32_t item0_prev,
+											  uint32_t lq0, uint32_t lq1, uint32_t &q0, uint32_t &q1) {
+	using Cfg = FusedCfg<KP>;
+	constexpr int K = Cfg::KSTEPS, AR = 4, OFF = CUR * Cfg::TILE_BYTES;
+	constexpr int EPS = 16 / K > 0 ? 16 / K : 1;  // filter elements per k-step (Kp = 64: 4, 128: 2, 256: 1)
+	static_assert(K <= 16 && 2 * K >= AR, "staggered path: 2..16 k-steps");
+	u32x4 ring[AR];
+#pragma unroll
+	for (int i = 0; i < AR - 1; ++i) lds_read_frag<OFF>(ring[i], aoff[i % K]);
+	f32x16 accA = {0}, accB = {0};
+#pragma unroll
+	for (int g = 0; g < 2 * K; ++g) {
+		const int nxt = g + AR - 1;  // the slot it lands in was consumed by the MFMA of step g-1
+		if (nxt < 2 * K) lds_read_frag<OFF>(ring[nxt % AR], aoff[nxt % K]);
+		const int after = 2 * K - 1 - g;
+		lds_wait_frag(ring[g % AR], after < AR - 1 ? after : AR - 1);
+		const bf16x8 a = __builtin_bit_cast(bf16x8, ring[g % AR]);
+		if (g < K) {
+			accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][g], accA, 0, 0, 0);
+#pragma unroll
+			for (int e = g * EPS; e < (g + 1) * EPS; ++e) filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
+		} else {
+			accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[1][g - K], accB, 0, 0, 0);
+#pragma unroll
+			for (int e = (g - K) * EPS; e < (g - K + 1) * EPS; ++e) filter_one<Cfg::QDEPTH>(accA[e], e, tau0, item0, lq0, q0);
 		}
 	}
-	qcnt = 0;
+	acc1 = accB;
 }
 
 // MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep.
@@ -225,83 +288,49 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	// candidate segment of (query, lane half, split); sub-tile t adds a wave-uniform stride
 	uint2 *seg0 = p.cand + ((qv[0] * 2 + h) * (int64_t)p.S + split) * (int64_t)p.capg;
 	const int64_t seg_dt = (int64_t)32 * 2 * p.S * p.capg;
-	const uint32_t lq0 = lds_addr(smem + 2 * Cfg::TILE_BYTES) + (uint32_t)tid * 8u;  // slot i of sub-tile t at byte lq0 + (t*QDEPTH + i)*2048
+	const uint32_t lq0 = lds_addr(smem + Cfg::QUEUE_OFF) + (uint32_t)tid * 8u;  // slot i of sub-tile t at byte lq0 + (t*QDEPTH + i)*2048
+	static_assert(Cfg::QUEUE_OFF % (Cfg::QDEPTH * 2048) == 0 && Cfg::QDEPTH * 2048 == 16384, "ring must be 16 KiB aligned");
+	if (MODE == 1 && (lds_addr(smem) & 0x3fffu) != 0u) __builtin_trap();  // filter_one() ORs the slot offset into the address
 
 	if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
 
 	if constexpr (MODE == 1 && QT == 2) {
-		// ---- staggered sweep: the wave's two 32-query sub-tiles run half a tile apart.  While the MFMA chain of one sub-tile
-		// executes on the matrix pipe, the threshold filter of the OTHER sub-tile's finished accumulator is issued element by
-		// element in the MFMA shadow (one accumulator register per k-step at Kp = 256).  Same registers as the plain loop.
-		constexpr int AR = 3;                                       // A-fragment prefetch distance (k-steps)
-		constexpr int EPS = 16 / KSTEPS > 0 ? 16 / KSTEPS : 1;      // filter elements per k-step (Kp = 64: 4, 128: 2, 256: 1)
-		static_assert(KSTEPS <= 16, "staggered path needs at most 16 k-steps");
-		f32x16 acc0, acc1;
+		// ---- staggered sweep (stagger_tile): tile loop unrolled by two so that the LDS buffer parity is a compile-time offset
+		f32x16 acc1;
 #pragma unroll
-		for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+		for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
 		float tau1_prev = INFINITY;  // no previous tile yet: the filter of acc1 never fires
-		uint32_t item0_prev = 0, lim_prev = 0xffffffffu;
+		uint32_t item0_prev = 0;
 		const uint32_t lq1 = lq0 + Cfg::QDEPTH * 2048;
+		uint32_t aoff[KSTEPS];       // LDS byte address of this lane's A fragment of k-step s in tile buffer 0
+#pragma unroll
+		for (int s = 0; s < KSTEPS; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
 		int flush_in2 = p.flush_tiles;
-		for (int j = j_begin; j < j_end; ++j) {
-			const int cur = (j - j_begin) & 1;
-			const int tile = tile_of(j);
-			const bool more = j + 1 < j_end;
-			if (more) tile_dma<KP>(p.Et, tile_of(j + 1), smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
-			if (--flush_in2 == 0) {
-				flush_in2 = p.flush_tiles;
-				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg);
-				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg);
-			}
-			const uint32_t item0 = (uint32_t)tile * TILE_I + 4 * h;
-			const uint32_t lim = ((tile == p.n_tiles - 1) && ((p.I & (TILE_I - 1)) != 0)) ? (uint32_t)p.I : 0xffffffffu;
-			const u32x4 *tb = reinterpret_cast<const u32x4 *>(smem + cur * Cfg::TILE_BYTES);
-			// phase A: sub-tile 0 of this tile  ||  filter of sub-tile 1 of the previous tile
-			{
-				f32x16 acc = {0};
-				u32x4 ring[AR];  // A fragments, AR k-steps ahead: one step of MFMA + filter does not cover the LDS latency
-#pragma unroll
-				for (int i = 0; i < AR; ++i)
-					if (i < KSTEPS) ring[i] = tb[r * CPR + swz<CPR>(r, 2 * i + h)];
-#pragma unroll
-				for (int s = 0; s < KSTEPS; ++s) {
-					const bf16x8 a = __builtin_bit_cast(bf16x8, ring[s % AR]);
-					if (s + AR < KSTEPS) ring[s % AR] = tb[r * CPR + swz<CPR>(r, 2 * (s + AR) + h)];
-					acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][s], acc, 0, 0, 0);
-#pragma unroll
-					for (int e = s * EPS; e < (s + 1) * EPS; ++e)
-						filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lim_prev, lq1, qcnt[1], ncand[1]);
-				}
-				acc0 = acc;
-			}
-			// phase B: sub-tile 1 of this tile  ||  filter of sub-tile 0 of this tile
-			{
-				f32x16 acc = {0};
-				u32x4 ring[AR];  // A fragments, AR k-steps ahead: one step of MFMA + filter does not cover the LDS latency
-#pragma unroll
-				for (int i = 0; i < AR; ++i)
-					if (i < KSTEPS) ring[i] = tb[r * CPR + swz<CPR>(r, 2 * i + h)];
-#pragma unroll
-				for (int s = 0; s < KSTEPS; ++s) {
-					const bf16x8 a = __builtin_bit_cast(bf16x8, ring[s % AR]);
-					if (s + AR < KSTEPS) ring[s % AR] = tb[r * CPR + swz<CPR>(r, 2 * (s + AR) + h)];
-					acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[1][s], acc, 0, 0, 0);
-#pragma unroll
-					for (int e = s * EPS; e < (s + 1) * EPS; ++e)
-						filter_one<Cfg::QDEPTH>(acc0[e], e, tau[0], item0, lim, lq0, qcnt[0], ncand[0]);
-				}
-				acc1 = acc;
-			}
-			tau1_prev = tau[1]; item0_prev = item0; lim_prev = lim;
-			__builtin_amdgcn_s_waitcnt(0x0F70);
-			__syncthreads();
+#define STAGGER_STEP(CUR, J)                                                                                                    \
+		do {                                                                                                                    \
+			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
+			if (--flush_in2 == 0) {                                                                                             \
+				flush_in2 = p.flush_tiles;                                                                                      \
+				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);                        \
+				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I);               \
+			}                                                                                                                   \
+			const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * h;                                                              \
+			stagger_tile<KP, CUR>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1]);            \
+			tau1_prev = tau[1]; item0_prev = item0;                                                                             \
+			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
+			__syncthreads();                                                                                                    \
+		} while (0)
+		for (int j = j_begin; j < j_end; j += 2) {
+			STAGGER_STEP(0, j);
+			if (j + 1 < j_end) STAGGER_STEP(1, j + 1);
 		}
-		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg);  // keep one tile's hits per queue window
+#undef STAGGER_STEP
+		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I);  // keep one tile's hits per queue window
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
-			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lim_prev, lq1, qcnt[1], ncand[1]);
+			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
 	} else {
 	int flush_in = p.flush_tiles;
 	for (int j = j_begin; j < j_end; ++j) {
@@ -314,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 			if (--flush_in == 0) {
 				flush_in = p.flush_tiles;
 #pragma unroll
-				for (int t = 0; t < QT; ++t) flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
+				for (int t = 0; t < QT; ++t) flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I);
 			}
 		}
 
@@ -357,12 +386,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 #endif
 		} else {
 			const uint32_t item0 = (uint32_t)tile * TILE_I + 4 * h;
-			const bool tail = (tile == p.n_tiles - 1) && ((p.I & (TILE_I - 1)) != 0);  // uniform
 #pragma unroll
-			for (int t = 0; t < QT; ++t) {
-				if (tail) filter_queue<true, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], ncand[t]);
-				else filter_queue<false, Cfg::QDEPTH>(acc[t], tau[t], item0, (uint32_t)p.I, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], ncand[t]);
-			}
+			for (int t = 0; t < QT; ++t) filter_queue<Cfg::QDEPTH>(acc[t], tau[t], item0, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
 		}
 		if (MODE != 3) {
 			__builtin_amdgcn_s_waitcnt(0x0F70);  // the DMA of tile j+1 (and the queue stores issued with it) have landed
@@ -375,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	if (MODE == 1) {
 #pragma unroll
 		for (int t = 0; t < QT; ++t) {
-			flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg);
+			flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I);
 			if (qv[t] < p.Q) p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] = ncand[t];
 		}
 	}
@@ -578,9 +603,16 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k) {
 	// sweep stages: after the first 10 % and 40 % of the item tiles the threshold is raised to the k-th best candidate seen
 	// so far (wave-level kernel), which cuts the survivors ~2.6x.  Needs the wave-level selector (k <= 128, <= 64 segments).
 	{
-		const double frac[3] = {0.10, 0.40, 1.0};
+		double frac[3] = {0.10, 0.40, 1.0};
 		const bool staged = k <= WSEL_K && 2 * P.S <= WAVE && P.n_tiles >= 24 * P.S;
 		P.n_stages = staged ? 3 : 1;
+		if (const char *dbg = getenv("ANNCUR_DEBUG_STAGES")) {  // tuning knob "f1,f2" or "f1": any split is exact, only speed changes
+			double f1 = 0, f2 = 0;
+			const int n = sscanf(dbg, "%lf,%lf", &f1, &f2);
+			if (staged && n == 2 && f1 > 0 && f2 > f1 && f2 < 1) { frac[0] = f1; frac[1] = f2; }
+			else if (staged && n == 1 && f1 > 0 && f1 < 1) { frac[0] = f1; frac[1] = 1.0; P.n_stages = 2; }
+			else if (n == 1 && f1 >= 1) P.n_stages = 1;
+		}
 		double rate = exp_hits / ((double)P.n_tiles * 2.0);  // expected hits per (query half, tile) in the first stage
 		int prev = 0;
 		for (int i = 0; i < P.n_stages; ++i) {

@@ -138,12 +138,37 @@ __device__ __forceinline__ void lds_store_2x32(uint32_t addr, uint32_t lo, uint3
 // to the bare minimum (slot address, item id, one LDS store, count): the sweep is vector-issue bound, every instruction here is
 // paid ~0.3 times per MFMA.  The queue is a ring of D slots; what does not belong in it is sorted out at flush time
 // (items past I of the matrix' last, partial tile; a count above D = the ring wrapped = overflow).
-template <int D>
+// Measured on cfg2 (MI355X): branch version 0.58 ms per sweep, predicated version 0.655 ms independent of the hit rate (its
+// compare -> exec -> store chain sits in front of the wave's next MFMA) -> the branch version is the one in use.
+constexpr bool STAGGER_PREDICATED = false;
+template <int D, bool FILTER_PREDICATED = false>
 __device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t item0, uint32_t lq, uint32_t &qcnt) {
 	static_assert((D & (D - 1)) == 0, "queue depth must be a power of two");
-	if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
+	// qcnt is kept pre-shifted (slot stride 2048 B); lq has bits 11..13 clear (16 KiB-aligned ring), so OR == ADD
+	if (FILTER_PREDICATED) {
+		// Branch-free: the push is executed under the compare's lane mask.  With lane = query a wave-level "any hit" branch is
+		// taken by ~30 % of the compares, and each taken branch (out and back) cost more than these five always-issued
+		// instructions, which fit in the MFMA shadow (4 VALU issue slots per MFMA and wave).
+		// CAUTION: the asm is opaque to hipcc's hazard recognizer: the caller must make sure that `v` is not the result of an
+		// MFMA issued within the last ~48 clocks (stagger_tile: no filter in the first step of a half).
+#if defined(__HIP_DEVICE_COMPILE__)
+		uint32_t addr, item;
+		uint64_t sv;
+		asm volatile(
+			"v_cmp_ge_f32 vcc, %[v], %[tau]\n\t"
+			"s_and_saveexec_b64 %[sv], vcc\n\t"
+			"v_and_or_b32 %[a], %[q], %[m], %[lq]\n\t"
+			"v_add_u32 %[it], %[c], %[i0]\n\t"
+			"ds_write2_b32 %[a], %[v], %[it] offset1:1\n\t"
+			"v_add_u32 %[q], 0x800, %[q]\n\t"
+			"s_mov_b64 exec, %[sv]"
+			: [q] "+v"(qcnt), [a] "=&v"(addr), [it] "=&v"(item), [sv] "=&s"(sv)
+			: [v] "v"(v), [tau] "v"(tau), [m] "s"((uint32_t)((D - 1) << 11)), [lq] "v"(lq), [i0] "v"(item0),
+			  [c] "n"((e & 3) + 8 * (e >> 2))
+			: "vcc", "memory");
+#endif
+	} else if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
 		if (v >= tau) {
-			// qcnt is kept pre-shifted (slot stride 2048 B); lq has bits 11..13 clear (16 KiB-aligned ring), so OR == ADD
 			lds_store_2x32((qcnt & (uint32_t)((D - 1) << 11)) | lq, __float_as_uint(v), item0 + (uint32_t)((e & 3) + 8 * (e >> 2)));
 			qcnt += 2048u;
 		}
@@ -226,11 +251,15 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 		if (g < K) {
 			accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][g], accA, 0, 0, 0);
 #pragma unroll
-			for (int e = g * EPS; e < (g + 1) * EPS; ++e) filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
+			for (int e = (g == 1 ? 0 : g) * EPS; e < (g == 0 ? 0 : g + 1) * EPS; ++e)
+				filter_one<Cfg::QDEPTH, STAGGER_PREDICATED>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
 		} else {
+			// no filter in the first step of the half: accA's last MFMA is still in the pipe (and the predicated filter is
+			// inline asm, invisible to the compiler's MFMA -> VALU hazard handling); step 1 takes two groups instead
 			accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[1][g - K], accB, 0, 0, 0);
 #pragma unroll
-			for (int e = (g - K) * EPS; e < (g - K + 1) * EPS; ++e) filter_one<Cfg::QDEPTH>(accA[e], e, tau0, item0, lq0, q0);
+			for (int e = (g - K == 1 ? 0 : g - K) * EPS; e < (g == K ? 0 : g - K + 1) * EPS; ++e)
+				filter_one<Cfg::QDEPTH, STAGGER_PREDICATED>(accA[e], e, tau0, item0, lq0, q0);
 		}
 	}
 	acc1 = accB;
@@ -600,24 +629,47 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k) {
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
 	int ft = (int)(0.5 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-	// sweep stages: after the first 10 % and 40 % of the item tiles the threshold is raised to the k-th best candidate seen
-	// so far (wave-level kernel), which cuts the survivors ~2.6x.  Needs the wave-level selector (k <= 128, <= 64 segments).
+	// sweep stages: between stages the threshold is raised to the k-th best candidate seen so far (wave-level kernel), which cuts
+	// the survivors of the remaining tiles from H0 to ~1.2 k / (fraction seen).  Any split is exact; the split is picked by a small
+	// cost model with constants measured on MI355X (cfg2, round 1): ~2.4e-11 s of chip time per survivor, ~25 us + 3 ns per query
+	// per extra stage (threshold kernel + launch ramp).  Needs the wave-level selector (k <= 128, <= 64 segments).
 	{
-		double frac[3] = {0.10, 0.40, 1.0};
+		double frac[3] = {1.0, 1.0, 1.0};
 		const bool staged = k <= WSEL_K && 2 * P.S <= WAVE && P.n_tiles >= 24 * P.S;
-		P.n_stages = staged ? 3 : 1;
-		if (const char *dbg = getenv("ANNCUR_DEBUG_STAGES")) {  // tuning knob "f1,f2" or "f1": any split is exact, only speed changes
+		P.n_stages = 1;
+		if (staged) {
+			const double H0 = exp_hits, c_hit = 2.4e-11 * (double)Q, c_stage = 25e-6 + 3e-9 * (double)Q;
+			auto later = [&](double f) { const double h = 1.2 * k / f; return h < H0 ? h : H0; };
+			double best = H0 * c_hit;
+			static const double grid[] = {0.02, 0.03, 0.04, 0.06, 0.08, 0.10, 0.12, 0.15, 0.18, 0.22, 0.26, 0.30, 0.35, 0.40, 0.50};
+			const int ng = (int)(sizeof(grid) / sizeof(grid[0]));
+			const double fmin = 4.0 * P.S / P.n_tiles;  // at least four tiles per split and stage
+			for (int i = 0; i < ng; ++i) {
+				const double f1 = grid[i];
+				if (f1 < fmin) continue;
+				const double c2 = (f1 * H0 + (1 - f1) * later(f1)) * c_hit + c_stage;
+				if (c2 < best) { best = c2; P.n_stages = 2; frac[0] = f1; frac[1] = 1.0; }
+				for (int j = i + 1; j < ng; ++j) {
+					const double f2 = grid[j];
+					if (f2 - f1 < fmin) continue;
+					const double c3 = (f1 * H0 + (f2 - f1) * later(f1) + (1 - f2) * later(f2)) * c_hit + 2 * c_stage;
+					if (c3 < best) { best = c3; P.n_stages = 3; frac[0] = f1; frac[1] = f2; }
+				}
+			}
+		}
+		if (const char *dbg = getenv("ANNCUR_DEBUG_STAGES")) {  // tuning knob "f1,f2" or "f1" (>= 1: single stage)
 			double f1 = 0, f2 = 0;
 			const int n = sscanf(dbg, "%lf,%lf", &f1, &f2);
-			if (staged && n == 2 && f1 > 0 && f2 > f1 && f2 < 1) { frac[0] = f1; frac[1] = f2; }
+			if (staged && n == 2 && f1 > 0 && f2 > f1 && f2 < 1) { frac[0] = f1; frac[1] = f2; P.n_stages = 3; }
 			else if (staged && n == 1 && f1 > 0 && f1 < 1) { frac[0] = f1; frac[1] = 1.0; P.n_stages = 2; }
 			else if (n == 1 && f1 >= 1) P.n_stages = 1;
 		}
 		double rate = exp_hits / ((double)P.n_tiles * 2.0);  // expected hits per (query half, tile) in the first stage
 		int prev = 0;
 		for (int i = 0; i < P.n_stages; ++i) {
-			int end = staged ? (int)(frac[i] * P.n_tiles + 0.5) : P.n_tiles;
-			if (i == P.n_stages - 1) end = P.n_tiles;
+			int end = (int)(frac[i] * P.n_tiles + 0.5);
+			if (i == P.n_stages - 1 || end > P.n_tiles) end = P.n_tiles;
+			if (end <= prev) end = prev + 1 < P.n_tiles ? prev + 1 : P.n_tiles;
 			P.stage_end[i] = end;
 			P.stage_tps[i] = (end - prev + P.S - 1) / P.S;
 			int ft = (int)(0.5 / (rate > 1e-9 ? rate : 1e-9));

@@ -128,14 +128,88 @@ __global__ __launch_bounds__(SEL_THREADS) void rowwise_topk_kernel(const T *__re
 }
 
 // ------------------------------------------------------------------ a7/a8: exact scan, ONE WAVE PER ROW (k <= 128)
-// Barrier-free variant of the scan: each wave streams its own row with 16-byte loads (WS_PF loads in flight per lane),
-// filters against its running threshold and keeps candidates in a wave-private LDS buffer (wave_select.hpp).  The
-// threshold is seeded from the group maxima of the first 512 vectors so that only ~k (1 + ln(I/4096)) elements are ever
-// pushed.  4 rows per 256-thread workgroup, 11 KB LDS per wave.
+// Barrier-free scan: each wave streams its own row with 16-byte nontemporal loads (WS_PF in flight per lane), filters against
+// its running threshold and keeps candidates in a wave-private LDS buffer (wave_select.hpp).  4 rows per 256-thread
+// workgroup, 11 KB LDS per wave.  The wave-per-row access pattern itself streams at 6.2 TB/s (6.9 nontemporal) on MI355X
+// (scripts/probes/stream_probe.hip); what the kernel adds is instruction issue, so the stream is built to issue little:
+//  * seed: the maxima of the lane's first WS_PF vectors (packed max, values only) -> their k-th largest is a valid lower bound
+//    on the row's k-th best; the threshold starts just below it with an EMPTY buffer and the stream starts at element 0, so
+//    indices are in order from the first element on and a strict score compare is exact throughout;
+//  * per vector a prefilter on the raw words ("does any of this lane's elements beat the threshold?"); the per-element path
+//    runs only for vectors in which some lane has a candidate, and compares integers (bf16) without unpacking;
+//  * the threshold used inside a block of WS_PF vectors is the one at block start: thresholds only rise, a stale one lets a
+//    superset through, and the compaction (exact composite keys) sorts that out;
+//  * the compaction is out of line (wsel_compact_call).
+// bf16 ordering trick: y = x ^ M per 16-bit pattern with M = 0x8000 if tau >= 0 else 0xffff.  For tau >= 0 an element beats tau
+// iff it is positive and larger, i.e. iff y > tau ^ 0x8000 as UNSIGNED (negative floats get the top bit cleared); for tau < 0
+// iff y > ~tau as unsigned (positives become >= 0x8000, negatives order by falling magnitude).  NaN patterns can pass these
+// integer tests; they are dropped at the push (v == v).
+typedef unsigned short h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short h16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short h16x2 __attribute__((ext_vector_type(2)));
+
 constexpr int WS_CAP = 1024;  // trigger at 512 candidates + at most 512 pushes per step (typical rows never compact mid-stream)
 constexpr int WS_TRIGGER = 512;
 constexpr int WS_TIE_LIMIT = 320;
 constexpr int WS_PF = 8;
+
+template <typename T> struct ScanPre;
+template <> struct ScanPre<float> {  // fp32 rows: plain float compares
+	float pre;
+	__device__ __forceinline__ void set(float tau) { pre = tau; }
+	__device__ __forceinline__ u32x4 xform(const u32x4 &c) const { return c; }
+	__device__ __forceinline__ bool any(const u32x4 &y) const {
+		return fmaxf(fmaxf(fmaxf(__uint_as_float(y[0]), __uint_as_float(y[1])), __uint_as_float(y[2])), __uint_as_float(y[3])) > pre;
+	}
+	__device__ __forceinline__ uint32_t word_hits(uint32_t yw) const { return __uint_as_float(yw) > pre ? 1u : 0u; }  // one element per word
+	__device__ __forceinline__ bool elem_hit(uint32_t hw, int) const { return hw != 0u; }
+	static __device__ __forceinline__ uint32_t group_max_key(const u32x4 &c) {  // NaN-free maximum as a sortable key
+		return f32_sortable(fmaxf(fmaxf(fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1])), __uint_as_float(c[2])), __uint_as_float(c[3])));
+	}
+};
+template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer compares on y = x ^ M
+	uint32_t mask, pre_pk;  // wave-uniform
+	__device__ __forceinline__ void set(float tau) {
+		const uint32_t b = __builtin_amdgcn_readfirstlane(__float_as_uint(tau));
+		const bool neg = (b >> 31) != 0u;
+		uint32_t t16 = b >> 16;                        // largest bf16 <= tau (tau is a bf16 value, -inf, or the fp32 just below one)
+		if (neg && (b & 0xffffu) != 0u) t16 += 1u;
+		const uint32_t m16 = neg ? 0xffffu : 0x8000u;
+		mask = m16 | (m16 << 16);
+		const uint32_t p16 = t16 ^ m16;
+		pre_pk = p16 | (p16 << 16);
+	}
+	__device__ __forceinline__ u32x4 xform(const u32x4 &c) const { return c ^ mask; }
+	__device__ __forceinline__ bool any(const u32x4 &y) const {
+		const h16x8 v = __builtin_bit_cast(h16x8, y);
+		const h16x4 a = __builtin_elementwise_max(v.lo, v.hi);
+		const h16x2 m = __builtin_elementwise_max(a.lo, a.hi);
+		return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(m, __builtin_bit_cast(h16x2, pre_pk))) != pre_pk;
+	}
+	__device__ __forceinline__ uint32_t word_hits(uint32_t yw) const {  // non-zero half-word = that element beats the threshold
+		return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, yw), __builtin_bit_cast(h16x2, pre_pk))) ^ pre_pk;
+	}
+	__device__ __forceinline__ bool elem_hit(uint32_t hw, int e) const { return ((e & 1) ? (hw >> 16) : (hw & 0xffffu)) != 0u; }
+	static __device__ __forceinline__ uint32_t group_max_key(const u32x4 &c) {  // maximum of the 8 sortable 16-bit keys, as a 32-bit key
+		u32x4 k;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {  // per half-word: x ^ (sign ? 0xffff : 0x8000); NaN patterns -> 0 (never the maximum)
+			const uint32_t x = c[j];
+			const uint32_t sgn = (x >> 15) & 0x00010001u;
+			uint32_t s = x ^ (sgn * 0x7fffu) ^ 0x80008000u;
+			const uint32_t mag = x & 0x7fff7fffu;
+			if ((mag & 0xffffu) > 0x7f80u) s &= 0xffff0000u;
+			if ((mag >> 16) > 0x7f80u) s &= 0x0000ffffu;
+			k[j] = s;
+		}
+		const h16x8 v = __builtin_bit_cast(h16x8, k);
+		const h16x4 a = __builtin_elementwise_max(v.lo, v.hi);
+		const h16x2 m = __builtin_elementwise_max(a.lo, a.hi);
+		const uint32_t mm = __builtin_bit_cast(uint32_t, m);
+		const uint32_t top = (mm >> 16) > (mm & 0xffffu) ? (mm >> 16) : (mm & 0xffffu);
+		return top << 16;
+	}
+};
 
 template <typename T>
 __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
@@ -156,7 +230,6 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	const u32x4 *vp = reinterpret_cast<const u32x4 *>(row + head);
 	const int64_t vlast = nvec > 0 ? nvec - 1 : 0;
 	const int64_t nsteps = (nvec + WAVE - 1) / WAVE;
-	int64_t s0 = 0;
 
 	// the first WS_PF vectors of every lane: they seed the threshold AND are the first prefetch set of the stream
 	u32x4 pf[WS_PF];
@@ -165,64 +238,69 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		const int64_t iv = (int64_t)d * WAVE + lane;
 		pf[d] = vp[iv < nvec ? iv : vlast];
 	}
-	const bool seeded = nvec >= (int64_t)WS_PF * WAVE;
-	if (seeded) {
-		// ---- seed: the maxima of the first 512 vectors are real elements; their k best give the first threshold.
-		// Each prefetch register is refilled with the stream's next vector as soon as it has been reduced, so the loads
-		// of the stream are in flight during the compaction below.
-		uint32_t am_packed = 0;
+	if (nvec >= (int64_t)WS_PF * WAVE && k <= (uint32_t)(WS_PF * WAVE)) {
+		// ---- seed: WS_PF*64 group maxima (real elements of the row); the k-th largest bounds the row's k-th best from below
 #pragma unroll
-		for (int d = 0; d < WS_PF; ++d) {
-			const u32x4 sv = pf[d];
-			const int64_t ivn = (int64_t)(WS_PF + d) * WAVE + lane;
-			pf[d] = vp[ivn < nvec ? ivn : vlast];
-			float m = vec_elem<T>(sv, 0);
-			uint32_t a = 0;
-#pragma unroll
-			for (int e = 1; e < VEC; ++e) {
-				const float x = vec_elem<T>(sv, e);
-				if (x > m) { m = x; a = (uint32_t)e; }
-			}
-			am_packed |= a << (3 * d);
-			wsel_push(w, m == m, f32_sortable(m), 0xffffffffu - (uint32_t)(head + ((int64_t)d * WAVE + lane) * VEC + a));
+		for (int d = 0; d < WS_PF; ++d) w.whi[d * WAVE + lane] = ScanPre<T>::group_max_key(pf[d]);
+		__builtin_amdgcn_wave_barrier();
+		uint32_t need;
+		const uint32_t kth = wsel_kth<false, HP>(w, w.whi, (uint32_t)(WS_PF * WAVE), k, need, w.whi, 0u);
+		// admit the bound itself: the threshold is the fp32 value just below it (the buffer is still empty).  kth == 0 only if
+		// fewer than k maxima are real numbers: leave the threshold at -inf then.
+		if (kth != 0u) {
+			float t = f32_unsortable(kth - 1u);
+			if (fabsf(t) < 1.17549435e-38f) t = -1.17549435e-38f;  // bound = +-0 or a denormal: any negative normal admits it (and +0 == -0)
+			w.tau = t;
 		}
-		if (w.cnt > k) wsel_compact<HP, false>(w, k);
-#pragma unroll
-		for (int d = 0; d < WS_PF; ++d) {  // the other elements of those vectors (re-read: L2 hits; the maxima are already in)
-			const u32x4 sv = vp[(int64_t)d * WAVE + lane];
-			const int a = (int)((am_packed >> (3 * d)) & 7u);
-#pragma unroll
-			for (int e = 0; e < VEC; ++e)
-				wsel_offer(w, e != a, vec_elem<T>(sv, e), (uint32_t)(head + ((int64_t)d * WAVE + lane) * VEC + e));
-			if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, false>(w, k);
-		}
-		s0 = WS_PF;
 	}
-	{  // unaligned head (fewer than VEC elements); exact composite compare: the seed broke the index order
+	{  // unaligned head (fewer than VEC elements): lowest indices first
 		const bool in = lane < head;
-		wsel_offer(w, in, in ? load_as_f32<T>(row + lane) : 0.f, (uint32_t)lane);
-		if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, false>(w, k);
+		wsel_offer_inorder(w, in, in ? load_as_f32<T>(row + lane) : 0.f, (uint32_t)lane);
 	}
-	// ---- stream (strictly increasing indices from here on: one float compare per element is exact)
-	for (; s0 < nsteps; s0 += WS_PF) {
-#pragma unroll
-		for (int d = 0; d < WS_PF; ++d) {  // steps past the row are masked, never branched around (keeps the prefetch registers PHI-free)
-			const int64_t iv = (s0 + d) * WAVE + lane;
-			const bool ok = iv < nvec;
-			const int64_t i0 = head + iv * VEC;
-			const u32x4 cur = pf[d];
-			const int64_t ivn = iv + (int64_t)WS_PF * WAVE;
-			pf[d] = vp[ivn < nvec ? ivn : vlast];
-#pragma unroll
-			for (int e = 0; e < VEC; ++e) wsel_offer_inorder(w, ok, vec_elem<T>(cur, e), (uint32_t)(i0 + e));
-			if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact<HP, true>(w, k, WS_TIE_LIMIT);
-		}
+	// ---- stream, element 0 onwards, blocks of WS_PF vectors per lane
+	ScanPre<T> sp;
+#define SCAN_STEP(d)                                                                                                            \
+	{                                                                                                                           \
+		const u32x4 cur = pf[d];                                                                                                \
+		const int64_t iv = (s0 + (d)) * WAVE + lane;                                                                            \
+		const u32x4 y = sp.xform(cur);                                                                                          \
+		bool pass = sp.any(y);                                                                                                  \
+		if (full) {                                                                                                             \
+			pf[d] = __builtin_nontemporal_load(vp + iv + (int64_t)WS_PF * WAVE);                                                \
+		} else {  /* the last blocks: prefetches clamped, steps past the row masked (never branched around) */                  \
+			const int64_t ivn = iv + (int64_t)WS_PF * WAVE;                                                                     \
+			pf[d] = vp[ivn < nvec ? ivn : vlast];                                                                               \
+			pass = pass && iv < nvec;                                                                                           \
+		}                                                                                                                       \
+		if (__ballot(pass) != 0ull) {                                                                                           \
+			const uint32_t i0 = (uint32_t)(head + iv * VEC);                                                                    \
+			_Pragma("unroll") for (int j = 0; j < 4; ++j) {  /* word by word: most words of a passing vector hold no candidate */ \
+				const uint32_t hw = pass ? sp.word_hits(y[j]) : 0u;                                                             \
+				if (__ballot(hw != 0u) != 0ull) {                                                                               \
+					_Pragma("unroll") for (int e = j * VEC / 4; e < (j + 1) * VEC / 4; ++e) {                                   \
+						const bool hit = sp.elem_hit(hw, e);                                                                    \
+						if (VEC == 4 || __ballot(hit) != 0ull) {                                                                \
+							const float v = vec_elem<T>(cur, e);                                                                \
+							wsel_push(w, hit && v == v, f32_sortable(v), 0xffffffffu - (i0 + (uint32_t)e));                     \
+						}                                                                                                       \
+					}                                                                                                           \
+				}                                                                                                               \
+			}                                                                                                                   \
+			if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact_call<WS_CAP, HP, true>(w, k, WS_TIE_LIMIT);                          \
+		}                                                                                                                       \
 	}
+	static_assert(WS_PF == 8, "the block spells out eight steps");
+	for (int64_t s0 = 0; s0 < nsteps; s0 += WS_PF) {
+		sp.set(w.tau);  // frozen for the block
+		const bool full = (s0 + 2 * WS_PF) * WAVE <= nvec;  // (wave-uniform) the block and its prefetch lie inside the row
+		SCAN_STEP(0) SCAN_STEP(1) SCAN_STEP(2) SCAN_STEP(3) SCAN_STEP(4) SCAN_STEP(5) SCAN_STEP(6) SCAN_STEP(7)
+	}
+#undef SCAN_STEP
 	{  // the tail (fewer than VEC elements), still in index order
 		const bool in = lane < I - tail0;
 		wsel_offer_inorder(w, in, in ? load_as_f32<T>(row + tail0 + lane) : 0.f, (uint32_t)(tail0 + lane));
 	}
-	wsel_finish(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	wsel_finish<WS_CAP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
 
 // ------------------------------------------------------------------ k-th largest VALUE of short fp32 rows, one wave per row

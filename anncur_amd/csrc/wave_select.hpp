@@ -180,6 +180,32 @@ __device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t ti
 	__builtin_amdgcn_wave_barrier();
 }
 
+// Out-of-line compaction for kernels that reach it from many unrolled sites (the scan: one inline copy is ~6 KB of code, a
+// dozen of them no longer fit the instruction cache).  The selector's state crosses the call as plain scalars: the LDS offset
+// of the wave's region going in, (count, threshold key) coming back through the histogram words.
+template <int CAP, int HI_PASSES, bool KEEP_TIES>
+__device__ __attribute__((noinline)) void wsel_compact_outlined(uint32_t lds_off, uint32_t n, uint32_t k, uint32_t tie_limit) {
+	WaveSel w;
+	w.whi = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)lds_off;
+	w.wlo = w.whi + CAP;
+	w.sort_buf = reinterpret_cast<uint2 *>(w.wlo + CAP);
+	w.hist = reinterpret_cast<uint32_t *>(w.sort_buf + 128);
+	w.cnt = n; w.tau_hi = 0; w.tau_lo = 0; w.tau = 0.f;
+	wsel_compact<HI_PASSES, KEEP_TIES>(w, k, tie_limit);
+	if (lane_id() == 0) { w.hist[0] = w.cnt; w.hist[1] = w.tau_hi; w.hist[2] = w.tau_lo; }
+	__builtin_amdgcn_wave_barrier();
+}
+template <int CAP, int HI_PASSES, bool KEEP_TIES>
+__device__ __forceinline__ void wsel_compact_call(WaveSel &w, uint32_t k, uint32_t tie_limit = 0) {
+	wsel_compact_outlined<CAP, HI_PASSES, KEEP_TIES>((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)w.whi, w.cnt, k, tie_limit);
+	__builtin_amdgcn_wave_barrier();
+	w.cnt = __builtin_amdgcn_readfirstlane(w.hist[0]);
+	w.tau_hi = __builtin_amdgcn_readfirstlane(w.hist[1]);
+	w.tau_lo = __builtin_amdgcn_readfirstlane(w.hist[2]);
+	w.tau = f32_unsortable(w.tau_hi);
+	__builtin_amdgcn_wave_barrier();
+}
+
 // Bitonic sort (descending) of 128 64-bit keys held as (hi, lo) pairs, two per lane: element i = e*64 + lane.
 __device__ __forceinline__ void wave_sort128_desc(uint32_t (&hi)[2], uint32_t (&lo)[2]) {
 	const int lane = lane_id();
@@ -212,9 +238,13 @@ __device__ __forceinline__ void wave_sort128_desc(uint32_t (&hi)[2], uint32_t (&
 }
 
 // Reduce to the k best, sort them, write the output row.  Fewer than k candidates -> (-inf, -1) padding.
+template <int OUTLINED_CAP = 0>
 __device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx) {
 	const int lane = lane_id();
-	if (w.cnt > k) wsel_compact<4, false>(w, k);
+	if (w.cnt > k) {
+		if constexpr (OUTLINED_CAP > 0) wsel_compact_call<OUTLINED_CAP, 4, false>(w, k);
+		else wsel_compact<4, false>(w, k);
+	}
 	__builtin_amdgcn_wave_barrier();
 	uint32_t sh[2], sl[2];
 #pragma unroll

@@ -148,9 +148,10 @@ typedef unsigned short h16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short h16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short h16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int WS_CAP = 1024;  // trigger at 512 candidates + at most 512 pushes per step (typical rows never compact mid-stream)
-constexpr int WS_TRIGGER = 512;
-constexpr int WS_TIE_LIMIT = 320;
+constexpr int WS_CAP = 1024;  // compaction trigger (<= 512 candidates) + at most 512 pushes per step
+// The trigger is k + max(64, 1.5 k): the threshold only tightens at a compaction, so a lazy trigger (512) let ~2.5x more
+// elements through than a continuously updated threshold would; a compaction costs about as much as 50 pushes.
+static inline uint32_t ws_trigger(uint32_t k) { const uint32_t m = k + (k >> 1) > 64u ? k + (k >> 1) : 64u; return k + m < 512u ? k + m : 512u; }
 constexpr int WS_PF = 8;
 
 template <typename T> struct ScanPre;
@@ -213,7 +214,7 @@ template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer comp
 
 template <typename T>
 __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
-																 float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+																 uint32_t trig, float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id(), wave = threadIdx.x >> 6;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	}
 	// ---- stream, element 0 onwards, blocks of WS_PF vectors per lane
 	ScanPre<T> sp;
+	const uint32_t tie_limit = k + (trig - k) / 2;  // ties at the k-th score are kept while they fit below
 #define SCAN_STEP(d)                                                                                                            \
 	{                                                                                                                           \
 		const u32x4 cur = pf[d];                                                                                                \
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 					}                                                                                                           \
 				}                                                                                                               \
 			}                                                                                                                   \
-			if (w.cnt > (uint32_t)WS_TRIGGER) wsel_compact_call<WS_CAP, HP, true>(w, k, WS_TIE_LIMIT);                          \
+			if (w.cnt > trig) wsel_compact_call<WS_CAP, HP, true>(w, k, tie_limit);                                             \
 		}                                                                                                                       \
 	}
 	static_assert(WS_PF == 8, "the block spells out eight steps");
@@ -556,10 +558,15 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 	if (k <= WSEL_K && !getenv("ANNCUR_DEBUG_BLOCK_SCAN")) {  // barrier-free path: one wave per row
 		const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
 		const unsigned grid = (unsigned)ceil_div64(Q, 4);
+		uint32_t trig = ws_trigger((uint32_t)k);
+		if (const char *dbg = getenv("ANNCUR_DEBUG_SCAN_TRIGGER")) {  // tuning knob: any value in (k, 512] is exact
+			const int t = atoi(dbg);
+			if (t > k && t <= 512) trig = (uint32_t)t;
+		}
 		if (dtype == ANNCUR_F32)
-			hipLaunchKernelGGL((rowwise_topk_wave_kernel<float>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, out_val, out_idx);
+			hipLaunchKernelGGL((rowwise_topk_wave_kernel<float>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
 		else
-			hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, out_val, out_idx);
+			hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
 		ANNCUR_LAUNCH_OK();
 		return ANNCUR_OK;
 	}

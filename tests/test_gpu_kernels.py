@@ -242,3 +242,49 @@ def test_overlap_counts_long_lists(ops):
 	got = ops.overlap_counts(torch.tensor(a).cuda(), torch.tensor(b).cuda(), pairs).cpu().numpy()
 	for p, (ka, kb) in enumerate(pairs):
 		assert got[p].tolist() == [len(set(a[q, :ka]) & set(b[q, :kb])) for q in range(20)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rowwise_topk_threshold_crossing_zero_nan_and_sorted_rows(ops, dtype):
+	"""The scan's integer-domain compares switch form with the sign of the running threshold, and its seed is a bound taken
+	from the row's first 512 vectors: rows built to sit on those edges."""
+	g = _g(123)
+	I = 60000
+	def check(A, k, exact_idx=True):
+		v, i = ops.rowwise_topk(A.cuda(), k)
+		v, i = v.cpu(), i.cpu().long()
+		Af = A.float()
+		Ar = torch.where(torch.isnan(Af), torch.full_like(Af, -float("inf")), Af)   # NaN is never selected
+		rv, _ = torch.topk(Ar, k, dim=1)
+		assert torch.equal(v, rv)
+		assert torch.equal(torch.gather(Ar, 1, i), rv)
+		assert all(len(set(r.tolist())) == k for r in i)
+		if exact_idx:  # defined tie order: score descending, then smaller index
+			order = torch.argsort(Ar, dim=1, descending=True, stable=True)[:, :k]
+			assert torch.equal(i, order)
+	# (1) ReLU-like: mostly exact zeros, top-k reaches into the zeros (seed bound = +0.0)
+	relu = torch.relu(torch.randn(6, I, generator=g) - 2.2).to(dtype)
+	for k in (1, 10, 100, 128): check(relu, k)
+	# (2) first 10 % strongly negative (threshold starts negative), positives only later: the threshold crosses zero mid-stream
+	cross = torch.randn(5, I, generator=g)
+	cross[:, :6000] = -5.0 - torch.rand(5, 6000, generator=g)
+	for k in (10, 100): check(cross.to(dtype), k)
+	# (3) all negative (log-prob like) with ties
+	neg = (-torch.rand(4, I, generator=g) * 8).to(dtype)
+	check(neg, 100)
+	# (4) NaN / +inf / -inf scattered, including inside the seed region
+	sp = torch.randn(4, I, generator=g)
+	sp[:, ::97] = float("nan"); sp[:, 5::1013] = float("inf"); sp[:, 7::511] = -float("inf")
+	check(sp.to(dtype), 100)
+	# (5) sorted rows: descending (the seed bound is the final threshold), ascending (every element is a candidate)
+	desc = torch.sort(torch.randn(3, I, generator=g), dim=1, descending=True).values.to(dtype)
+	check(desc, 100)
+	asc = torch.sort(torch.randn(3, I, generator=g), dim=1).values.to(dtype)
+	check(asc, 100)
+	# (6) misaligned row start (unaligned head elements come first in index order)
+	base = torch.randn(4, I + 16, generator=g).to(dtype).cuda()
+	for off in (1, 3, 7):
+		view = base[:, off:off + I - 9]
+		v, i = ops.rowwise_topk(view, 64)
+		order = torch.argsort(view.float().cpu(), dim=1, descending=True, stable=True)[:, :64]
+		assert torch.equal(i.cpu().long(), order)

@@ -436,71 +436,117 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 }
 
 // ------------------------------------------------------------------ select
-// One workgroup per query: exact top-k of the query's candidate segments.  If a segment
-// overflowed (or fewer than k candidates arrived) the query is recomputed exactly here.
+// Item-tile ranges of the sweep stages (which tiles item split s swept in stage g): [begin[g] + s*tps[g], + tps[g]) below end[g].
+struct SweepStages {
+	int n, begin[3], end[3], tps[3];
+};
+
+// One workgroup per query: exact top-k of the query's candidate segments.  A segment that overflowed (or whose LDS ring
+// wrapped: poisoned count) is repaired locally: the scores of the item tiles its split swept are recomputed here (fp32 dot
+// products of the same bf16 operands) and offered unfiltered, the stored candidates of that split are ignored.  Only a query
+// that still ends with fewer than k candidates is recomputed in full.
 template <int KMAX>
 __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
-	const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg, int capg, const uint16_t *__restrict__ X,
-	int64_t ldx, const uint16_t *__restrict__ Et, int64_t I, int KP, uint32_t k, float *__restrict__ out_val,
-	int32_t *__restrict__ out_idx, uint32_t *__restrict__ n_fallback, const int32_t *__restrict__ hard_list,
-	const uint32_t *__restrict__ hard_cnt) {
+	const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg, int S, SweepStages stg, int capg,
+	const uint16_t *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ Et, int64_t I, int KP, uint32_t k,
+	float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *__restrict__ n_fallback,
+	const int32_t *__restrict__ hard_list, const uint32_t *__restrict__ hard_cnt) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const SelState s = sel_carve<KMAX>(smem);
-	float *xq = reinterpret_cast<float *>(smem + SelCfg<KMAX>::LDS_BYTES);  // [KP], fallback only
+	float *xq = reinterpret_cast<float *>(smem + SelCfg<KMAX>::LDS_BYTES);  // [KP], repair / fallback only
+	uint32_t *bad = reinterpret_cast<uint32_t *>(xq + KP);                  // [8]: bitmap of splits to repair (S <= 256)
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	auto score_of = [&](int64_t i) {
+		float v = 0.f;
+		const uint4 *er = reinterpret_cast<const uint4 *>(Et + i * KP);
+		for (int c = 0; c < KP / 8; ++c) {
+			const uint4 w = er[c];
+			const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+			for (int d = 0; d < 4; ++d) {
+				v = fmaf(__uint_as_float(ww[d] << 16), xq[8 * c + 2 * d], v);
+				v = fmaf(__uint_as_float(ww[d] & 0xffff0000u), xq[8 * c + 2 * d + 1], v);
+			}
+		}
+		return v;
+	};
 	// either one query per workgroup (hard_list == nullptr) or a grid-stride walk over the queries the wave kernel deferred
 	const uint32_t n_work = hard_list ? *hard_cnt : gridDim.x;
 	for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
 	__syncthreads();
 	sel_init(s);
+	if (tid < 8) bad[tid] = 0u;
+	__syncthreads();
 	const int64_t q = hard_list ? (int64_t)hard_list[wi] : (int64_t)wi;
 	const uint32_t *cnts = seg_cnt + q * nseg;
 	for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
 		const uint32_t c = cnts[sg];
-		if (c > (uint32_t)capg) atomicOr(&s.scal[8], 1u);
-		const uint32_t cc = min(c, (uint32_t)capg);
+		if (c > (uint32_t)capg) { const int sp = sg % S; atomicOr(&bad[sp >> 5], 1u << (sp & 31)); }
+	}
+	__syncthreads();
+	const bool repair = (bad[0] | bad[1] | bad[2] | bad[3] | bad[4] | bad[5] | bad[6] | bad[7]) != 0u;
+	for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
+		const int sp = sg % S;
+		const uint32_t cc = ((bad[sp >> 5] >> (sp & 31)) & 1u) ? 0u : cnts[sg];
 		atomicAdd(&s.scal[9], cc);
 		atomicMax(&s.scal[10], cc);
 	}
 	__syncthreads();
-	const bool overflow = s.scal[8] != 0;
 	const uint32_t total = s.scal[9], maxc = s.scal[10];
 	float tau = -INFINITY;
 	uint64_t tau_key = 0;
-	if (!overflow && total >= k) {
+	bool full = !repair && total < k;  // cannot happen with a valid threshold; kept as the last line of defence
+	if (!full) {
 		for (int sb = 0; sb < nseg; sb += 4) {
 			const int sg = sb + wave;
-			const uint32_t c = (sg < nseg) ? min(cnts[sg], (uint32_t)capg) : 0u;
-			const uint2 *sp = cand + (q * nseg + (sg < nseg ? sg : 0)) * (int64_t)capg;
+			const int sp = sg % S;
+			const bool use = sg < nseg && !((bad[sp >> 5] >> (sp & 31)) & 1u);
+			const uint32_t c = use ? cnts[sg] : 0u;
+			const uint2 *sp_ptr = cand + (q * nseg + (sg < nseg ? sg : 0)) * (int64_t)capg;
 			for (uint32_t e0 = 0; e0 < maxc; e0 += WAVE) {
 				const uint32_t e = e0 + lane;
 				const bool in = e < c;
-				const uint2 ce = in ? sp[e] : make_uint2(0, 0);
+				const uint2 ce = in ? sp_ptr[e] : make_uint2(0, 0);
 				sel_offer(s, in, __uint_as_float(ce.x), ce.y, tau, tau_key);
 				sel_maybe_compact<KMAX>(s, k, tau, tau_key);
 			}
 		}
-	} else {
+	}
+	if (repair || full) {
 		if (tid == 0) atomicAdd(n_fallback, 1u);
 		for (int c = tid; c < KP; c += SEL_THREADS) xq[c] = bf16_bits_to_f32(X[q * ldx + c]);
 		__syncthreads();
+	}
+	if (repair) {
+		for (int sp = 0; sp < S; ++sp) {
+			if (!((bad[sp >> 5] >> (sp & 31)) & 1u)) continue;  // uniform
+			for (int g = 0; g < stg.n; ++g) {
+				const int t0 = stg.begin[g] + sp * stg.tps[g];
+				const int t1 = min(t0 + stg.tps[g], stg.end[g]);
+				int it = 0;
+				for (int64_t i0 = (int64_t)t0 * TILE_I; i0 < (int64_t)t1 * TILE_I; i0 += SEL_THREADS, ++it) {
+					const int64_t i = i0 + tid;
+					const bool in = i < (int64_t)t1 * TILE_I && i < I;
+					const float v = in ? score_of(i) : 0.f;
+					sel_offer(s, in, v, (uint32_t)i, tau, tau_key);
+					if ((it & 15) == 15) sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+				}
+				sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+			}
+		}
+		__syncthreads();
+		full = s.scal[0] < k && tau_key == 0;  // fewer than k even after the repair (and nothing was compacted away)
+	}
+	if (full) {
+		__syncthreads();
+		if (tid == 0) s.scal[0] = 0;
+		__syncthreads();
+		tau = -INFINITY; tau_key = 0;
 		int it = 0;
 		for (int64_t i0 = 0; i0 < I; i0 += SEL_THREADS, ++it) {
 			const int64_t i = i0 + tid;
 			const bool in = i < I;
-			float v = 0.f;
-			if (in) {
-				const uint4 *er = reinterpret_cast<const uint4 *>(Et + i * KP);
-				for (int c = 0; c < KP / 8; ++c) {
-					const uint4 w = er[c];
-					const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-					for (int d = 0; d < 4; ++d) {
-						v = fmaf(__uint_as_float(ww[d] << 16), xq[8 * c + 2 * d], v);
-						v = fmaf(__uint_as_float(ww[d] & 0xffff0000u), xq[8 * c + 2 * d + 1], v);
-					}
-				}
-			}
+			const float v = in ? score_of(i) : 0.f;
 			sel_offer(s, in, v, (uint32_t)i, tau, tau_key);
 			if ((it & 15) == 15) sel_maybe_compact<KMAX>(s, k, tau, tau_key);
 		}
@@ -767,9 +813,12 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	EV(3);
 	// 4. select
 	const int nseg = 2 * P.S;
+	SweepStages stages{};
+	stages.n = P.n_stages;
+	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) { stages.begin[g] = prev; stages.end[g] = P.stage_end[g]; stages.tps[g] = P.stage_tps[g]; }
 #define LAUNCH_SELECT(KM)                                                                                              \
 	do {                                                                                                               \
-		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)KP * 4;                                                     \
+		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)KP * 4 + 32;                                                \
 		static size_t attr_lds = 0;                                                                                    \
 		if (attr_lds < lds) {                                                                                          \
 			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_candidates_kernel<KM>,                              \
@@ -777,7 +826,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			attr_lds = lds;                                                                                            \
 		}                                                                                                              \
 		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, p.cand, p.seg_cnt, nseg, \
-						   P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt);  \
+						   P.S, stages, P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt);  \
 	} while (0)
 	// fast path: one wave per query; what it cannot take lands in hard_list for the workgroup-level kernel
 	const int32_t *hard_list = nullptr;

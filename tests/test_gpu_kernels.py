@@ -193,6 +193,28 @@ def test_fused_overflow_fallback_is_exact(ops):
 	assert i[0, 0].item() == first
 
 
+def test_fused_local_overflow_is_repaired_exactly(ops):
+	# a contiguous block of items scores far above the rest for every query: the item splits that sweep it overflow their
+	# candidate segments and wrap their LDS rings; only those splits are recomputed (select_candidates_kernel), the result is exact
+	Q, I, K, k = 300, 80000, 128, 100
+	g = _g(4242)
+	X = (1.0 + 0.1 * torch.randn(Q, K, generator=g)).bfloat16()
+	E = 0.05 * torch.randn(K, I, generator=g)
+	E[:, 41000:44000] += 0.5
+	E = E.bfloat16()
+	Xp = ops.pack_bf16(X.cuda(), 128); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 128, row_multiple=32)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	torch.cuda.synchronize()
+	assert nfb.item() > 0
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
+	got = i.cpu().long()
+	assert ((got >= 41000) & (got < 44000)).all()
+	torch.testing.assert_close(torch.gather(S, 1, got), v.cpu().double(), rtol=1e-4, atol=1e-4)
+	assert all(len(set(r.tolist())) == k for r in got)
+
+
 def test_fused_unsupported_shapes_raise(ops):
 	from anncur_amd._lib import AnncurHipError
 	assert not ops.fused_supported(1000, 5000, 64, 10)          # too few items for a sampled threshold

@@ -55,13 +55,26 @@ def plot(res_dir, method_vals):
 	return made
 
 
-def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overrides, dtype, device, pinv_backend="numpy"):
+def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overrides, dtype, device, pinv_backend="numpy", score_chunks=None):
 	from anncur_amd import harness
 	data_name, data_fname = data_info
-	LOGGER.info("Loading precomputed ment_to_ent scores")
-	dump = harness.load_score_pickle(data_fname["crossenc_ment_to_ent_scores"])
-	scores = dump["ment_to_ent_scores"]
-	total_n_ment, total_n_ent = scores.shape
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	chunked = None
+	if score_chunks:
+		# the producer's row chunks go straight to the device (each rank keeps its own row block): no combined pickle
+		from anncur_amd import ingest
+		LOGGER.info(f"Ingesting {len(score_chunks)} score chunks")
+		if world > 1:
+			device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+			torch.cuda.set_device(device)
+		chunked = ingest.load_score_chunks(score_chunks, device, dtype, rank=int(os.environ.get("RANK", "0")), world=world)
+		total_n_ment, total_n_ent = chunked["n_rows"], chunked["n_ent"]
+		scores = None
+	else:
+		LOGGER.info("Loading precomputed ment_to_ent scores")
+		dump = harness.load_score_pickle(data_fname["crossenc_ment_to_ent_scores"])
+		scores = dump["ment_to_ent_scores"]
+		total_n_ment, total_n_ent = scores.shape
 	grids = harness.default_grids_A(total_n_ment, total_n_ent)
 	for key, val in grid_overrides.items():
 		if val is not None:
@@ -70,7 +83,6 @@ def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overri
 	Path(res_dir).mkdir(exist_ok=True, parents=True)
 	other_args = {"arg_dict": arg_dict, "top_k_vals": grids["top_k_vals"], "top_k_retr_vals": grids["top_k_retr_vals"],
 				  "n_ent_anchors_vals": grids["n_ent_anchors_vals"], "n_ment_anchors_vals": grids["n_ment_anchors_vals"]}
-	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if not plot_only:
 		def progress(method, ctr, n):
 			if ctr % max(1, n // 10) == 0:
@@ -85,7 +97,8 @@ def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overri
 			if not dist.is_initialized():
 				dist.init_process_group(os.environ.get("ANNCUR_DIST_BACKEND", "nccl"))
 			s, e = shard_bounds(total_n_ment, dist.get_rank(), world)
-			sharded = ShardedScoreMatrix(harness.to_device_matrix(scores[s:e], device, dtype), total_n_ment)
+			local = chunked["A_local"] if chunked is not None else harness.to_device_matrix(scores[s:e], device, dtype)
+			sharded = ShardedScoreMatrix(local, total_n_ment)
 			if "cur_oracle" in grids["eval_methods"]:
 				LOGGER.info("row-sharded run: only method=cur is evaluated (cur_oracle needs the whole matrix on one device)")
 			grids["eval_methods"] = ["cur"]
@@ -93,7 +106,7 @@ def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overri
 			if eval_res is None:          # ranks > 0 are done
 				return res_dir
 		else:
-			A_dev = harness.to_device_matrix(scores, device, dtype)
+			A_dev = chunked["A_local"] if chunked is not None else harness.to_device_matrix(scores, device, dtype)
 			eval_res = harness.run_entry_A(A_dev, grids, n_seeds, progress, pinv_backend)
 		eval_res["other_args"] = other_args
 		with open(f"{res_dir}/retrieval_wrt_exact_crossenc.json", "w") as fout:
@@ -131,6 +144,8 @@ def main(argv=None):
 	parser.add_argument("--device", type=str, default="cuda:0")
 	parser.add_argument("--pinv", type=str, default="numpy", choices=["numpy", "device"],
 						help="pseudo-inverse: the reference's numpy.linalg.pinv on the host (bit-identical U) or Newton-Schulz on the GPU")
+	parser.add_argument("--score_chunks", type=str, nargs="+", default=None,
+						help="the producer's per-chunk score pickles (mention order) instead of the combined file: ingested chunk by chunk, row-sharded under torchrun")
 	args = parser.parse_args(argv)
 	if args.bi_model_file != "":
 		raise SystemExit("--bi_model_file: the bi-encoder baseline needs the reference's BERT models and is out of scope of this build")
@@ -141,7 +156,7 @@ def main(argv=None):
 			   n_seeds=args.n_seeds, plot_only=bool(args.plot_only), misc=misc, arg_dict=dict(args.__dict__),
 			   grid_overrides={"eval_methods": args.eval_methods, "n_ment_anchors_vals": args.n_ment_anchors_vals,
 							   "n_ent_anchors_vals": args.n_ent_anchors_vals, "top_k_vals": args.top_k_vals, "top_k_retr_vals": args.top_k_retr_vals},
-			   dtype=args.dtype, device=torch.device(args.device), pinv_backend=args.pinv)
+			   dtype=args.dtype, device=torch.device(args.device), pinv_backend=args.pinv, score_chunks=args.score_chunks)
 
 
 if __name__ == "__main__":

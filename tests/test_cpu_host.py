@@ -156,3 +156,58 @@ def test_split_producer_matches_reference_kat(tmp_path, golden_dir):
 		assert [int(x) for x in d["ment_idxs"]] == want["ment_idxs"], key
 		assert float(d["ment_to_ent_scores"][0, 0]) == want["first_score"] and sorted(d.keys()) == want["keys"]
 	assert not (tmp_path / "out" / "nm_train=200").exists()     # more train mentions than there are: skipped
+
+
+# ------------------------------------------------------------------ chunk ingestion: host logic on the CPU
+def _write_chunks(tmp_path, world, n_ent, sizes, seed=0, bad_entities_in=None):
+	import pickle
+	from anncur_amd import ingest
+	g = torch.Generator().manual_seed(seed)
+	files, mats, start = [], [], 0
+	for ci, n in enumerate(sizes):
+		m = torch.randn(n, n_ent, generator=g)
+		ids = np.arange(n_ent) if bad_entities_in != ci else np.arange(n_ent)[::-1].copy()
+		path = ingest.chunk_filename(str(tmp_path), world, n, n_ent, mstart=start)
+		os.makedirs(os.path.dirname(path), exist_ok=True)
+		with open(path, "wb") as f:
+			pickle.dump({"ment_to_ent_scores": m, "ment_to_ent_scores.shape": m.shape, "test_data": [{"mention_id": start + j} for j in range(n)],
+						 "mention_tokens_list": [[start + j] * 4 for j in range(n)], "entity_id_list": ids, "entity_tokens_list": None,
+						 "arg_dict": {"chunk": ci}}, f)
+		files.append(path); mats.append(m); start += n
+	return files, torch.cat(mats)
+
+
+def test_chunk_ingestion_names_shards_and_schema(tmp_path):
+	from anncur_amd import ingest
+	sizes = [50, 50, 27, 10]
+	files, full = _write_chunks(tmp_path, "lego", 300, sizes)
+	# the producer's naming convention round-trips
+	assert files[2].endswith("lego/ment_to_ent_scores_n_m_27_n_e_300_all_layers_Falsemstart_100.pkl")
+	assert ingest.parse_chunk_filename(files[2]) == (27, 300, 100)
+	assert ingest.parse_chunk_filename("ment_to_ent_scores_n_m_2500_n_e_34430_all_layers_False.pkl") == (2500, 34430, None)
+	assert ingest.parse_chunk_filename("something_else.pkl") is None
+	assert ingest.chunk_row_counts(files) == sizes
+	up = lambda rows, device, dtype: rows.clone()     # CPU stand-in for the HIP upload/convert
+	whole = ingest.load_score_chunks(files, "cpu", "fp32", upload=up)
+	assert whole["n_rows"] == 137 and whole["n_ent"] == 300 and whole["row_range"] == (0, 137)
+	assert torch.equal(whole["A_local"], full)
+	assert [d["mention_id"] for d in whole["test_data"]] == list(range(137)) and whole["arg_dict"] == {"chunk": 3}
+	# row-sharded: the blocks of the ranks tile the matrix in order, whatever the chunk boundaries
+	for world in (2, 3, 5):
+		blocks = [ingest.load_score_chunks(files, "cpu", "fp32", rank=r, world=world, upload=up) for r in range(world)]
+		assert torch.equal(torch.cat([b["A_local"] for b in blocks]), full)
+		assert [b["row_range"] for b in blocks] == [__import__("anncur_amd.dist", fromlist=["x"]).shard_bounds(137, r, world) for r in range(world)]
+	# the combined file has the reference's schema and content
+	out = ingest.combine_score_chunks(files, str(tmp_path / "comb.pkl"))
+	import pickle
+	d = pickle.load(open(out, "rb"))
+	assert set(d) == {"ment_to_ent_scores", "ment_to_ent_scores.shape", "test_data", "mention_tokens_list", "entity_id_list", "entity_tokens_list", "arg_dict"}
+	assert torch.equal(d["ment_to_ent_scores"], full) and tuple(d["ment_to_ent_scores.shape"]) == (137, 300) and len(d["mention_tokens_list"]) == 137
+	with pytest.raises(FileExistsError):
+		ingest.combine_score_chunks(files, out)
+	# the reference's consistency checks
+	bad, _ = _write_chunks(tmp_path / "bad", "lego", 300, [20, 20], bad_entities_in=1)
+	with pytest.raises(ValueError, match="entity_id_list"):
+		ingest.load_score_chunks(bad, "cpu", "fp32", upload=up)
+	with pytest.raises(ValueError, match="empty"):
+		ingest.load_score_chunks([], "cpu")

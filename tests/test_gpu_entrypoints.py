@@ -166,3 +166,33 @@ def test_row_sharded_entry_A_equals_single_process(gpu):
 	for t in ("anchor", "non_anchor", "all"):
 		for m, (sharded, single) in res[t].items():
 			assert sharded == pytest.approx(single, rel=1e-5, abs=1e-6), (t, m)
+
+
+def test_entry_A_from_score_chunks_equals_combined_pickle(gpu, tmp_path):
+	"""the producer's row chunks ingested straight to the device give the same results file as the combined pickle
+	(the reference's pickle -> cat -> pickle -> load route), and the combiner writes that pickle with the reference's schema."""
+	from eval import run_retrieval_eval_wrt_exact_crossenc as epA
+	from eval import combine_chunked_computations as comb
+	from anncur_amd import ingest
+	from utils.zeshel_utils import N_ENTS_ZESHEL, score_matrix_filename
+	torch.manual_seed(5)
+	A = torch.randn(700, 24) @ torch.randn(24, 4000) / (24 ** 0.5) + 0.1 * torch.randn(700, 4000)
+	res_dir = str(tmp_path / "res")
+	files, start = [], 0
+	for n in (300, 300, 100):
+		path = ingest.chunk_filename(res_dir, "lego", n, N_ENTS_ZESHEL["lego"], mstart=start)
+		_dump(path, A[start:start + n].clone(), test_data=[{"i": start + j} for j in range(n)])
+		files.append(path); start += n
+	common = ["--data_name", "lego", "--res_dir", res_dir, "--n_ment", "700", "--n_seeds", "2", "--disable_wandb", "1", "--eval_methods", "cur",
+			  "--n_ment_anchors_vals", "100", "--n_ent_anchors_vals", "50", "--top_k_vals", "1,10", "--top_k_retr_vals", "100"]
+	out_a = epA.main(common + ["--misc", "chunks", "--score_chunks"] + files)
+	combined = comb.combine_m2e_eval_results(files, res_dir=res_dir, dataset_name="lego")
+	assert combined == score_matrix_filename(res_dir, "lego", 700)
+	out_b = epA.main(common + ["--misc", "pickle"])
+	ra = json.load(open(os.path.join(out_a, "retrieval_wrt_exact_crossenc.json")))
+	rb = json.load(open(os.path.join(out_b, "retrieval_wrt_exact_crossenc.json")))
+	assert ra["cur"] == rb["cur"]
+	for bf in ("fp32", "bf16"):   # the device block equals the matrix (bf16: rounded once on the device)
+		blk = ingest.load_score_chunks(files, gpu, bf)
+		want = A.cuda() if bf == "fp32" else A.cuda().bfloat16()
+		assert blk["A_local"].dtype == want.dtype and torch.equal(blk["A_local"], want) and blk["row_range"] == (0, 700)

@@ -58,6 +58,11 @@ def main():
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
 	cfg = CONFIGS[args.config]
+	# stdout carries exactly ONE line (the result JSON): libraries that print banners to fd 1 (RCCL at communicator creation
+	# does) are sent to stderr for the whole run, the JSON goes to the saved descriptor at the end
+	sys.stdout.flush()
+	result_fd = os.dup(1)
+	os.dup2(2, 1)
 
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	rank = int(os.environ.get("RANK", "0"))
@@ -318,7 +323,8 @@ def main():
 							   "recall_gpu_same_queries": {f"recall@{t}": got[t][key] for t in top_k_vals}}
 		out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
 	if rank == 0:
-		print(json.dumps(out))
+		sys.stdout.flush()
+		os.write(result_fd, (json.dumps(out) + "\n").encode())
 	if use_dist:
 		torch.distributed.destroy_process_group()
 

@@ -61,6 +61,10 @@ def load():
 		raise AnncurHipError(
 			f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
 			"(or `make -C anncur_amd/csrc`). anncur_amd has no CPU fallback.")
+	# torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  The library binds to whichever libamdhip64 the
+	# process loaded first; had it pulled in /opt/rocm's copy before torch loaded its own, the process would hold two runtimes and
+	# the kernels here would launch on one that never saw torch's device context ("no ROCm-capable device is detected").
+	import torch  # noqa: F401
 	lib = ctypes.CDLL(LIB_PATH)
 	for name, (res, args) in SIGNATURES.items():
 		fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -337,6 +337,9 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 #pragma unroll
 		for (int s = 0; s < KSTEPS; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
 		int flush_in2 = p.flush_tiles;
+		// stagger_tile() counts LDS reads with lgkmcnt(n): no scalar load of the prologue may still be in flight (scalar loads share
+		// the counter and return out of order)
+		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
 #define STAGGER_STEP(CUR, J)                                                                                                    \
 		do {                                                                                                                    \
 			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		const bool in = lane < I - tail0;
 		wsel_offer_inorder(w, in, in ? load_as_f32<T>(row + tail0 + lane) : 0.f, (uint32_t)(tail0 + lane));
 	}
-	wsel_finish<WS_CAP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	wsel_finish<WS_CAP, HP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
 
 // ------------------------------------------------------------------ k-th largest VALUE of short fp32 rows, one wave per row

@@ -238,12 +238,12 @@ __device__ __forceinline__ void wave_sort128_desc(uint32_t (&hi)[2], uint32_t (&
 }
 
 // Reduce to the k best, sort them, write the output row.  Fewer than k candidates -> (-inf, -1) padding.
-template <int OUTLINED_CAP = 0>
+template <int OUTLINED_CAP = 0, int HI_PASSES = 4>
 __device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx) {
 	const int lane = lane_id();
 	if (w.cnt > k) {
-		if constexpr (OUTLINED_CAP > 0) wsel_compact_call<OUTLINED_CAP, 4, false>(w, k);
-		else wsel_compact<4, false>(w, k);
+		if constexpr (OUTLINED_CAP > 0) wsel_compact_call<OUTLINED_CAP, HI_PASSES, false>(w, k);
+		else wsel_compact<HI_PASSES, false>(w, k);
 	}
 	__builtin_amdgcn_wave_barrier();
 	uint32_t sh[2], sl[2];

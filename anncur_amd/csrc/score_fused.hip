@@ -15,12 +15,14 @@
 //
 // Launches (all on the caller's stream):
 //   1. prepass   : group maxima of S_hat over a strided sample of item tiles  -> gmax[Q x G]
-//   2. threshold : tau[q] = k-th largest group maximum (exact scan kernel)    -> a lower bound on the
+//   2. threshold : tau[q] = k-th largest group maximum (wave-per-query radix select) -> a lower bound on the
 //                  k-th best score of the query (k distinct groups each hold an element >= tau)
-//   3. sweep     : all tiles; every S_hat[q,i] >= tau[q] is appended to the lane's private candidate
-//                  segment in HBM (no atomics, no LDS traffic)
-//   4. select    : per query, exact top-k of its candidates (radix select + bitonic sort in LDS);
-//                  a query whose segment overflowed is recomputed exactly inside the same kernel.
+//   3. sweep     : all tiles, in 1-3 stages (plan_fused picks the split); every S_hat[q,i] >= tau[q] goes through the
+//                  lane's private LDS ring to the lane's private candidate segment in HBM (no atomics); between stages
+//                  a wave-per-query kernel raises tau[q] to the k-th best candidate collected so far
+//   4. select    : per query, exact top-k of its candidates (wave-level selector; workgroup-level kernel for k > 128).
+//                  A segment that overflowed or whose ring wrapped is repaired by recomputing only the item tiles its
+//                  split swept; nothing leaves the call inexact.
 // Algorithmic work: 2*Q*Kp*I flops in (3) (+ sample fraction in (1)).
 #include <stdlib.h>
 #include <type_traits>

@@ -29,6 +29,7 @@ SIGNATURES = {
 							   c_int64, c_int64, c_int64, ctypes.c_float, ctypes.c_float, c_void_p, c_int64, c_int64, c_void_p]),
 	"anncur_sumsq": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
 	"anncur_scale_copy": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, ctypes.c_float, c_void_p, c_void_p]),
+	"anncur_approx_error_packed": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_approx_error": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64,
 									c_int64, c_void_p, c_void_p, c_void_p]),
 	"anncur_rowwise_topk": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

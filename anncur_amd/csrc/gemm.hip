@@ -196,9 +196,10 @@ extern "C" int anncur_gemm(const void *A, int a_dtype, int64_t a_sm, int64_t a_s
 	return anncur_gemm_ex(A, a_dtype, a_sm, a_sk, B, b_dtype, b_sk, b_sn, C, c_dtype, c_sm, c_sn, M, N, K, 1.0f, 0.0f, nullptr, 0, 0, stream);
 }
 
-extern "C" int anncur_approx_error(const void *X, int x_dtype, int64_t ldx, const void *Et, int e_dtype, int64_t lde,
-								   const void *Aex, int a_dtype, int64_t lda, int64_t Q, int64_t I, int64_t K, float *err_sq,
-								   float *norm_sq, void *stream) {
+// err_sq / norm_sq are ACCUMULATED into (the public entry point zeroes them first; score_fused.hip adds a column range)
+int anncur_internal_approx_error_acc(const void *X, int x_dtype, int64_t ldx, const void *Et, int e_dtype, int64_t lde,
+									 const void *Aex, int a_dtype, int64_t lda, int64_t Q, int64_t I, int64_t K, float *err_sq,
+									 float *norm_sq, void *stream) {
 	ANNCUR_REQUIRE(dtype_ok(x_dtype) && dtype_ok(e_dtype) && dtype_ok(a_dtype), ANNCUR_E_INVALID, "approx_error: bad dtype");
 	ANNCUR_REQUIRE(Q >= 0 && I >= 1 && K >= 1 && ldx >= K && lde >= K && lda >= I, ANNCUR_E_INVALID, "approx_error: bad shape");
 	ANNCUR_REQUIRE(X && Et && Aex && err_sq && norm_sq, ANNCUR_E_INVALID, "approx_error: null pointer");
@@ -206,8 +207,6 @@ extern "C" int anncur_approx_error(const void *X, int x_dtype, int64_t ldx, cons
 	const int64_t gx = ceil_div64(I, BN), gy = ceil_div64(Q, BM);
 	ANNCUR_REQUIRE(gy <= 65535, ANNCUR_E_INVALID, "approx_error: Q too large for one launch");
 	hipStream_t st = (hipStream_t)stream;
-	ANNCUR_HIP_OK(hipMemsetAsync(err_sq, 0, (size_t)Q * 4, st));
-	ANNCUR_HIP_OK(hipMemsetAsync(norm_sq, 0, (size_t)Q * 4, st));
 	dispatch3<1>(x_dtype, e_dtype, a_dtype, [&](auto *a, auto *b, auto *c) {
 		using TA = std::remove_cv_t<std::remove_pointer_t<decltype(a)>>;
 		using TB = std::remove_cv_t<std::remove_pointer_t<decltype(b)>>;
@@ -220,6 +219,16 @@ extern "C" int anncur_approx_error(const void *X, int x_dtype, int64_t ldx, cons
 	});
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
+}
+
+extern "C" int anncur_approx_error(const void *X, int x_dtype, int64_t ldx, const void *Et, int e_dtype, int64_t lde,
+								   const void *Aex, int a_dtype, int64_t lda, int64_t Q, int64_t I, int64_t K, float *err_sq,
+								   float *norm_sq, void *stream) {
+	ANNCUR_REQUIRE(err_sq && norm_sq && Q >= 0, ANNCUR_E_INVALID, "approx_error: null pointer");
+	if (Q == 0) return ANNCUR_OK;
+	ANNCUR_HIP_OK(hipMemsetAsync(err_sq, 0, (size_t)Q * 4, (hipStream_t)stream));
+	ANNCUR_HIP_OK(hipMemsetAsync(norm_sq, 0, (size_t)Q * 4, (hipStream_t)stream));
+	return anncur_internal_approx_error_acc(X, x_dtype, ldx, Et, e_dtype, lde, Aex, a_dtype, lda, Q, I, K, err_sq, norm_sq, stream);
 }
 
 // ------------------------------------------------------------------ small helpers for the on-device pseudo-inverse

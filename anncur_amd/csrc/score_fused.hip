@@ -440,6 +440,116 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	}
 }
 
+// ------------------------------------------------------------------ a11: approximation error on the same MFMA loop
+// err_sq[q] += sum_i (S_hat[q,i] - A[q,i])^2, norm_sq[q] += sum_i A[q,i]^2 over this workgroup's item tiles; S_hat is never
+// written.  Same orientation as the sweep: lane = query, so both sums are lane-local accumulators and the exact matrix is read
+// as 4 consecutive items (8 or 16 bytes) per lane and accumulator register group; the next tile's exact values are in flight
+// during the MFMAs.  One atomicAdd pair per lane at the end (2 S per query).
+template <typename TA> struct ExactQuad;
+template <> struct ExactQuad<uint16_t> {
+	uint2 w;
+	__device__ __forceinline__ void load(const uint16_t *p) { w = *reinterpret_cast<const uint2 *>(p); }
+	__device__ __forceinline__ float get(int c) const {
+		const uint32_t x = (c & 2) ? w.y : w.x;
+		return __uint_as_float((c & 1) ? (x & 0xffff0000u) : (x << 16));
+	}
+};
+template <> struct ExactQuad<float> {
+	float4 w;
+	__device__ __forceinline__ void load(const float *p) { w = *reinterpret_cast<const float4 *>(p); }
+	__device__ __forceinline__ float get(int c) const { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; }
+};
+
+// Full 32-item tiles only (p.n_tiles = I / 32): the host adds the last I % 32 columns with the strided kernel of gemm.hip.
+template <int KP, typename TA>
+__global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, const TA *__restrict__ Aex, int64_t lda,
+														float *__restrict__ err_sq, float *__restrict__ norm_sq) {
+	using Cfg = FusedCfg<KP>;
+	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int r = lane & 31, h = lane >> 5;
+	const int wid = xcd_remap(blockIdx.x, p.n_wg);
+	const int n_rb = (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ);
+	const int split = wid / n_rb, rb = wid - split * n_rb;
+
+	bf16x8 xb[QT][KSTEPS];
+	int64_t qv[QT];
+	const TA *rowp[QT];  // this lane's row of the exact matrix, at its half's first item of a tile
+#pragma unroll
+	for (int t = 0; t < QT; ++t) {
+		qv[t] = (int64_t)rb * Cfg::BQ + wave * 32 * QT + 32 * t + r;
+		const bool ok = qv[t] < p.Q;
+		rowp[t] = Aex + (ok ? qv[t] : 0) * lda + 4 * h;  // rows past Q read row 0 (their sums are dropped)
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(p.X + (ok ? qv[t] : 0) * p.ldx) + h;
+#pragma unroll
+		for (int s = 0; s < KSTEPS; ++s) {
+			const u32x4 zero = {0u, 0u, 0u, 0u};
+			const u32x4 w = ok ? src[2 * s] : zero;
+			xb[t][s] = __builtin_bit_cast(bf16x8, w);
+		}
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);  // see score_kernel: keeps vmcnt(0) out of the tile loop
+
+	const int j_begin = split * p.tiles_per_split, j_end = min(j_begin + p.tiles_per_split, p.n_tiles);
+	float se[QT], sn[QT];
+	ExactQuad<TA> ex[QT][4];  // exact values of the tile whose MFMAs run next: items 32 j + 8 g + 4 h + {0..3}, g = 0..3
+#pragma unroll
+	for (int t = 0; t < QT; ++t) { se[t] = 0.f; sn[t] = 0.f; }
+	if (j_begin < j_end) {
+		tile_dma<KP>(p.Et, j_begin, smem, wave, lane);
+#pragma unroll
+		for (int t = 0; t < QT; ++t)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) ex[t][g].load(rowp[t] + (int64_t)j_begin * TILE_I + 8 * g);
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);
+	__syncthreads();
+	for (int j = j_begin; j < j_end; ++j) {
+		const int cur = (j - j_begin) & 1;
+		const bool more = j + 1 < j_end;
+		if (more) tile_dma<KP>(p.Et, j + 1, smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
+		f32x16 acc[QT];
+#pragma unroll
+		for (int t = 0; t < QT; ++t)
+#pragma unroll
+			for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+		const u32x4 *tb = reinterpret_cast<const u32x4 *>(smem + cur * Cfg::TILE_BYTES);
+#pragma unroll
+		for (int s = 0; s < KSTEPS; ++s) {
+			const u32x4 w = tb[r * CPR + swz<CPR>(r, 2 * s + h)];
+			const bf16x8 a = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+			for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[t][s], acc[t], 0, 0, 0);
+		}
+#pragma unroll
+		for (int t = 0; t < QT; ++t)
+#pragma unroll
+			for (int e = 0; e < 16; ++e) {
+				const float x = ex[t][e >> 2].get(e & 3);
+				const float d = acc[t][e] - x;
+				se[t] = fmaf(d, d, se[t]);
+				sn[t] = fmaf(x, x, sn[t]);
+			}
+		// the next tile's exact values are requested now and consumed after the next MFMA chain; the wait below covers the
+		// tile DMA only (loads return in order: the QT*4 quads issued after it may still be in flight)
+		if (more) {
+#pragma unroll
+			for (int t = 0; t < QT; ++t)
+#pragma unroll
+				for (int g = 0; g < 4; ++g) ex[t][g].load(rowp[t] + (int64_t)(j + 1) * TILE_I + 8 * g);
+			__builtin_amdgcn_s_waitcnt(QT == 2 ? 0x0F78 : 0x0F74);  // vmcnt(8) / vmcnt(4)
+		}
+		__syncthreads();
+	}
+#pragma unroll
+	for (int t = 0; t < QT; ++t)
+		if (qv[t] < p.Q) {
+			atomicAdd(&err_sq[qv[t]], se[t]);
+			atomicAdd(&norm_sq[qv[t]], sn[t]);
+		}
+}
+
 // ------------------------------------------------------------------ select
 // Item-tile ranges of the sweep stages (which tiles item split s swept in stage g): [begin[g] + s*tps[g], + tps[g]) below end[g].
 struct SweepStages {
@@ -926,5 +1036,57 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 	const FusedPlan P = plan_fused(Q, I, Kp, k);
 	ANNCUR_REQUIRE(P.ok && out5, ANNCUR_E_UNSUPPORTED, "score_topk_plan: unsupported shape");
 	out5[0] = P.n_st; out5[1] = P.n_tiles; out5[2] = P.S; out5[3] = P.capg; out5[4] = P.group;
+	return ANNCUR_OK;
+}
+
+/* a11 on packed bf16 operands (the layout of anncur_score_topk): err_sq[q] = sum_i (X[q,:].Et[i,:] - A[q,i])^2, norm_sq[q] = sum_i A[q,i]^2 */
+extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *A, int a_dtype, int64_t lda,
+										  int64_t Q, int64_t I, int32_t Kp, float *err_sq, float *norm_sq, void *stream) {
+	ANNCUR_REQUIRE(Kp == 64 || Kp == 128 || Kp == 256 || Kp == 512, ANNCUR_E_UNSUPPORTED, "approx_error_packed: Kp must be 64, 128, 256 or 512 (got %d)", Kp);
+	ANNCUR_REQUIRE(dtype_ok(a_dtype), ANNCUR_E_INVALID, "approx_error_packed: bad dtype");
+	ANNCUR_REQUIRE(Q >= 0 && I >= 1 && I < (int64_t)0x7fffffff - 64 && lda >= I, ANNCUR_E_INVALID, "approx_error_packed: bad shape");
+	ANNCUR_REQUIRE(X && Et && A && err_sq && norm_sq, ANNCUR_E_INVALID, "approx_error_packed: null pointer");
+	ANNCUR_REQUIRE(lde == Kp && ldx >= Kp && (ldx % 8) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Et % 16) == 0, ANNCUR_E_INVALID,
+				   "approx_error_packed: X / Et must be packed bf16 (lde == Kp, ldx multiple of 8, 16-byte aligned)");
+	ANNCUR_REQUIRE((lda % 4) == 0 && ((uintptr_t)A % 16) == 0, ANNCUR_E_UNSUPPORTED,
+				   "approx_error_packed: the exact matrix must be 16-byte aligned with lda a multiple of 4 (use anncur_approx_error otherwise)");
+	if (Q == 0) return ANNCUR_OK;
+	hipStream_t st = (hipStream_t)stream;
+	ANNCUR_HIP_OK(hipMemsetAsync(err_sq, 0, (size_t)Q * 4, st));
+	ANNCUR_HIP_OK(hipMemsetAsync(norm_sq, 0, (size_t)Q * 4, st));
+	const int64_t I_full = I / TILE_I * TILE_I;
+	if (I_full < I) {  // the last I % 32 columns: strided kernel of gemm.hip, accumulating into the same sums
+		const int rc = anncur_internal_approx_error_acc((const uint16_t *)X, ANNCUR_BF16, ldx, (const uint16_t *)Et + I_full * lde, ANNCUR_BF16, lde,
+														a_dtype == ANNCUR_F32 ? (const void *)((const float *)A + I_full) : (const void *)((const uint16_t *)A + I_full),
+														a_dtype, lda, Q, I - I_full, Kp, err_sq, norm_sq, stream);
+		if (rc != ANNCUR_OK) return rc;
+	}
+	if (I_full == 0) return ANNCUR_OK;
+	FusedParams p{};
+	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I_full;
+	const int QT = (Kp <= 256) ? 2 : 1, BQ = 128 * QT;
+	const int n_rb = (int)ceil_div64(Q, BQ);
+	p.n_tiles = (int)(I_full / TILE_I);
+	int S = 2 * num_cu() / n_rb;
+	if (S < 1) S = 1;
+	if (S > p.n_tiles) S = p.n_tiles;
+	p.tiles_per_split = (p.n_tiles + S - 1) / S;
+	S = (p.n_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
+	p.n_wg = n_rb * S;
+#define LAUNCH_ERR(KPV, TA)                                                                                                   \
+	hipLaunchKernelGGL((error_kernel<KPV, TA>), dim3(p.n_wg), dim3(256), 2 * FusedCfg<KPV>::TILE_BYTES, st, p, (const TA *)A, lda, err_sq, norm_sq)
+#define LAUNCH_ERR_K(TA)                                                                                                      \
+	do {                                                                                                                      \
+		switch (Kp) {                                                                                                         \
+			case 64: LAUNCH_ERR(64, TA); break;                                                                               \
+			case 128: LAUNCH_ERR(128, TA); break;                                                                             \
+			case 256: LAUNCH_ERR(256, TA); break;                                                                             \
+			default: LAUNCH_ERR(512, TA); break;                                                                              \
+		}                                                                                                                     \
+	} while (0)
+	if (a_dtype == ANNCUR_F32) LAUNCH_ERR_K(float); else LAUNCH_ERR_K(uint16_t);
+#undef LAUNCH_ERR_K
+#undef LAUNCH_ERR
+	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -187,8 +187,12 @@ class CURApprox(object):
 		return TopK(self._back(v, sparse_rows), self._back(i.long(), sparse_rows))
 
 	def approx_error_rows(self, sparse_rows, exact_rows):
-		"""Per-row sum (S_hat - A)^2 and sum A^2 (a11) without materialising S_hat."""
-		return ops.approx_error(self._to_dev(sparse_rows), self._Et, self._to_dev(exact_rows))
+		"""Per-row sum (S_hat - A)^2 and sum A^2 (a11) without materialising S_hat.  On the bf16 route S_hat is the one the retrieval
+		ranks (bf16 item embeddings), computed on the sweep's MFMA loop."""
+		X, A = self._to_dev(sparse_rows), self._to_dev(exact_rows)
+		if self.compute_dtype == "bf16" and self._Etp is not None and ops.approx_error_packed_ok(self._Etp.shape[1], A):
+			return ops.approx_error_packed(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, A, self.m)
+		return ops.approx_error(X, self._Et, A)
 
 
 class CURRowIndex(object):
@@ -221,4 +225,6 @@ class CURRowIndex(object):
 		return ops.score_topk_dense(X, Et, k)
 
 	def approx_error_rows(self, X, exact_rows):
+		if self.compute_dtype == "bf16" and self._Etp is not None and ops.approx_error_packed_ok(self._Etp.shape[1], exact_rows):
+			return ops.approx_error_packed(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, exact_rows, self.m)
 		return ops.approx_error(X, self._Et, exact_rows)

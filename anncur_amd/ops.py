@@ -167,6 +167,26 @@ def approx_error(X, Et, A_exact):
 	return err, nrm
 
 
+def approx_error_packed_ok(Kp, A_exact):
+	"""True if anncur_approx_error_packed takes these operands (bf16 MFMA loop of the sweep instead of the strided fp32 GEMM)."""
+	return Kp in (64, 128, 256, 512) and A_exact.stride(1) == 1 and A_exact.stride(0) % 4 == 0 and A_exact.data_ptr() % 16 == 0
+
+
+def approx_error_packed(Xp, Etp, A_exact, n_items):
+	"""a11 on the fused path's operands: Xp [Q x Kp] packed bf16, Etp [ceil32(I) x Kp] packed bf16, A_exact [Q x I] fp32 / bf16."""
+	_dev(Xp, Etp, A_exact)
+	Q, Kp = Xp.shape
+	if Etp.shape[1] != Kp or tuple(A_exact.shape) != (Q, n_items) or Etp.shape[0] < (n_items + 31) // 32 * 32:
+		raise ValueError("approx_error_packed: shape mismatch")
+	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16 or not approx_error_packed_ok(Kp, A_exact):
+		raise ValueError("approx_error_packed: operands must be packed bf16 and the exact matrix 16-byte aligned with a row pitch multiple of 4")
+	err = torch.empty(Q, dtype=torch.float32, device=Xp.device)
+	nrm = torch.empty(Q, dtype=torch.float32, device=Xp.device)
+	check(_lib.load().anncur_approx_error_packed(_p(Xp), _ld(Xp), _p(Etp), _ld(Etp), _p(A_exact), _dt(A_exact), _ld(A_exact), Q, n_items, Kp,
+												 _p(err), _p(nrm), _stream()), "approx_error_packed")
+	return err, nrm
+
+
 # ------------------------------------------------------------------ a7/a8
 def rowwise_topk(A, k):
 	"""Exact torch.topk(A, k, dim=1) on the device: (values f32 [Q,k], indices int32 [Q,k]),

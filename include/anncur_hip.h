@@ -100,6 +100,14 @@ int anncur_approx_error(const void *X, int x_dtype, int64_t ldx,
                         int64_t Q, int64_t I, int64_t K,
                         float *err_sq, float *norm_sq, void *stream);
 
+/* The same on the fused path's packed bf16 operands (layouts of anncur_score_topk: X [Q x Kp], Et [ceil32(I) x Kp], Kp in
+ * {64,128,256,512}), on the bf16 MFMA loop of the sweep instead of the strided fp32 GEMM: ~25x faster at Q=10k, I=100k, Kp=256.
+ * A: fp32 or bf16, 16-byte aligned, lda a multiple of 4 (ANNCUR_E_UNSUPPORTED otherwise: use anncur_approx_error). */
+int anncur_approx_error_packed(const void *X, int64_t ldx, const void *Et, int64_t lde,
+                               const void *A, int a_dtype, int64_t lda,
+                               int64_t Q, int64_t I, int32_t Kp,
+                               float *err_sq, float *norm_sq, void *stream);
+
 /* a7/a8: exact row-wise top-k of a stored matrix (HBM-streaming scan) ---------------
  *   torch.topk(S, k, dim=1)                  eval/matrix_approx_zeshel.py:106,126
  *   curr_ment_scores.topk(top_k)             ...crossenc.py:103 ; ..._splits.py:86

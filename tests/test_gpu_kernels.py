@@ -310,3 +310,29 @@ def test_rowwise_topk_threshold_crossing_zero_nan_and_sorted_rows(ops, dtype):
 		v, i = ops.rowwise_topk(view, 64)
 		order = torch.argsort(view.float().cpu(), dim=1, descending=True, stable=True)[:, :64]
 		assert torch.equal(i.cpu().long(), order)
+
+
+@pytest.mark.parametrize("Q,I,K,adt", [(300, 4096, 64, torch.bfloat16), (257, 10031, 128, torch.bfloat16), (130, 7000, 256, torch.bfloat16),
+									   (70, 5023, 500, torch.bfloat16), (129, 6400, 256, torch.float32), (40, 40, 64, torch.bfloat16), (33, 20, 128, torch.float32)])
+def test_approx_error_packed_matches_strided_and_fp64(ops, Q, I, K, adt):
+	"""a11 on the sweep's MFMA loop (full 32-item tiles + the strided kernel for the last I % 32 columns) against the strided fp32
+	GEMM reduction on the same bf16 operands and against fp64 on the CPU."""
+	g = _g(Q + I + K)
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	E = (torch.randn(K, I, generator=g) / K ** 0.5).bfloat16()
+	ld = (I + 3) // 4 * 4 + 8                                      # padded rows (row pitch a multiple of 4)
+	Abuf = torch.zeros(Q, ld, dtype=adt)
+	Abuf[:, :I] = (X.float() @ E.float() + 0.3 * torch.randn(Q, I, generator=g)).to(adt)
+	A = Abuf.cuda()[:, :I]
+	Kp = ops.padded_k(K)
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	assert ops.approx_error_packed_ok(Kp, A)
+	err, nrm = ops.approx_error_packed(Xp, Etp, A, I)
+	err2, nrm2 = ops.approx_error(X.cuda(), E.t().contiguous().cuda(), A)
+	torch.testing.assert_close(err.cpu(), err2.cpu(), rtol=2e-4, atol=1e-4)
+	torch.testing.assert_close(nrm.cpu(), nrm2.cpu(), rtol=1e-5, atol=1e-5)
+	S = X.double() @ E.double()
+	Ad = Abuf[:, :I].double()
+	torch.testing.assert_close(err.cpu().double(), ((S - Ad) ** 2).sum(1), rtol=2e-4, atol=1e-4)
+	torch.testing.assert_close(nrm.cpu().double(), (Ad ** 2).sum(1), rtol=1e-5, atol=1e-5)
+	assert not ops.approx_error_packed_ok(Kp, Abuf.cuda()[:, 1:I + 1])   # misaligned view: callers fall back to the strided kernel

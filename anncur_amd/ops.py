@@ -286,6 +286,16 @@ def fused_plan(Q, I, Kp, k):
 	return dict(zip(("n_sample_tiles", "n_tiles", "splits", "segment_capacity", "group"), [int(x) for x in out]))
 
 
+def _dense_scores(X, Et):
+	"""S = X @ Et^T with fp32 sums.  bf16 x bf16 operands of GEMM size go to the library GEMM (hipBLASLt through torch.mm, fp32
+	output: a plain GEMM, ~750 TFLOP/s); everything else to the strided fp32-MFMA kernel (exact fp32 products, any strides)."""
+	K = X.shape[1]
+	if (X.dtype == torch.bfloat16 and Et.dtype == torch.bfloat16 and K >= 128 and X.shape[0] * Et.shape[0] >= (1 << 20)
+			and X.stride(1) == 1 and Et.stride(1) == 1):
+		return torch.mm(X, Et.t(), out_dtype=torch.float32)
+	return gemm(X, Et.t())
+
+
 def score_topk_dense(X, Et, k, max_bytes=2 << 30):
 	"""Unfused route: S = X @ Et^T in fp32 (row chunks), then the exact scan.  Any K, any dtype."""
 	_dev(X, Et)
@@ -295,7 +305,7 @@ def score_topk_dense(X, Et, k, max_bytes=2 << 30):
 	rows = max(1, min(Q, max_bytes // max(4 * I, 1)))
 	for q0 in range(0, Q, rows):
 		q1 = min(Q, q0 + rows)
-		S = gemm(X[q0:q1], Et.t())
+		S = _dense_scores(X[q0:q1], Et)
 		v, i = rowwise_topk(S, k)
 		val[q0:q1], idx[q0:q1] = v, i
 	return TopK(val, idx)

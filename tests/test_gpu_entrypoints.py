@@ -205,3 +205,27 @@ def test_entry_A_from_score_chunks_equals_combined_pickle(gpu, tmp_path):
 		blk = ingest.load_score_chunks(files, gpu, bf)
 		want = A.cuda() if bf == "fp32" else A.cuda().bfloat16()
 		assert blk["A_local"].dtype == want.dtype and torch.equal(blk["A_local"], want) and blk["row_range"] == (0, 700)
+
+
+def test_bench_contract_small_config(gpu):
+	"""bench.py prints exactly one JSON line on stdout with the driver's keys plus `roofline` and `cpu_baseline` (small config)."""
+	import subprocess, sys
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "small", "--steps", "3", "--warmup", "1", "--cpu-sample-queries", "256"],
+						 capture_output=True, text=True, timeout=600)
+	assert out.returncode == 0, out.stderr[-2000:]
+	lines = [l for l in out.stdout.splitlines() if l.strip()]
+	assert len(lines) == 1, out.stdout[-2000:]
+	d = json.loads(lines[0])
+	for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+				"roofline", "cpu_baseline"):
+		assert key in d, key
+	assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["unit"] == "queries/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+	assert d["value"] > 0 and abs(d["value"] - 2000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+	assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "mfma"
+	assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+	assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+	assert "workload" in d["config"] and "model" not in d["config"]
+	# same queries through both paths: identical recall up to the tie-stable statement of the reference loop
+	for key, want in d["cpu_baseline"]["recall_cpu_fp32_tie_stable"].items():
+		assert abs(d["cpu_baseline"]["recall_gpu_same_queries"][key] - want) <= 5e-3, key

@@ -306,30 +306,14 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 }
 
 // ------------------------------------------------------------------ k-th largest VALUE of short fp32 rows, one wave per row
-// (the fused path's threshold step: rows of a few hundred group maxima).  No LDS, no barriers.
-template <int NR>
+// (the fused path's threshold step: rows of a few hundred group maxima).  The row's sortable keys go to a wave-private LDS
+// array; MSB-first radix select with 8-bit digits (wsel_kth: four histogram passes instead of 32 bit-by-bit ballot rounds).
+// No workgroup barrier.  NaN is never selected.
+constexpr int KTH_MAX_N = 2048;
 __global__ __launch_bounds__(256) void kth_value_wave_kernel(const float *__restrict__ G, int64_t Q, int n, int64_t ldg, uint32_t k,
 															  float *__restrict__ out, int64_t out_stride) {
-	const int lane = lane_id();
-	const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	if (q >= Q) return;
-	uint32_t key[NR];
-	const float *g = G + q * ldg;
-	const int nr = (n + WAVE - 1) / WAVE;
-#pragma unroll
-	for (int r = 0; r < NR; ++r) {
-		const int j = r * WAVE + lane;
-		float v = (r < nr && j < n) ? g[j] : 0.f;
-		key[r] = (r < nr && j < n && v == v) ? f32_sortable(v) : 0u;  // NaN never selected
-	}
-	const uint32_t kk = wave_kth_largest_regs<NR>(key, nr, k);
-	if (lane == 0) out[q * out_stride] = f32_unsortable(kk);
-}
-
-// Same for rows of up to 2048 values: keys in a wave-private LDS region, runtime loops.
-__global__ __launch_bounds__(256) void kth_value_wave_lds_kernel(const float *__restrict__ G, int64_t Q, int n, int64_t ldg, uint32_t k,
-																  float *__restrict__ out, int64_t out_stride) {
-	__shared__ uint32_t keys[4][2048];
+	__shared__ uint32_t keys[4][KTH_MAX_N];
+	__shared__ uint32_t hist[4][256];
 	const uint32_t lane = (uint32_t)lane_id();
 	const int wave = threadIdx.x >> 6;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -340,23 +324,12 @@ __global__ __launch_bounds__(256) void kth_value_wave_lds_kernel(const float *__
 		keys[wave][j] = (v == v) ? f32_sortable(v) : 0u;
 	}
 	__builtin_amdgcn_wave_barrier();
-	uint32_t prefix = 0, need = k;
-	for (int bit = 31; bit >= 0; --bit) {
-		const uint32_t himask = (bit == 31) ? 0u : ~((2u << bit) - 1u);
-		uint32_t cnt = 0;
-		for (uint32_t j0 = 0; j0 < (uint32_t)n; j0 += WAVE) {
-			const uint32_t j = j0 + lane;
-			bool c = false;
-			if (j < (uint32_t)n) {
-				const uint32_t x = keys[wave][j];
-				c = ((x & himask) == prefix) && ((x >> bit) & 1u);
-			}
-			cnt += (uint32_t)__popcll(__ballot(c));
-		}
-		if (cnt >= need) prefix |= (1u << bit);
-		else need -= cnt;
-	}
-	if (lane == 0) out[q * out_stride] = f32_unsortable(prefix);
+	WaveSel w;
+	w.whi = keys[wave]; w.wlo = nullptr; w.sort_buf = nullptr; w.hist = hist[wave];
+	w.cnt = (uint32_t)n; w.tau_hi = 0; w.tau_lo = 0; w.tau = 0.f;
+	uint32_t need;
+	const uint32_t kk = wsel_kth<false, 4>(w, w.whi, (uint32_t)n, k, need, w.whi, 0u);
+	if (lane == 0) out[q * out_stride] = f32_unsortable(kk);
 }
 
 // ------------------------------------------------------------------ a8: exact re-rank
@@ -523,8 +496,7 @@ int kmax_class(int k) { return k <= 128 ? 128 : (k <= 512 ? 512 : 2048); }
 int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st) {
 	ANNCUR_REQUIRE(n >= 1 && n <= 2048 && k >= 1 && k <= n, ANNCUR_E_INVALID, "kth_value: need 1 <= k <= n <= 2048");
 	const unsigned grid = (unsigned)ceil_div64(Q, 4);
-	if (n <= 512) hipLaunchKernelGGL((kth_value_wave_kernel<8>), dim3(grid), dim3(256), 0, st, G, Q, n, ldg, (uint32_t)k, out, out_stride);
-	else hipLaunchKernelGGL(kth_value_wave_lds_kernel, dim3(grid), dim3(256), 0, st, G, Q, n, ldg, (uint32_t)k, out, out_stride);
+	hipLaunchKernelGGL(kth_value_wave_kernel, dim3(grid), dim3(256), 0, st, G, Q, n, ldg, (uint32_t)k, out, out_stride);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -266,25 +266,4 @@ __device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_v
 	}
 }
 
-// k-th largest of the 64*NR keys held one-per-(lane, register) (short rows kept entirely in registers).
-template <int NR>
-__device__ __forceinline__ uint32_t wave_kth_largest_regs(const uint32_t (&key)[NR], int nr, uint32_t k) {
-	uint32_t prefix = 0, need = k;
-#pragma unroll 1
-	for (int bit = 31; bit >= 0; --bit) {
-		const uint32_t himask = (bit == 31) ? 0u : ~((2u << bit) - 1u);
-		uint32_t cnt = 0;
-#pragma unroll
-		for (int r = 0; r < NR; ++r) {
-			if (r < nr) {
-				const bool c = ((key[r] & himask) == prefix) && ((key[r] >> bit) & 1u);
-				cnt += (uint32_t)__popcll(__ballot(c));
-			}
-		}
-		if (cnt >= need) prefix |= (1u << bit);
-		else need -= cnt;
-	}
-	return prefix;
-}
-
 }  // namespace anncur

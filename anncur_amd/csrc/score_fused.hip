@@ -236,19 +236,25 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 											  f32x16 &acc1, float tau0, float tau1_prev, uint32_t item0, uint32_t item0_prev,
 											  uint32_t lq0, uint32_t lq1, uint32_t &q0, uint32_t &q1) {
 	using Cfg = FusedCfg<KP>;
-	constexpr int K = Cfg::KSTEPS, AR = 4, OFF = CUR * Cfg::TILE_BYTES;
+	constexpr int K = Cfg::KSTEPS, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;  // ring slots / prefetch distance in k-steps
 	constexpr int EPS = 16 / K > 0 ? 16 / K : 1;  // filter elements per k-step (Kp = 64: 4, 128: 2, 256: 1)
-	static_assert(K <= 16 && 2 * K >= AR, "staggered path: 2..16 k-steps");
+	static_assert(K <= 16 && 2 * K >= DIST && AR >= DIST + 2, "staggered path: 2..16 k-steps; a slot is rewritten two MFMAs after its use");
 	u32x4 ring[AR];
 #pragma unroll
-	for (int i = 0; i < AR - 1; ++i) lds_read_frag<OFF>(ring[i], aoff[i % K]);
+	for (int i = 0; i < DIST; ++i) lds_read_frag<OFF>(ring[i], aoff[i % K]);
 	f32x16 accA = {0}, accB = {0};
 #pragma unroll
 	for (int g = 0; g < 2 * K; ++g) {
-		const int nxt = g + AR - 1;  // the slot it lands in was consumed by the MFMA of step g-1
+		// the slot the new fragment lands in was consumed by the MFMA of step g-2: the asynchronous LDS return can never meet
+		// an MFMA that is still reading its operands
+		const int nxt = g + DIST;
 		if (nxt < 2 * K) lds_read_frag<OFF>(ring[nxt % AR], aoff[nxt % K]);
+#if defined(__HIP_DEVICE_COMPILE__)
+		// (keeps the register allocator from handing that read the registers of the fragment the PREVIOUS MFMA was given)
+		if (g >= 1) asm volatile("" ::"v"(ring[(g - 1) % AR]));
+#endif
 		const int after = 2 * K - 1 - g;
-		lds_wait_frag(ring[g % AR], after < AR - 1 ? after : AR - 1);
+		lds_wait_frag(ring[g % AR], after < DIST ? after : DIST);
 		const bf16x8 a = __builtin_bit_cast(bf16x8, ring[g % AR]);
 		if (g < K) {
 			accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][g], accA, 0, 0, 0);

@@ -451,19 +451,21 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 // written.  Same orientation as the sweep: lane = query, so both sums are lane-local accumulators and the exact matrix is read
 // as 4 consecutive items (8 or 16 bytes) per lane and accumulator register group; the next tile's exact values are in flight
 // during the MFMAs.  One atomicAdd pair per lane at the end (2 S per query).
-template <typename TA> struct ExactQuad;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+template <typename TA> struct ExactQuad;  // four consecutive items of one row of the exact matrix (native vectors: asm operands)
 template <> struct ExactQuad<uint16_t> {
-	uint2 w;
-	__device__ __forceinline__ void load(const uint16_t *p) { w = *reinterpret_cast<const uint2 *>(p); }
+	u32x2 w;
+	__device__ __forceinline__ void load(const uint16_t *p) { w = *reinterpret_cast<const u32x2 *>(p); }
 	__device__ __forceinline__ float get(int c) const {
-		const uint32_t x = (c & 2) ? w.y : w.x;
+		const uint32_t x = (c & 2) ? w[1] : w[0];
 		return __uint_as_float((c & 1) ? (x & 0xffff0000u) : (x << 16));
 	}
 };
 template <> struct ExactQuad<float> {
-	float4 w;
-	__device__ __forceinline__ void load(const float *p) { w = *reinterpret_cast<const float4 *>(p); }
-	__device__ __forceinline__ float get(int c) const { return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; }
+	f32x4n w;
+	__device__ __forceinline__ void load(const float *p) { w = *reinterpret_cast<const f32x4n *>(p); }
+	__device__ __forceinline__ float get(int c) const { return w[c]; }
 };
 
 // Full 32-item tiles only (p.n_tiles = I / 32): the host adds the last I % 32 columns with the strided kernel of gemm.hip.
@@ -528,6 +530,15 @@ __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, cons
 #pragma unroll
 			for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[t][s], acc[t], 0, 0, 0);
 		}
+#if defined(__HIP_DEVICE_COMPILE__)
+		// the exact values are consumed HERE, behind the MFMA chain: hipcc otherwise hoists their unpacking to the top of the
+		// iteration and waits vmcnt(0) there -- for them and for the tile DMA it has just issued.  (It still waits vmcnt(0)
+		// here, DMA included, because the loads sit behind `if (more)`; counted waits would need asm loads: not done.)
+#pragma unroll
+		for (int t = 0; t < QT; ++t)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));
+#endif
 #pragma unroll
 		for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -540,13 +551,27 @@ __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, cons
 		// the next tile's exact values are requested now and consumed after the next MFMA chain; the wait below covers the
 		// tile DMA only (loads return in order: the QT*4 quads issued after it may still be in flight)
 		if (more) {
+#if defined(__HIP_DEVICE_COMPILE__)
+			// the quads must be issued AFTER the tile DMA (the counted wait below relies on it) and after the sums above have
+			// consumed the previous ones: otherwise hipcc sinks the sums below the loads, renames the loads' destinations and
+			// waits for them at the end of the iteration to copy them back
+			if (QT == 2) asm volatile("" : "+v"(se[0]), "+v"(sn[0]), "+v"(se[QT - 1]), "+v"(sn[QT - 1])::"memory");
+			else asm volatile("" : "+v"(se[0]), "+v"(sn[0])::"memory");
+#endif
 #pragma unroll
 			for (int t = 0; t < QT; ++t)
 #pragma unroll
 				for (int g = 0; g < 4; ++g) ex[t][g].load(rowp[t] + (int64_t)(j + 1) * TILE_I + 8 * g);
 			__builtin_amdgcn_s_waitcnt(QT == 2 ? 0x0F78 : 0x0F74);  // vmcnt(8) / vmcnt(4)
 		}
-		__syncthreads();
+		// raw barrier: __syncthreads() carries a release fence for which hipcc waits vmcnt(0), i.e. for the quads just issued.
+		// What the barrier orders here is LDS only: this wave's fragment reads are complete (their MFMAs have issued), its part
+		// of the DMA has landed (counted wait above).
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+#endif
 	}
 #pragma unroll
 	for (int t = 0; t < QT; ++t)

@@ -15,12 +15,12 @@ Q, I = 10000, 100000
 A = torch.randn(Q, I, device=dev).bfloat16()
 for K in (256, 1024):
 	X = torch.randn(Q, K, device=dev).bfloat16(); Et = torch.randn(I, K, device=dev).bfloat16()
-	ms = t(lambda: ops.approx_error(X, Et, A))
-	print("approx_error bf16 K=%d: %.2f ms  %.1f TFLOP/s" % (K, ms, 2.0 * Q * I * K / ms / 1e9), flush=True)
 	if K <= 512:
 		Xp = ops.pack_bf16(X, K); Etp = ops.pack_bf16(Et, K, row_multiple=32)
 		ms = t(lambda: ops.approx_error_packed(Xp, Etp, A, I), n=10)
 		print("approx_error_packed bf16 K=%d: %.3f ms  %.1f TFLOP/s" % (K, ms, 2.0 * Q * I * K / ms / 1e9), flush=True)
+	ms = t(lambda: ops.approx_error(X, Et, A))
+	print("approx_error bf16 K=%d: %.2f ms  %.1f TFLOP/s" % (K, ms, 2.0 * Q * I * K / ms / 1e9), flush=True)
 	Xf, Etf = X.float(), Et.float()
 	ms = t(lambda: ops.approx_error(Xf, Etf, A))
 	print("approx_error fp32 operands K=%d: %.2f ms  %.1f TFLOP/s" % (K, ms, 2.0 * Q * I * K / ms / 1e9), flush=True)

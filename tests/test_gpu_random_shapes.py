@@ -1,0 +1,85 @@
+"""Randomised shape / distribution sweeps of the two selection kernels (hypothesis, bounded): exact top-k scan and fused score + top-k.
+Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+	if not torch.cuda.is_available():
+		pytest.skip("no GPU")
+	from anncur_amd import ops as _ops
+	return _ops
+
+
+def _row_data(kind, Q, I, g):
+	if kind == "normal":
+		return torch.randn(Q, I, generator=g)
+	if kind == "ties":       # a handful of distinct values: every compare is a tie somewhere
+		return torch.randint(-3, 4, (Q, I), generator=g).float() / 4
+	if kind == "const":
+		return torch.full((Q, I), -1.5)
+	if kind == "negative":
+		return -torch.rand(Q, I, generator=g) * 100 - 1
+	if kind == "special":
+		A = torch.randn(Q, I, generator=g)
+		m = torch.rand(Q, I, generator=g)
+		A[m < 0.02] = float("nan"); A[(m >= 0.02) & (m < 0.03)] = float("inf"); A[(m >= 0.03) & (m < 0.05)] = -float("inf")
+		return A
+	if kind == "ascending":
+		return torch.sort(torch.randn(Q, I, generator=g), dim=1).values
+	return torch.sort(torch.randn(Q, I, generator=g), dim=1, descending=True).values   # "descending"
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 24), I=st.integers(1, 40000), kfrac=st.floats(0.0, 1.0), bf16=st.booleans(),
+	   kind=st.sampled_from(["normal", "ties", "const", "negative", "special", "ascending", "descending"]), off=st.integers(0, 7), seed=st.integers(0, 10 ** 6))
+def test_rowwise_topk_random(ops, Q, I, kfrac, bf16, kind, off, seed):
+	g = torch.Generator().manual_seed(seed)
+	k = max(1, min(I, 1 + int(kfrac * min(I, 300))))
+	buf = torch.zeros(Q, I + 16)
+	buf[:, off:off + I] = _row_data(kind, Q, I, g)
+	buf = buf.to(torch.bfloat16 if bf16 else torch.float32).cuda()
+	A = buf[:, off:off + I]                                      # misaligned, padded rows
+	v, i = ops.rowwise_topk(A, k)
+	v, i = v.cpu(), i.cpu().long()
+	Af = A.float().cpu()
+	Ar = torch.where(torch.isnan(Af), torch.full_like(Af, -float("inf")), Af)   # NaN is never selected (ranks with -inf)
+	order = torch.argsort(Ar, dim=1, descending=True, stable=True)[:, :k]
+	want_v = torch.gather(Ar, 1, order)
+	assert torch.equal(v, want_v)
+	nan_free = not torch.isnan(Af).any()
+	if nan_free:
+		assert torch.equal(i, order)                              # defined tie order: score descending, then smaller index
+	else:
+		valid = i >= 0
+		assert torch.equal(torch.gather(Ar, 1, i.clamp(min=0))[valid], v[valid])
+		assert all(len(set(r[r >= 0].tolist())) == int((r >= 0).sum()) for r in i)
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 300), I=st.integers(20000, 90000), K=st.integers(8, 512), k=st.integers(1, 200), rank=st.integers(2, 48),
+	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6))
+def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed):
+	g = torch.Generator().manual_seed(seed)
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	E = (torch.randn(K, rank, generator=g) @ torch.randn(rank, I, generator=g) / rank ** 0.5 + noise * torch.randn(K, I, generator=g)).bfloat16()
+	Kp = ops.padded_k(K)
+	if not ops.fused_supported(Q, I, Kp, k):
+		return
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	v, i = ops.score_topk_fused(Xp, Etp, I, k)
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	scale = float(S.abs().max()) + 1e-30
+	got = i.cpu().long()
+	assert (got >= 0).all() and (got < I).all() and all(len(set(r.tolist())) == k for r in got)
+	assert (v.cpu().double() - rv).abs().max() <= 1e-4 * scale
+	assert (torch.gather(S, 1, got) - v.cpu().double()).abs().max() <= 1e-4 * scale
+	assert ((v[:, :-1] >= v[:, 1:]).all())                       # sorted descending
+	# every selected item beats (up to fp32 round-off) the true k-th score
+	assert (torch.gather(S, 1, got).min(dim=1).values >= rv[:, -1] - 1e-4 * scale).all()

@@ -713,7 +713,7 @@ template <bool TAU_ONLY>
 __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg,
 														   int capg, int64_t Q, uint32_t k, float *__restrict__ out_val,
 														   int32_t *__restrict__ out_idx, uint32_t *__restrict__ hard_cnt,
-														   int32_t *__restrict__ hard_list, float *__restrict__ tau, int tau_stride) {
+														   int32_t *__restrict__ hard_list, float *__restrict__ tau, int tau_stride, int prefilter) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id(), wave = threadIdx.x >> 6;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -731,6 +731,9 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 		return;  // TAU_ONLY: keep the old (still valid) threshold
 	}
 	WaveSel w = wsel_init<WQ_CAP>(smem + wave * WaveSelLayout<WQ_CAP>::BYTES);
+	// the threshold the last sweep stage ran with is a valid lower bound on the k-th best: candidates of earlier stages below it
+	// are dropped at the load (at least k candidates are >= it by construction)
+	if (tau && prefilter) w.tau = tau[q * tau_stride];
 	const uint2 *qc = cand + q * nseg * (int64_t)capg;
 #pragma unroll 4
 	for (uint32_t j0 = 0; j0 < total; j0 += WAVE) {
@@ -952,7 +955,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		if (stg + 1 < P.n_stages) {
 			hipLaunchKernelGGL((select_wave_kernel<true>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
 							   p.seg_cnt, 2 * P.S, P.capg, Q, (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
-							   (int32_t *)nullptr, const_cast<float *>(p.tau), p.tau_stride);
+							   (int32_t *)nullptr, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0);
 			ANNCUR_LAUNCH_OK();
 		}
 	}
@@ -982,7 +985,8 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		int32_t *hl = (int32_t *)(ws + P.off_hard);
 		uint32_t *hc = (uint32_t *)(ws + 4);
 		hipLaunchKernelGGL((select_wave_kernel<false>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
-						   p.seg_cnt, nseg, P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl, (float *)nullptr, 0);
+						   p.seg_cnt, nseg, P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(p.tau), p.tau_stride,
+						   P.n_stages > 1 ? 1 : 0);
 		ANNCUR_LAUNCH_OK();
 		hard_list = hl; hard_cnt = hc;
 		sel_grid = (unsigned)(Q < 1024 ? Q : 1024);

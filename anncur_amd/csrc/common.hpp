@@ -57,8 +57,8 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
 
 // order-preserving map float -> uint32 (larger float => larger uint)
 __device__ __forceinline__ uint32_t f32_sortable(float f) {
-	uint32_t u = __float_as_uint(f);
-	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+	const uint32_t u = __float_as_uint(f);
+	return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);  // negative: flip all bits, positive: set the top bit (3 VALU ops)
 }
 __device__ __forceinline__ float f32_unsortable(uint32_t s) {
 	uint32_t u = (s & 0x80000000u) ? (s & 0x7fffffffu) : ~s;

@@ -280,11 +280,10 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 				const uint32_t hw = pass ? sp.word_hits(y[j]) : 0u;                                                             \
 				if (__ballot(hw != 0u) != 0ull) {                                                                               \
 					_Pragma("unroll") for (int e = j * VEC / 4; e < (j + 1) * VEC / 4; ++e) {                                   \
-						const bool hit = sp.elem_hit(hw, e);                                                                    \
-						if (VEC == 4 || __ballot(hit) != 0ull) {                                                                \
-							const float v = vec_elem<T>(cur, e);                                                                \
-							wsel_push(w, hit && v == v, f32_sortable(v), 0xffffffffu - (i0 + (uint32_t)e));                     \
-						}                                                                                                       \
+						const float v = vec_elem<T>(cur, e);                                                                    \
+						const bool hit = sp.elem_hit(hw, e) && v == v;  /* NaN patterns can pass the integer tests */            \
+						const unsigned long long hm = __ballot(hit);                                                            \
+						if (hm != 0ull) wsel_push_mask(w, hm, hit, f32_sortable(v), 0xffffffffu - (i0 + (uint32_t)e));          \
 					}                                                                                                           \
 				}                                                                                                               \
 			}                                                                                                                   \

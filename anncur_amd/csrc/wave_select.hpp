@@ -37,16 +37,21 @@ __device__ __forceinline__ WaveSel wsel_init(unsigned char *wave_lds) {
 	return w;
 }
 
-// Append the lanes with `hit` (wave-uniform call; caller guarantees room).
-__device__ __forceinline__ void wsel_push(WaveSel &w, bool hit, uint32_t hi, uint32_t lo) {
-	const unsigned long long m = __ballot(hit);
-	if (m == 0ull) return;
+// Append the lanes of `m` (= __ballot(hit), non-zero; wave-uniform call; caller guarantees room).  v_mbcnt gives the lane's rank
+// among the set bits in two instructions.
+__device__ __forceinline__ void wsel_push_mask(WaveSel &w, unsigned long long m, bool hit, uint32_t hi, uint32_t lo) {
 	if (hit) {
-		const uint32_t pos = w.cnt + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+		const uint32_t pos = w.cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 		w.whi[pos] = hi;
 		w.wlo[pos] = lo;
 	}
 	w.cnt += (uint32_t)__popcll(m);
+}
+// Append the lanes with `hit` (wave-uniform call; caller guarantees room).
+__device__ __forceinline__ void wsel_push(WaveSel &w, bool hit, uint32_t hi, uint32_t lo) {
+	const unsigned long long m = __ballot(hit);
+	if (m == 0ull) return;
+	wsel_push_mask(w, m, hit, hi, lo);
 }
 
 // Offer one element per lane: cheap float filter first, exact composite-key comparison only when some lane passes.

@@ -240,8 +240,20 @@ def fused_supported(Q, I, Kp, k):
 	return Kp in _KP_CHOICES and bool(_lib.load().anncur_score_topk_supported(Q, I, Kp, k))
 
 
-def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False):
-	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16)."""
+def fused_workspace(Q, I, Kp, k, device):
+	"""A private workspace for score_topk_fused (256-byte aligned uint8 tensor): calls that may run concurrently on different
+	streams must not share the default one."""
+	nbytes = _lib.load().anncur_score_topk_workspace_bytes(Q, I, Kp, k)
+	if nbytes == 0:
+		raise _lib.AnncurHipError(f"score_topk: shape (Q={Q}, I={I}, Kp={Kp}, k={k}) is outside the fused path")
+	buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+	off = (-buf.data_ptr()) % 256
+	return buf[off:off + nbytes]
+
+
+def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None):
+	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16).
+	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time)."""
 	_dev(Xp, Etp)
 	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16:
 		raise TypeError("score_topk_fused takes bf16 operands")
@@ -253,7 +265,12 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False):
 	nbytes = lib.anncur_score_topk_workspace_bytes(Q, I, Kp, k)
 	if nbytes == 0:
 		raise _lib.AnncurHipError(f"score_topk: shape (Q={Q}, I={I}, Kp={Kp}, k={k}) is outside the fused path")
-	ws = _Workspace.get(nbytes, Xp.device)
+	if workspace is None:
+		ws = _Workspace.get(nbytes, Xp.device)
+	else:
+		ws = workspace
+		if ws.numel() < nbytes or ws.data_ptr() % 256 != 0 or ws.device != Xp.device:
+			raise ValueError("score_topk_fused: workspace too small, misaligned or on another device (use fused_workspace())")
 	val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 	check(lib.anncur_score_topk(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes, _stream()), "score_topk")

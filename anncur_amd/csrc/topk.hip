@@ -157,12 +157,13 @@ constexpr int WS_PF = 8;
 template <typename T> struct ScanPre;
 template <> struct ScanPre<float> {  // fp32 rows: plain float compares
 	float pre;
-	__device__ __forceinline__ void set(float tau) { pre = tau; }
+	bool all;  // (wave-uniform) no threshold yet: every real number is a candidate, -inf included
+	__device__ __forceinline__ void set(float tau) { pre = tau; all = !(tau > -INFINITY); }
 	__device__ __forceinline__ u32x4 xform(const u32x4 &c) const { return c; }
 	__device__ __forceinline__ bool any(const u32x4 &y) const {
-		return fmaxf(fmaxf(fmaxf(__uint_as_float(y[0]), __uint_as_float(y[1])), __uint_as_float(y[2])), __uint_as_float(y[3])) > pre;
+		return all || fmaxf(fmaxf(fmaxf(__uint_as_float(y[0]), __uint_as_float(y[1])), __uint_as_float(y[2])), __uint_as_float(y[3])) > pre;
 	}
-	__device__ __forceinline__ uint32_t word_hits(uint32_t yw) const { return __uint_as_float(yw) > pre ? 1u : 0u; }  // one element per word
+	__device__ __forceinline__ uint32_t word_hits(uint32_t yw) const { return (all || __uint_as_float(yw) > pre) ? 1u : 0u; }  // one element per word
 	__device__ __forceinline__ bool elem_hit(uint32_t hw, int) const { return hw != 0u; }
 	static __device__ __forceinline__ uint32_t group_max_key(const u32x4 &c) {  // NaN-free maximum as a sortable key
 		return f32_sortable(fmaxf(fmaxf(fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1])), __uint_as_float(c[2])), __uint_as_float(c[3])));
@@ -170,8 +171,10 @@ template <> struct ScanPre<float> {  // fp32 rows: plain float compares
 };
 template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer compares on y = x ^ M
 	uint32_t mask, pre_pk;  // wave-uniform
+	bool all;               // (wave-uniform) no threshold yet: every real number is a candidate, -inf included
 	__device__ __forceinline__ void set(float tau) {
 		const uint32_t b = __builtin_amdgcn_readfirstlane(__float_as_uint(tau));
+		all = b == 0xff800000u || (b & 0x7fffffffu) > 0x7f800000u;  // -inf (or, defensively, a NaN threshold)
 		const bool neg = (b >> 31) != 0u;
 		uint32_t t16 = b >> 16;                        // largest bf16 <= tau (tau is a bf16 value, -inf, or the fp32 just below one)
 		if (neg && (b & 0xffffu) != 0u) t16 += 1u;
@@ -185,9 +188,10 @@ template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer comp
 		const h16x8 v = __builtin_bit_cast(h16x8, y);
 		const h16x4 a = __builtin_elementwise_max(v.lo, v.hi);
 		const h16x2 m = __builtin_elementwise_max(a.lo, a.hi);
-		return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(m, __builtin_bit_cast(h16x2, pre_pk))) != pre_pk;
+		return all || __builtin_bit_cast(uint32_t, __builtin_elementwise_max(m, __builtin_bit_cast(h16x2, pre_pk))) != pre_pk;
 	}
 	__device__ __forceinline__ uint32_t word_hits(uint32_t yw) const {  // non-zero half-word = that element beats the threshold
+		if (all) return 0x00010001u;
 		return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h16x2, yw), __builtin_bit_cast(h16x2, pre_pk))) ^ pre_pk;
 	}
 	__device__ __forceinline__ bool elem_hit(uint32_t hw, int e) const { return ((e & 1) ? (hw >> 16) : (hw & 0xffffu)) != 0u; }
@@ -246,9 +250,9 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		__builtin_amdgcn_wave_barrier();
 		uint32_t need;
 		const uint32_t kth = wsel_kth<false, HP>(w, w.whi, (uint32_t)(WS_PF * WAVE), k, need, w.whi, 0u);
-		// admit the bound itself: the threshold is the fp32 value just below it (the buffer is still empty).  kth == 0 only if
-		// fewer than k maxima are real numbers: leave the threshold at -inf then.
-		if (kth != 0u) {
+		// admit the bound itself: the threshold is the fp32 value just below it (the buffer is still empty).  If fewer than k
+		// maxima are finite the bound is -inf (or the NaN key 0): the threshold stays at -inf = "none yet".
+		if (kth > f32_sortable(-INFINITY)) {  // (a bound of -inf or below is no bound: stay unthresholded)
 			float t = f32_unsortable(kth - 1u);
 			if (fabsf(t) < 1.17549435e-38f) t = -1.17549435e-38f;  // bound = +-0 or a denormal: any negative normal admits it (and +0 == -0)
 			w.tau = t;

@@ -65,7 +65,7 @@ __device__ __forceinline__ void wsel_offer(WaveSel &w, bool valid, float v, uint
 // In-order stream variant: every candidate already in the buffer has a smaller index than this element, so a score tie
 // with the threshold loses and one strict float compare is exact.
 __device__ __forceinline__ void wsel_offer_inorder(WaveSel &w, bool valid, float v, uint32_t idx) {
-	const bool hit = valid && (v > w.tau);
+	const bool hit = valid && v == v && (v > w.tau || !(w.tau > -INFINITY));  // no threshold yet: -inf is a candidate too; NaN never
 	if (__ballot(hit) == 0ull) return;
 	wsel_push(w, hit, f32_sortable(v), 0xffffffffu - idx);
 }

@@ -303,6 +303,15 @@ def test_rowwise_topk_threshold_crossing_zero_nan_and_sorted_rows(ops, dtype):
 	check(desc, 100)
 	asc = torch.sort(torch.randn(3, I, generator=g), dim=1).values.to(dtype)
 	check(asc, 100)
+	# (7) mostly -inf rows (masked scores): fewer finite values than k, also inside the seed region of a long row; -inf entries
+	#     are real candidates (smallest indices first), only NaN is never selected
+	masked = torch.full((5, I), -float("inf"))
+	cols = torch.randperm(I, generator=g)[:37]
+	masked[:, cols] = torch.randn(5, 37, generator=g)
+	masked[2, :] = -float("inf")                       # nothing finite at all
+	for k in (1, 37, 64, 128): check(masked.to(dtype), k)
+	check(torch.full((9, 1), -float("inf")).to(dtype), 1)
+	check(torch.tensor([[-float("inf"), 1.0, -float("inf"), float("inf"), -2.0]]).to(dtype), 5)
 	# (6) misaligned row start (unaligned head elements come first in index order)
 	base = torch.randn(4, I + 16, generator=g).to(dtype).cuda()
 	for off in (1, 3, 7):

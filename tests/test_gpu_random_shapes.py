@@ -3,9 +3,14 @@ Needs an MI355X."""
 import numpy as np
 import pytest
 import torch
+import os
+
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 pytestmark = pytest.mark.gpu
+# Deterministic by default (the same examples every run); ANNCUR_FUZZ=1 draws fresh ones and ANNCUR_FUZZ_EXAMPLES=n draws more.
+_FUZZ = os.environ.get("ANNCUR_FUZZ", "") not in ("", "0")
+_N = int(os.environ.get("ANNCUR_FUZZ_EXAMPLES", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -30,14 +35,19 @@ def _row_data(kind, Q, I, g):
 		m = torch.rand(Q, I, generator=g)
 		A[m < 0.02] = float("nan"); A[(m >= 0.02) & (m < 0.03)] = float("inf"); A[(m >= 0.03) & (m < 0.05)] = -float("inf")
 		return A
+	if kind == "masked":     # mostly -inf, a few finite values
+		A = torch.full((Q, I), -float("inf"))
+		m = torch.rand(Q, I, generator=g) < 0.01
+		A[m] = torch.randn(int(m.sum()), generator=g)
+		return A
 	if kind == "ascending":
 		return torch.sort(torch.randn(Q, I, generator=g), dim=1).values
 	return torch.sort(torch.randn(Q, I, generator=g), dim=1, descending=True).values   # "descending"
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=_N or 60, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(Q=st.integers(1, 24), I=st.integers(1, 40000), kfrac=st.floats(0.0, 1.0), bf16=st.booleans(),
-	   kind=st.sampled_from(["normal", "ties", "const", "negative", "special", "ascending", "descending"]), off=st.integers(0, 7), seed=st.integers(0, 10 ** 6))
+	   kind=st.sampled_from(["normal", "ties", "const", "negative", "special", "masked", "ascending", "descending"]), off=st.integers(0, 7), seed=st.integers(0, 10 ** 6))
 def test_rowwise_topk_random(ops, Q, I, kfrac, bf16, kind, off, seed):
 	g = torch.Generator().manual_seed(seed)
 	k = max(1, min(I, 1 + int(kfrac * min(I, 300))))
@@ -61,7 +71,7 @@ def test_rowwise_topk_random(ops, Q, I, kfrac, bf16, kind, off, seed):
 		assert all(len(set(r[r >= 0].tolist())) == int((r >= 0).sum()) for r in i)
 
 
-@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=(_N // 4) or 25, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(Q=st.integers(1, 300), I=st.integers(20000, 90000), K=st.integers(8, 512), k=st.integers(1, 200), rank=st.integers(2, 48),
 	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6))
 def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed):

@@ -169,7 +169,8 @@ def approx_error(X, Et, A_exact):
 
 def approx_error_packed_ok(Kp, A_exact):
 	"""True if anncur_approx_error_packed takes these operands (bf16 MFMA loop of the sweep instead of the strided fp32 GEMM)."""
-	return Kp in (64, 128, 256, 512) and A_exact.stride(1) == 1 and A_exact.stride(0) % 4 == 0 and A_exact.data_ptr() % 16 == 0
+	return (Kp in (64, 128, 256, 512) and A_exact.dim() == 2 and A_exact.stride(1) == 1 and _ld(A_exact) % 4 == 0
+			and _ld(A_exact) >= A_exact.shape[1] and A_exact.data_ptr() % 16 == 0)
 
 
 def approx_error_packed(Xp, Etp, A_exact, n_items):

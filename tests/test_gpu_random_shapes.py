@@ -93,3 +93,62 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed):
 	assert ((v[:, :-1] >= v[:, 1:]).all())                       # sorted descending
 	# every selected item beats (up to fp32 round-off) the true k-th score
 	assert (torch.gather(S, 1, got).min(dim=1).values >= rv[:, -1] - 1e-4 * scale).all()
+
+
+@settings(max_examples=_N or 40, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(M=st.integers(1, 300), N=st.integers(1, 300), K=st.integers(1, 200), ta=st.booleans(), tb=st.booleans(), a16=st.booleans(), b16=st.booleans(),
+	   c16=st.booleans(), alpha=st.sampled_from([1.0, -0.5, 2.0]), use_cin=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_gemm_random(ops, M, N, K, ta, tb, a16, b16, c16, alpha, use_cin, seed):
+	g = torch.Generator().manual_seed(seed)
+	A = torch.randn((K, M) if ta else (M, K), generator=g).to(torch.bfloat16 if a16 else torch.float32).cuda()
+	B = torch.randn((N, K) if tb else (K, N), generator=g).to(torch.bfloat16 if b16 else torch.float32).cuda()
+	Av, Bv = (A.t() if ta else A), (B.t() if tb else B)
+	cin = torch.randn(M, N, generator=g).cuda() if use_cin else None
+	beta = 0.75 if use_cin else 0.0
+	out = ops.gemm(Av, Bv, out_dtype=torch.bfloat16 if c16 else torch.float32, alpha=alpha, beta=beta, cin=cin)
+	want = alpha * (Av.double().cpu() @ Bv.double().cpu()) + (beta * cin.double().cpu() if use_cin else 0.0)
+	tol = (2e-2 if c16 else 1e-4) * (float(want.abs().max()) + 1.0)
+	assert out.dtype == (torch.bfloat16 if c16 else torch.float32) and tuple(out.shape) == (M, N)
+	assert (out.double().cpu() - want).abs().max() <= tol
+
+
+@settings(max_examples=_N or 40, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 60), la=st.integers(1, 400), lb=st.integers(1, 400), universe=st.integers(1, 5000), n_pairs=st.integers(1, 6), seed=st.integers(0, 10 ** 6))
+def test_overlap_and_rerank_random(ops, Q, la, lb, universe, n_pairs, seed):
+	rng = np.random.default_rng(seed)
+	universe = max(universe, la, lb)
+	a = np.stack([rng.permutation(universe)[:la] for _ in range(Q)]).astype(np.int32)
+	b = np.stack([rng.permutation(universe)[:lb] for _ in range(Q)]).astype(np.int32)
+	pairs = [(int(rng.integers(0, la + 1)), int(rng.integers(0, lb + 1))) for _ in range(n_pairs)]
+	got = ops.overlap_counts(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), pairs).cpu().numpy()
+	for p, (ka, kb) in enumerate(pairs):
+		assert got[p].tolist() == [len(set(a[q, :ka]) & set(b[q, :kb])) for q in range(Q)]
+	# re-rank: the k_out best of approx[:, :k_retvr] by exact score, ties -> smaller index
+	A = torch.from_numpy(rng.integers(-8, 9, size=(Q, universe)).astype(np.float32) / 4)
+	k_retvr = int(rng.integers(1, la + 1)); k_out = int(rng.integers(1, min(k_retvr, 2048) + 1))
+	rr = ops.rerank(A.cuda(), torch.from_numpy(a).cuda(), k_retvr, k_out)
+	for q in range(Q):
+		cand = a[q, :k_retvr].astype(np.int64)
+		order = sorted(cand.tolist(), key=lambda i: (-float(A[q, i]), i))[:k_out]
+		assert rr.indices[q].cpu().tolist() == order
+		assert rr.values[q].cpu().tolist() == [float(A[q, i]) for i in order]
+
+
+@settings(max_examples=(_N // 4) or 15, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 400), I=st.integers(1, 9000), K=st.integers(1, 512), fp32_exact=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_approx_error_packed_random(ops, Q, I, K, fp32_exact, seed):
+	g = torch.Generator().manual_seed(seed)
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	E = (torch.randn(K, I, generator=g) / K ** 0.5).bfloat16()
+	ld = (I + 3) // 4 * 4
+	Abuf = torch.zeros(Q, ld, dtype=torch.float32 if fp32_exact else torch.bfloat16)
+	Abuf[:, :I] = (X.float() @ E.float() + 0.3 * torch.randn(Q, I, generator=g)).to(Abuf.dtype)
+	A = Abuf.cuda()[:, :I]
+	Kp = ops.padded_k(K)
+	if ops.approx_error_packed_ok(Kp, A):
+		err, nrm = ops.approx_error_packed(ops.pack_bf16(X.cuda(), Kp), ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32), A, I)
+	else:   # (degenerate row pitch, e.g. a one-row matrix: the callers' fallback)
+		err, nrm = ops.approx_error(X.cuda(), E.t().contiguous().cuda(), A)
+	S = X.double() @ E.double(); Ad = Abuf[:, :I].double()
+	torch.testing.assert_close(err.cpu().double(), ((S - Ad) ** 2).sum(1), rtol=3e-4, atol=1e-4)
+	torch.testing.assert_close(nrm.cpu().double(), (Ad ** 2).sum(1), rtol=1e-5, atol=1e-5)

@@ -152,3 +152,46 @@ def test_approx_error_packed_random(ops, Q, I, K, fp32_exact, seed):
 	S = X.double() @ E.double(); Ad = Abuf[:, :I].double()
 	torch.testing.assert_close(err.cpu().double(), ((S - Ad) ** 2).sum(1), rtol=3e-4, atol=1e-4)
 	torch.testing.assert_close(nrm.cpu().double(), (Ad ** 2).sum(1), rtol=1e-5, atol=1e-5)
+
+
+@settings(max_examples=(_N // 8) or 12, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(12, 300), m=st.integers(40, 3000), rank=st.integers(2, 12), kr_frac=st.floats(0.1, 0.5), kc_frac=st.floats(0.02, 0.3),
+	   pref=st.sampled_from(["rows", "cols"]), seed=st.integers(0, 10 ** 6))
+def test_cur_operator_api_random_vs_oracle(ops, n, m, rank, kr_frac, kc_frac, pref, seed):
+	"""CURApprox (HIP, fp32 route) against the CPU restatement of the reference class on random low-rank + noise matrices with
+	over-sampled anchors: U, latent factors, get / get_rows / get_cols / get_complete_* and the top-k sets."""
+	from anncur_amd.cur import CURApprox
+	from oracle import cur_oracle as O
+	g = torch.Generator().manual_seed(seed)
+	A = torch.randn(n, rank, generator=g) @ torch.randn(rank, m, generator=g) / rank ** 0.5 + 0.05 * torch.randn(n, m, generator=g)
+	rng = np.random.default_rng(seed)
+	kc = min(m - 1, max(rank + 2, int(kc_frac * m)))
+	kr = min(n, max(2 * kc if pref == "rows" else rank + 2, int(kr_frac * n), 1))   # over-sampled rows keep the intersection well conditioned
+	if pref == "cols":
+		kc = min(m - 1, max(kc, 2 * kr))
+	ri = sorted(rng.choice(n, size=kr, replace=False).tolist()); ci = sorted(rng.choice(m, size=kc, replace=False).tolist())
+	ref = O.CURApproxOracle(rows=A[ri, :], cols=A[:, ci], row_idxs=ri, col_idxs=ci, approx_preference=pref)
+	cur = CURApprox(rows=A[ri, :], cols=A[:, ci], row_idxs=ri, col_idxs=ci, approx_preference=pref)
+	S_ref = ref.get(list(range(n)), list(range(m)))
+	scale = float(S_ref.abs().max()) + 1e-6
+	def close(a, b, tol=2e-3):
+		assert tuple(a.shape) == tuple(b.shape) and float((a.double() - b.double()).abs().max()) <= tol * scale
+	S = cur.get(list(range(n)), list(range(m)))
+	assert S.device.type == "cpu"
+	assert float(torch.linalg.norm(S - S_ref) / torch.linalg.norm(S_ref)) < 2e-3     # (conditioning-dependent; 1e-4 on the pinned goldens)
+	sub_r = sorted(rng.choice(n, size=min(n, 5), replace=False).tolist()); sub_c = sorted(rng.choice(m, size=min(m, 7), replace=False).tolist())
+	close(cur.get(sub_r, sub_c), ref.get(sub_r, sub_c)); close(cur.get_rows(sub_r), ref.get_rows(sub_r)); close(cur.get_cols(sub_c), ref.get_cols(sub_c))
+	k = int(rng.integers(1, min(m, 50) + 1))
+	if pref == "rows":
+		close(cur.get_complete_row(A[:, ci]), ref.get_complete_row(A[:, ci]))
+		tv, ti = cur.topk_in_row(A[:, ci], k)
+		rv, _ = torch.topk(S_ref, k, dim=1)
+		close(tv, rv)
+		close(torch.gather(S_ref, 1, ti), rv)          # the selected items' reference scores are the reference's top-k values
+		with pytest.raises(NotImplementedError):
+			cur.get_complete_col(A[ri, :][:, :3])
+	else:
+		cols_in = A[ri, :][:, :min(m, 9)]
+		close(cur.get_complete_col(cols_in), ref.get_complete_col(cols_in))
+		with pytest.raises(NotImplementedError):
+			cur.get_complete_row(A[:, ci])

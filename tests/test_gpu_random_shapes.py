@@ -195,3 +195,29 @@ def test_cur_operator_api_random_vs_oracle(ops, n, m, rank, kr_frac, kc_frac, pr
 		close(cur.get_complete_col(cols_in), ref.get_complete_col(cols_in))
 		with pytest.raises(NotImplementedError):
 			cur.get_complete_row(A[:, ci])
+
+
+@settings(max_examples=(_N // 8) or 12, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 200), I=st.integers(20000, 70000), K=st.integers(1, 96), k=st.integers(1, 300), levels=st.integers(1, 4),
+	   kind=st.sampled_from(["ties", "const", "hot"]), seed=st.integers(0, 10 ** 6))
+def test_fused_score_topk_random_ties_and_overflow(ops, Q, I, K, k, levels, kind, seed):
+	"""Small-integer operands: every score is an exactly representable integer, ties are everywhere and whole item ranges can
+	beat the sampled threshold (segment overflow / ring wrap -> the in-call repair).  The result must be THE top-k under the
+	defined order (score descending, then smaller index)."""
+	g = torch.Generator().manual_seed(seed)
+	X = torch.randint(0, levels + 1, (Q, K), generator=g).float()
+	if kind == "const":
+		E = torch.ones(K, I)
+	else:
+		E = torch.randint(-levels, levels + 1, (K, I), generator=g).float()
+		if kind == "hot":
+			lo = int(torch.randint(0, I - 4000, (1,), generator=g)); E[:, lo:lo + 3000] += levels + 1
+	Kp = ops.padded_k(K)
+	if not ops.fused_supported(Q, I, Kp, k):
+		return
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	v, i = ops.score_topk_fused(Xp, Etp, I, k)
+	S = X.double() @ E.double()
+	order = torch.argsort(S, dim=1, descending=True, stable=True)[:, :k]
+	assert torch.equal(v.cpu().double(), torch.gather(S, 1, order))
+	assert torch.equal(i.cpu().long(), order)

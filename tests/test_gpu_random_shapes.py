@@ -221,3 +221,40 @@ def test_fused_score_topk_random_ties_and_overflow(ops, Q, I, K, k, levels, kind
 	order = torch.argsort(S, dim=1, descending=True, stable=True)[:, :k]
 	assert torch.equal(v.cpu().double(), torch.gather(S, 1, order))
 	assert torch.equal(i.cpu().long(), order)
+
+
+@settings(max_examples=(_N // 20) or 6, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n_train=st.integers(60, 200), n_test=st.integers(20, 150), n_ent=st.integers(300, 4000), rank=st.integers(3, 10), seed=st.integers(0, 50),
+	   k_retvr=st.sampled_from([20, 64, 100]), bf16=st.booleans())
+def test_entry_point_sweeps_random_vs_oracle(ops, n_train, n_test, n_ent, rank, seed, k_retvr, bf16):
+	"""The two evaluation sweeps (entry A: one matrix, anchor / non-anchor / all rows; entry B: train/test split over an anchor
+	grid) against the CPU restatement of the reference loops on random low-rank + noise inputs."""
+	from anncur_amd import harness
+	from oracle import cur_oracle as O
+	g = torch.Generator().manual_seed(1000 + seed)
+	Z = torch.randn(rank, n_ent, generator=g)
+	mk = lambda n: torch.randn(n, rank, generator=g) @ Z / rank ** 0.5 + 0.05 * torch.randn(n, n_ent, generator=g)
+	A_train, A_test = mk(n_train), mk(n_test)
+	key = "exact_vs_reranked_approx_retvr~common_frac_mean"
+	# entry B over two anchor counts; bf16 storage is compared with the oracle on the same bf16-rounded values
+	if bf16:
+		A_train, A_test = A_train.bfloat16().float(), A_test.bfloat16().float()
+	dev = lambda t: t.cuda().bfloat16() if bf16 else t.cuda()
+	anc_vals = [max(rank + 2, n_train // 4), max(rank + 3, n_train // 2)]
+	grids = {"top_k_vals": [1, 10], "top_k_retr_vals": [k_retvr], "n_ent_anchors_vals": anc_vals}
+	got = harness.run_eval_method_cur(dev(A_test), dev(A_train), seed, grids)
+	want = O.run_eval_method_cur(A_test, A_train, seed, [1, 10], [k_retvr], anc_vals)
+	tol = 0.06 if bf16 else 0.02      # per-query boundary near-ties (and bf16 item embeddings) move single elements in and out
+	for k in (1, 10):
+		for n_anc in anc_vals:
+			cell = f"anc_n_m={n_train}_anc_n_e={n_anc}"
+			assert abs(got[f"top_k={k}"][f"k_retvr={k_retvr}"][cell][key] - want[f"top_k={k}"][f"k_retvr={k_retvr}"][cell][key]) <= tol, (k, n_anc)
+	# entry A on the test matrix (fp32 route only: the reference's own arithmetic)
+	if not bf16:
+		n_m, n_e = max(rank + 4, n_test // 3), max(rank + 2, min(n_ent // 10, n_test // 6 + rank))
+		a = harness.run_approx_eval_w_seed("cur", A_test.cuda(), n_m, n_e, 10, k_retvr, seed)
+		b = O.run_approx_eval_w_seed("cur", A_test, n_m, n_e, 10, k_retvr, seed)
+		for subset in ("anchor", "non_anchor", "all"):
+			assert abs(float(a[subset][key]) - float(b[subset][key])) <= 0.03, subset
+			if subset != "anchor":
+				assert float(a[subset]["approx_error_relative"]) == pytest.approx(float(b[subset]["approx_error_relative"]), rel=2e-2, abs=1e-4), subset

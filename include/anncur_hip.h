@@ -111,7 +111,9 @@ int anncur_approx_error_packed(const void *X, int64_t ldx, const void *Et, int64
 /* a7/a8: exact row-wise top-k of a stored matrix (HBM-streaming scan) ---------------
  *   torch.topk(S, k, dim=1)                  eval/matrix_approx_zeshel.py:106,126
  *   curr_ment_scores.topk(top_k)             ...crossenc.py:103 ; ..._splits.py:86
- * A [Q x I] (dtype), out_val float[Q x k] (ldo = k), out_idx int32[Q x k].  1 <= k <= min(I, ANNCUR_MAX_TOPK). */
+ * A [Q x I] (dtype), out_val float[Q x k] (ldo = k), out_idx int32[Q x k].  1 <= k <= min(I, ANNCUR_MAX_TOPK).
+ * Order: score descending, equal scores by ascending index (torch leaves ties unspecified).  -inf entries are ordinary
+ * candidates; NaN is never selected (torch ranks NaN first): a row with fewer than k non-NaN entries is padded with (-inf, -1). */
 int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k,
                         float *out_val, int32_t *out_idx, void *stream);
 
@@ -123,10 +125,11 @@ int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t 
  * Et [Ip x Kp] bf16 row-major (item embeddings E^T), Kp in {64,128,256,512} with the
  * logical K zero-padded up to Kp, Ip = I rounded up to a multiple of 32 with zero rows.
  * Products are exact (bf16 x bf16 in fp32), sums fp32 on v_mfma_f32_32x32x16_bf16.
- * Three launches on `stream`: (1) group-max pre-pass over a strided sample of item
- * tiles -> per-query lower bound tau on the k-th best; (2) full sweep, survivors >= tau
- * appended to per-lane candidate segments; (3) per-query select + sort (with an in-kernel
- * exact re-computation for any query whose segments overflowed).
+ * Launches on `stream`: (1) group-max pre-pass over a strided sample of item tiles ->
+ * (2) per-query lower bound tau on the k-th best; (3) full sweep in 1-3 stages, survivors
+ * >= tau appended to per-lane candidate segments, tau raised between stages; (4) per-query
+ * select + sort (a query whose segments overflowed is repaired in the same call by
+ * recomputing the affected item range: the result is always the exact top-k of S_hat).
  * out_val float[Q x k], out_idx int32[Q x k]. */
 size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k);
 int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int32_t k);   /* 1 / 0 */

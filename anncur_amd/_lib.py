@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libanncur_hip.so")
 
 F32, BF16 = 0, 1
+TOPK_LEADING_SAMPLE = 1
 MAX_TOPK = 2048
 
 _p32 = POINTER(c_int32)
@@ -37,8 +38,10 @@ SIGNATURES = {
 	"anncur_score_topk_supported": (c_int, [c_int64, c_int64, c_int32, c_int32]),
 	"anncur_score_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
 								  c_void_p, c_size_t, c_void_p]),
+	"anncur_score_topk_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+									 c_void_p, c_size_t, c_int32, c_void_p, c_void_p]),
 	"anncur_score_topk_timed": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
-										c_void_p, c_size_t, c_void_p, POINTER(ctypes.c_float)]),
+										c_void_p, c_size_t, c_int32, c_void_p, c_void_p, POINTER(ctypes.c_float)]),
 	"anncur_score_topk_plan": (c_int, [c_int64, c_int64, c_int32, c_int32, _p32]),
 	"anncur_rerank": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_overlap_counts": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, _p32, _p32, c_int32, c_void_p, c_void_p]),

@@ -93,6 +93,7 @@ class CURApprox(object):
 
 		self._Et = None   # [m x kc] fp32: latent_cols transposed ("rows" preference)
 		self._Etp = None  # bf16 packed copy for the fused kernel
+		self._Etp_sorted = self._item_ids = None
 		self.latent_rows, self.latent_cols = self._build_latent_row_cols(self.C, self.U, self.R, self.approx_preference)
 
 	# ------------------------------------------------------------------ helpers
@@ -123,7 +124,8 @@ class CURApprox(object):
 			latent_cols = self._Et.t()    # kc x m view (= U @ R)
 			kp = ops.padded_k(self._Et.shape[1])
 			if self.compute_dtype == "bf16" and kp is not None:
-				self._Etp = ops.pack_bf16(self._Et, kp, row_multiple=32)
+				self._Etp = ops.pack_bf16(self._Et, kp, row_multiple=32)               # item order: error terms, dense route
+				self._Etp_sorted, self._item_ids = _norm_sorted_pack(self._Et, kp)     # norm order: fused top-k
 		else:
 			raise NotImplementedError(f"approx_preference = {approx_preference} not supported")
 		return latent_rows, latent_cols
@@ -176,7 +178,7 @@ class CURApprox(object):
 		X = self._to_dev(sparse_rows)
 		Q = X.shape[0]
 		if self._Etp is not None and ops.fused_supported(Q, self.m, self._Etp.shape[1], k):
-			return ops.score_topk_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, self.m, k)
+			return ops.score_topk_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp_sorted, self.m, k, leading_sample=True, item_ids=self._item_ids)
 		Et = self._Et if self.compute_dtype == "fp32" else (self._Etp[:self.m, :X.shape[1]] if self._Etp is not None else self._Et)
 		if self.compute_dtype == "bf16" and X.dtype != torch.bfloat16:
 			X = ops.convert(X, torch.bfloat16)
@@ -193,6 +195,16 @@ class CURApprox(object):
 		if self.compute_dtype == "bf16" and self._Etp is not None and ops.approx_error_packed_ok(self._Etp.shape[1], A):
 			return ops.approx_error_packed(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, A, self.m)
 		return ops.approx_error(X, self._Et, A)
+
+
+def _norm_sorted_pack(Et, kp):
+	"""(packed bf16 E^T with its rows ordered by descending norm, int32 map row -> item id): the index builder's hint for the fused
+	top-k (anncur_score_topk_ex): items with a large ||E_i|| are the likeliest high scorers, so a threshold sampled from the leading
+	rows -- and a sweep that meets them first -- lets far fewer elements through (-40 % on the synthetic protocol, whose norms vary
+	by only 7 %).  The result is unchanged: the exact top-k of S_hat, reported with the original item ids."""
+	norms = (Et.float() ** 2).sum(dim=1)
+	order = torch.argsort(norms, descending=True, stable=True)
+	return ops.pack_bf16(ops.gather_rows(Et, order.to(torch.int32)), kp, row_multiple=32), order.to(torch.int32).contiguous()
 
 
 class CURRowIndex(object):
@@ -212,13 +224,16 @@ class CURRowIndex(object):
 		self.U = _pinv(W, rows.device, pinv_backend)             # kc x kr
 		self._Et = ops.gemm(rows.t(), self.U.t())                # m x kc
 		kp = ops.padded_k(self._Et.shape[1])
-		self._Etp = ops.pack_bf16(self._Et, kp, row_multiple=32) if (compute_dtype == "bf16" and kp is not None) else None
+		self._Etp = self._Etp_sorted = self._item_ids = None
+		if compute_dtype == "bf16" and kp is not None:
+			self._Etp = ops.pack_bf16(self._Et, kp, row_multiple=32)
+			self._Etp_sorted, self._item_ids = _norm_sorted_pack(self._Et, kp)
 
 	def topk(self, X, k):
 		"""X [q x kc]: the queries' exact scores against the anchor items -> (values f32, indices int32) on the GPU."""
 		Q = X.shape[0]
 		if self._Etp is not None and ops.fused_supported(Q, self.m, self._Etp.shape[1], k):
-			return ops.score_topk_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, self.m, k)
+			return ops.score_topk_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp_sorted, self.m, k, leading_sample=True, item_ids=self._item_ids)
 		Et = self._Et if self.compute_dtype == "fp32" or self._Etp is None else self._Etp[:self.m, :X.shape[1]]
 		if self.compute_dtype == "bf16" and X.dtype != torch.bfloat16:
 			X = ops.convert(X, torch.bfloat16)

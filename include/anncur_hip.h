@@ -138,6 +138,18 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
                       float *out_val, int32_t *out_idx,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with two hints an index builder can give (both leave the result the exact top-k of S_hat):
+ *  ANNCUR_TOPK_LEADING_SAMPLE: the rows of Et are ordered so that the likeliest high scorers come first (e.g. by descending
+ *    norm); the threshold sample then takes the leading item tiles instead of a strided sample (fewer survivors in the sweep);
+ *  item_ids (int32[I], may be NULL): out_idx reports item_ids[row of Et] instead of the row (undoes such a reordering; score
+ *    ties are then ordered by row, not by id).  Same workspace as anncur_score_topk. */
+#define ANNCUR_TOPK_LEADING_SAMPLE 1
+int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde,
+                         int64_t Q, int64_t I, int32_t Kp, int32_t k,
+                         float *out_val, int32_t *out_idx,
+                         void *workspace, size_t workspace_bytes,
+                         int32_t flags, const int32_t *item_ids, void *stream);
+
 /* Measurement only: same as anncur_score_topk but records HIP events on `stream` between the four
  * launches, synchronises, and returns their durations in stage_ms[6] (host floats, milliseconds):
  * {prepass, threshold, sweep stage (sweep launches + the threshold refinements between them), select,
@@ -146,7 +158,8 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
 int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t lde,
                             int64_t Q, int64_t I, int32_t Kp, int32_t k,
                             float *out_val, int32_t *out_idx,
-                            void *workspace, size_t workspace_bytes, void *stream, float *stage_ms);
+                            void *workspace, size_t workspace_bytes,
+                            int32_t flags, const int32_t *item_ids, void *stream, float *stage_ms);
 /* Plan introspection: out5 = {sample tiles, item tiles, item splits S, segment capacity, group size}. */
 int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t *out5);
 

@@ -6,7 +6,7 @@ from anncur_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--Q", type=int, default=10000); ap.add_argument("--I", type=int, default=100000)
 ap.add_argument("--K", type=int, default=256); ap.add_argument("--k", type=int, default=100); ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--scan", type=int, default=1)
+ap.add_argument("--scan", type=int, default=1); ap.add_argument("--by-norm", type=int, default=0)
 a = ap.parse_args()
 dev = torch.device("cuda")
 g = torch.Generator(device=dev).manual_seed(0)
@@ -15,10 +15,14 @@ X = (torch.randn(a.Q, 64, generator=g, device=dev) @ torch.randn(64, a.K, genera
 E = (torch.randn(a.K, 64, generator=g, device=dev) @ Z / 8 / 16 + 0.003 * torch.randn(a.K, a.I, generator=g, device=dev)).bfloat16()
 Kp = ops.padded_k(a.K)
 Xp = ops.pack_bf16(X, Kp); Etp = ops.pack_bf16(E.t().contiguous(), Kp, row_multiple=32)
+ids = None
+if a.by_norm:
+	from anncur_amd.cur import _norm_sorted_pack
+	Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), Kp)
 print("plan", ops.fused_plan(a.Q, a.I, Kp, a.k))
 acc = np.zeros(6)
 for i in range(a.iters + 2):
-	(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, a.I, a.k)
+	(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, a.I, a.k, leading_sample=bool(a.by_norm), item_ids=ids)
 	if i >= 2: acc += np.array(ms)
 acc /= a.iters
 print("stage_ms prepass/threshold/sweep-stage/select/sweep-kernels/n:", [round(float(x), 4) for x in acc], "sweep kernels TFLOP/s: %.1f" % (2.0 * a.Q * Kp * a.I / (acc[4] * 1e-3) / 1e12))

@@ -19,7 +19,7 @@ def step(ws, side):
 	with torch.cuda.stream(side):
 		exact = ops.rowwise_topk(A_test, k)
 	Xq = ops.gather_cols(A_test, anc_dev)
-	approx = ops.score_topk_fused(Xq, cur._Etp, I, k, workspace=ws)
+	approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, k, workspace=ws, leading_sample=True, item_ids=cur._item_ids)
 	main.wait_stream(side)
 	return ops.overlap_counts(exact.indices, approx.indices, cells)
 def build(n_streams):

@@ -345,3 +345,30 @@ def test_approx_error_packed_matches_strided_and_fp64(ops, Q, I, K, adt):
 	torch.testing.assert_close(err.cpu().double(), ((S - Ad) ** 2).sum(1), rtol=2e-4, atol=1e-4)
 	torch.testing.assert_close(nrm.cpu().double(), (Ad ** 2).sum(1), rtol=1e-5, atol=1e-5)
 	assert not ops.approx_error_packed_ok(Kp, Abuf.cuda()[:, 1:I + 1])   # misaligned view: callers fall back to the strided kernel
+
+
+def test_fused_index_hints_leave_the_result_unchanged(ops):
+	"""anncur_score_topk_ex: item rows reordered by descending norm + leading-tile threshold sample + id map give the same top-k
+	(values and item sets) as the plain call on the original order."""
+	from anncur_amd.cur import _norm_sorted_pack
+	Q, I, K, k = 333, 70001, 200, 100
+	g = _g(99)
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	E = (torch.randn(K, 24, generator=g) @ torch.randn(24, I, generator=g) / 5 + 0.05 * torch.randn(K, I, generator=g)) * (0.5 + torch.rand(1, I, generator=g))
+	E = E.bfloat16()
+	Kp = ops.padded_k(K)
+	Xp = ops.pack_bf16(X.cuda(), Kp); Et = E.t().contiguous().cuda()
+	v0, i0 = ops.score_topk_fused(Xp, ops.pack_bf16(Et, Kp, row_multiple=32), I, k)
+	Es, ids = _norm_sorted_pack(Et.float(), Kp)
+	assert ids.dtype == torch.int32 and sorted(ids.cpu().tolist()) == list(range(I))
+	n = (Et.float() ** 2).sum(1)[ids.long()]
+	assert (n[:-1] >= n[1:]).all()
+	(v1, i1), nfb = ops.score_topk_fused(Xp, Es, I, k, leading_sample=True, item_ids=ids, return_fallbacks=True)
+	assert nfb.item() == 0
+	torch.testing.assert_close(v1.cpu(), v0.cpu(), rtol=1e-6, atol=1e-6)
+	S = X.double() @ E.double()
+	torch.testing.assert_close(torch.gather(S, 1, i1.cpu().long()), v1.cpu().double(), rtol=1e-4, atol=1e-4)
+	same = [set(a.tolist()) == set(b.tolist()) for a, b in zip(i0.cpu(), i1.cpu())]
+	assert sum(same) >= Q - 2           # (a boundary tie may resolve by row order instead of by id)
+	v2, i2 = ops.score_topk_fused(Xp, Es, I, k, leading_sample=True)          # without the map: row numbers of the sorted matrix
+	assert torch.equal(ids.long()[i2.long()].cpu(), i1.cpu().long())

@@ -29,7 +29,7 @@ class FlatIPIndex:
 		self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 		self.ntotal = 0
 		self._X = None
-		self._Xp = None
+		self._Xp = self._ids = None  # packed bf16 copy in descending-norm order + row -> id map (built at the first bf16 search)
 		self.nprobe = 1  # accepted for FAISS API compatibility
 
 	def add(self, embeds):
@@ -49,8 +49,9 @@ class FlatIPIndex:
 		kp = ops.padded_k(self.d)
 		if self.dtype == "bf16" and kp is not None and ops.fused_supported(q.shape[0], self.ntotal, kp, k_eff):
 			if self._Xp is None:
-				self._Xp = ops.pack_bf16(self._X, kp, row_multiple=32)
-			v, i = ops.score_topk_fused(ops.pack_bf16(q, kp), self._Xp, self.ntotal, k_eff)
+				from .cur import _norm_sorted_pack
+				self._Xp, self._ids = _norm_sorted_pack(self._X, kp)   # largest-norm vectors first: the likeliest maximum inner products
+			v, i = ops.score_topk_fused(ops.pack_bf16(q, kp), self._Xp, self.ntotal, k_eff, leading_sample=True, item_ids=self._ids)
 		else:
 			v, i = ops.score_topk_dense(q, self._X, k_eff)
 		D = np.full((q.shape[0], k), -np.inf, dtype=np.float32)   # FAISS pads missing results with -inf / -1

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 	const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg, int S, SweepStages stg, int capg,
 	const uint16_t *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ Et, int64_t I, int KP, uint32_t k,
 	float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *__restrict__ n_fallback,
-	const int32_t *__restrict__ hard_list, const uint32_t *__restrict__ hard_cnt) {
+	const int32_t *__restrict__ hard_list, const uint32_t *__restrict__ hard_cnt, const float *__restrict__ tau_in, int tau_stride) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const SelState s = sel_carve<KMAX>(smem);
 	float *xq = reinterpret_cast<float *>(smem + SelCfg<KMAX>::LDS_BYTES);  // [KP], repair / fallback only
@@ -640,7 +640,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 	}
 	__syncthreads();
 	const uint32_t total = s.scal[9], maxc = s.scal[10];
-	float tau = -INFINITY;
+	// (the threshold the last sweep stage ran with: earlier stages' candidates below it are dropped at the load)
+	float tau = tau_in ? tau_in[q * tau_stride] : -INFINITY;
 	uint64_t tau_key = 0;
 	bool full = !repair && total < k;  // cannot happen with a valid threshold; kept as the last line of defence
 	if (!full) {
@@ -700,6 +701,48 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 	}
 	sel_finish<KMAX>(s, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 	}
+}
+
+// Threshold refinement between sweep stages for k > 128 (workgroup-level selector): tau[q] = max(tau[q], k-th best candidate so far).
+// A query with an overflowed segment, or with fewer than k candidates yet, keeps its (still valid) threshold.
+template <int KMAX>
+__global__ __launch_bounds__(SEL_THREADS) void tau_block_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg,
+																 int capg, uint32_t k, float *__restrict__ tau_out, int tau_stride, int prefilter) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const SelState s = sel_carve<KMAX>(smem);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int64_t q = blockIdx.x;
+	sel_init(s);
+	const uint32_t *cnts = seg_cnt + q * nseg;
+	for (int sg = tid; sg < nseg; sg += SEL_THREADS) {
+		const uint32_t c = cnts[sg];
+		if (c > (uint32_t)capg) atomicOr(&s.scal[8], 1u);
+		atomicAdd(&s.scal[9], c > (uint32_t)capg ? 0u : c);
+		atomicMax(&s.scal[10], c > (uint32_t)capg ? 0u : c);
+	}
+	__syncthreads();
+	if (s.scal[8] != 0u || s.scal[9] <= k) return;  // (uniform)
+	const uint32_t maxc = s.scal[10];
+	float tau = prefilter ? tau_out[q * tau_stride] : -INFINITY;  // earlier candidates below the running threshold cannot be the k-th best
+	uint64_t tau_key = 0;
+	for (int sb = 0; sb < nseg; sb += 4) {
+		const int sg = sb + wave;
+		const uint32_t c = sg < nseg ? cnts[sg] : 0u;
+		const uint2 *sp = cand + (q * nseg + (sg < nseg ? sg : 0)) * (int64_t)capg;
+		for (uint32_t e0 = 0; e0 < maxc; e0 += WAVE) {
+			const uint32_t e = e0 + lane;
+			const bool in = e < c;
+			const uint2 ce = in ? sp[e] : make_uint2(0, 0);
+			sel_offer(s, in, __uint_as_float(ce.x), ce.y, tau, tau_key);
+			sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+		}
+	}
+	__syncthreads();
+	if (s.scal[0] > k) {  // (uniform) cut to k: the k-th best key is the new threshold
+		tau_key = sel_compact<KMAX>(s, k);
+		tau = key_val(tau_key);
+	}
+	if (tid == 0 && tau_key != 0 && s.scal[0] >= k) tau_out[q * tau_stride] = fmaxf(tau_out[q * tau_stride], tau);
 }
 
 // One WAVE per query (k <= 128, <= 64 segments): the query's candidate segments are streamed through the wave-level
@@ -836,10 +879,12 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 	// per extra stage (threshold kernel + launch ramp).  Needs the wave-level selector (k <= 128, <= 64 segments).
 	{
 		double frac[3] = {1.0, 1.0, 1.0};
-		const bool staged = k <= WSEL_K && 2 * P.S <= WAVE && P.n_tiles >= 24 * P.S;
+		// k <= 128: wave-level refinement kernel (<= 64 segments); larger k: workgroup-level one (dearer: ~1.4e-11 s per candidate read)
+		const bool staged = (k <= WSEL_K ? 2 * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S;
 		P.n_stages = 1;
 		if (staged) {
-			const double H0 = exp_hits, c_hit = 2.4e-11 * (double)Q, c_stage = 25e-6 + 3e-9 * (double)Q;
+			const double H0 = exp_hits, c_hit = 2.4e-11 * (double)Q;
+			const double c_stage = k <= WSEL_K ? 25e-6 + 3e-9 * (double)Q : 25e-6 + 1.4e-11 * (double)Q * 0.3 * H0;
 			auto later = [&](double f) { const double h = 1.2 * k / f; return h < H0 ? h : H0; };
 			double best = H0 * c_hit;
 			static const double grid[] = {0.02, 0.03, 0.04, 0.06, 0.08, 0.10, 0.12, 0.15, 0.18, 0.22, 0.26, 0.30, 0.35, 0.40, 0.50};
@@ -958,10 +1003,25 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		}
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
-		if (stg + 1 < P.n_stages) {
+		if (stg + 1 < P.n_stages && k <= WSEL_K) {
 			hipLaunchKernelGGL((select_wave_kernel<true>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
 							   p.seg_cnt, 2 * P.S, P.capg, Q, (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
 							   (int32_t *)nullptr, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0);
+			ANNCUR_LAUNCH_OK();
+		} else if (stg + 1 < P.n_stages) {
+#define LAUNCH_TAU(KM)                                                                                                        \
+			do {                                                                                                              \
+				static bool attr_done = false;                                                                                \
+				if (!attr_done) {                                                                                             \
+					ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)tau_block_kernel<KM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+													  (int)SelCfg<KM>::LDS_BYTES));                                           \
+					attr_done = true;                                                                                         \
+				}                                                                                                             \
+				hipLaunchKernelGGL((tau_block_kernel<KM>), dim3((unsigned)Q), dim3(SEL_THREADS), SelCfg<KM>::LDS_BYTES, st, p.cand, p.seg_cnt, \
+								   2 * P.S, P.capg, (uint32_t)k, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0);  \
+			} while (0)
+			if (P.kmax == 512) LAUNCH_TAU(512); else LAUNCH_TAU(2048);
+#undef LAUNCH_TAU
 			ANNCUR_LAUNCH_OK();
 		}
 	}
@@ -981,7 +1041,8 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			attr_lds = lds;                                                                                            \
 		}                                                                                                              \
 		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, p.cand, p.seg_cnt, nseg, \
-						   P.S, stages, P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt);  \
+						   P.S, stages, P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt,      \
+						   P.n_stages > 1 ? p.tau : (const float *)nullptr, p.tau_stride);                                                   \
 	} while (0)
 	// fast path: one wave per query; what it cannot take lands in hard_list for the workgroup-level kernel
 	const int32_t *hard_list = nullptr;

@@ -372,3 +372,20 @@ def test_fused_index_hints_leave_the_result_unchanged(ops):
 	assert sum(same) >= Q - 2           # (a boundary tie may resolve by row order instead of by id)
 	v2, i2 = ops.score_topk_fused(Xp, Es, I, k, leading_sample=True)          # without the map: row numbers of the sorted matrix
 	assert torch.equal(ids.long()[i2.long()].cpu(), i1.cpu().long())
+
+
+def test_fused_wrong_index_hint_is_still_exact(ops):
+	"""ANNCUR_TOPK_LEADING_SAMPLE on rows ordered the WRONG way (ascending norm, strongly skewed norms): the threshold sampled from the
+	leading tiles is far too low, segments overflow, the in-call repair keeps the result exact."""
+	Q, I, K, k = 200, 60000, 64, 50
+	g = _g(7)
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	scale = torch.linspace(0.01, 3.0, I)                              # item norms grow along the row order
+	E = (torch.randn(K, I, generator=g) * scale).bfloat16()
+	Xp = ops.pack_bf16(X.cuda(), 64); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 64, row_multiple=32)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, return_fallbacks=True)
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
+	torch.testing.assert_close(torch.gather(S, 1, i.cpu().long()), v.cpu().double(), rtol=1e-4, atol=1e-4)
+	assert sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(i.cpu(), ri)) >= Q - 2

@@ -3,9 +3,13 @@ Data plumbing for bench.py / tests (torch RNG); not part of the compute path."""
 import torch
 
 
-def protocol_b(n_train, n_test, n_items, device, seed=0, rank=64, noise=0.05, dtype=torch.bfloat16, chunk=2048):
+def protocol_b(n_train, n_test, n_items, device, seed=0, rank=64, noise=0.05, dtype=torch.bfloat16, chunk=2048, row_seed=None):
+	"""row_seed: a second seed for the ROW factors and the noise.  The item factors Z always come from `seed`, so processes that
+	pass the same seed and different row seeds (the ranks of a row-sharded run) draw different queries of ONE score model."""
 	g = torch.Generator(device=device).manual_seed(seed)
 	Z = torch.randn(rank, n_items, generator=g, device=device)
+	if row_seed is not None:
+		g = torch.Generator(device=device).manual_seed(row_seed)
 
 	def make(n):
 		out = torch.empty(n, n_items, dtype=dtype, device=device)

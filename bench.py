@@ -39,10 +39,10 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
-def synth_device(cfg, device, seed):
+def synth_device(cfg, device, seed, row_seed=None):
 	"""Protocol-B synthetic matrices on the device: shared item factors, low rank + noise, bf16 storage."""
 	from anncur_amd.synth import protocol_b
-	return protocol_b(cfg["Kq"], cfg["Q"], cfg["I"], device, seed=seed)
+	return protocol_b(cfg["Kq"], cfg["Q"], cfg["I"], device, seed=seed, row_seed=row_seed)
 
 
 def main():
@@ -88,7 +88,8 @@ def main():
 	# ------------------------------------------------------------------ data + index (outside the timed region)
 	# Every rank owns Q queries; the index matrix (anchor queries' rows) is the same on every rank.  With N > 1 it is
 	# assembled the way a row-sharded score matrix delivers it: each rank contributes Kq/N anchor rows, one all-gather.
-	A_train, A_test = synth_device(cfg, device, args.seed * 1000 + rank)
+	# one score model for the whole job (item factors from --seed); every rank draws its own queries and its own share of the anchor rows
+	A_train, A_test = synth_device(cfg, device, args.seed, row_seed=None if world == 1 else args.seed * 1000 + rank + 1)
 	if use_dist:
 		A_train = allgather_anchor_rows(A_train, cfg["Kq"], rank, world)
 	rng = np.random.default_rng(args.seed)

@@ -229,3 +229,62 @@ def test_bench_contract_small_config(gpu):
 	# same queries through both paths: identical recall up to the tie-stable statement of the reference loop
 	for key, want in d["cpu_baseline"]["recall_cpu_fp32_tie_stable"].items():
 		assert abs(d["cpu_baseline"]["recall_gpu_same_queries"][key] - want) <= 5e-3, key
+
+
+def test_entry_point_B_other_methods_match_reference_restatement(gpu, tmp_path):
+	"""eval_method = fixed_anc_ent / fixed_anc_ent_cur (e2e pickle) and bienc (precomputed embeddings) through the CLI against a
+	CPU restatement of the reference's lines (splits.py:305-358: the approximations; :399-429: the sweep via the oracle loop)."""
+	from eval import run_retrieval_eval_wrt_exact_crossenc_w_fixed_train_test_splits as epB
+	from oracle import cur_oracle as O
+	g = torch.Generator().manual_seed(11)
+	n_ent, n_train, n_test, r, n_fixed = 700, 50, 45, 12, 40
+	Z = torch.randn(r, n_ent, generator=g)
+	A_train = torch.randn(n_train, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_train, n_ent, generator=g)
+	A_test = torch.randn(n_test, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_test, n_ent, generator=g)
+	_dump(str(tmp_path / "train.pkl"), A_train, ment_idxs=list(range(n_train)))
+	_dump(str(tmp_path / "test.pkl"), A_test, ment_idxs=list(range(n_train, n_train + n_test)))
+	# entity-to-entity scores against 60 "fixed anchor" entities (same factor model), as the e2e dump holds them
+	topk_ents = torch.randperm(n_ent, generator=g)[:60]
+	e2e = (Z.t() @ Z[:, topk_ents]) / r + 0.02 * torch.randn(n_ent, 60, generator=g)          # n_ents x n_anchors
+	with open(tmp_path / "e2e.pkl", "wb") as f:
+		pickle.dump({"ent_to_ent_scores": e2e, "topk_ents": [topk_ents.numpy()]}, f)
+	ment_emb = torch.randn(n_test, 32, generator=g); ent_emb = torch.randn(n_ent, 32, generator=g)
+	np.save(tmp_path / "ment.npy", ment_emb.numpy()); np.save(tmp_path / "ent.npy", ent_emb.numpy())
+	top_k, retr, ancs = [1, 10], [20, 50], [30, 45]
+	common = ["--data_name", "lego", "--res_dir", str(tmp_path / "out"), "--test_data_file", str(tmp_path / "test.pkl"), "--train_data_file", str(tmp_path / "train.pkl"),
+			  "--n_seeds", "1", "--top_k_vals", "1,10", "--top_k_retr_vals", "20,50", "--n_ent_anchors_vals", "30,45"]
+	key = "exact_vs_reranked_approx_retvr~common_frac_mean"
+
+	def sweep(approx_by_anchor):   # splits.py:399-429 with the oracle's statement of the per-query loop
+		out = {}
+		for n_anc, S in approx_by_anchor.items():
+			for kr in retr:
+				res = O.eval_approx_score_mat_for_all_topk(A_test, S, top_k, kr)
+				for k, m in res.items():
+					out[(k, kr, n_anc)] = m[key]
+		return out
+
+	def check(res_file, want, tol):
+		with open(res_file) as f:
+			got = json.load(f)["seed=0"]
+		for (k, kr, n_anc), v in want.items():
+			assert got[f"top_k={k}"][f"k_retvr={kr}"][f"anc_n_m={n_train}_anc_n_e={n_anc}"][key] == pytest.approx(v, abs=tol), (k, kr, n_anc)
+
+	# fixed_anc_ent (splits.py:305-324): scores = A_test[:, first n fixed anchors] @ e2e[:, :n].T, the same result for every anchor count
+	anc_ids = topk_ents[:n_fixed].numpy()
+	S_fix = A_test[:, anc_ids] @ e2e[:, :n_fixed].t()
+	f1 = epB.main(common + ["--eval_method", "fixed_anc_ent", "--e2e_fname", str(tmp_path / "e2e.pkl"), "--n_fixed_anc_ent", str(n_fixed), "--misc", "fae"])
+	check(f1, sweep({a: S_fix for a in ancs}), 0.03)
+	# fixed_anc_ent_cur (splits.py:327-358): R = e2e[:, :n].T, anchors from rng(0) consumed over the anchor counts, U = pinv(R[:, anc])
+	R = e2e[:, :n_fixed].t()
+	rng = np.random.default_rng(seed=0)
+	approx = {}
+	for n_anc in ancs:
+		anc = sorted(rng.choice(n_ent, size=n_anc, replace=False))
+		U = torch.tensor(np.linalg.pinv(R[:, anc].numpy()))
+		approx[n_anc] = A_test[:, anc] @ (U @ R)
+	f2 = epB.main(common + ["--eval_method", "fixed_anc_ent_cur", "--e2e_fname", str(tmp_path / "e2e.pkl"), "--n_fixed_anc_ent", str(n_fixed), "--misc", "faec"])
+	check(f2, sweep(approx), 0.05)
+	# bienc (splits.py:283): scores = mention_embeds @ label_embeds.T from precomputed embeddings
+	f3 = epB.main(common + ["--eval_method", "bienc", "--mention_embeds_file", str(tmp_path / "ment.npy"), "--entity_embeds_file", str(tmp_path / "ent.npy"), "--misc", "bi"])
+	check(f3, sweep({a: ment_emb @ ent_emb.t() for a in ancs}), 0.03)

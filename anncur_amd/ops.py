@@ -223,6 +223,9 @@ def pack_bf16(M, Kp, row_multiple=1):
 	return out
 
 
+FUSED_WS_LIMIT_BYTES = 32 << 30   # default workspace above this size -> score_topk_fused runs the queries in row chunks
+
+
 class _Workspace:
 	"""Grow-only device scratch for the fused kernel (one per device)."""
 	_bufs = {}
@@ -276,6 +279,17 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 	nbytes = lib.anncur_score_topk_workspace_bytes(Q, I, Kp, k)
 	if nbytes == 0:
 		raise _lib.AnncurHipError(f"score_topk: shape (Q={Q}, I={I}, Kp={Kp}, k={k}) is outside the fused path")
+	if workspace is None and nbytes > FUSED_WS_LIMIT_BYTES and Q > 512 and not return_fallbacks:
+		# very many queries: the candidate segments grow with Q; run row chunks whose workspace stays under the limit
+		qc = Q
+		while qc > 512 and lib.anncur_score_topk_workspace_bytes(qc, I, Kp, k) > FUSED_WS_LIMIT_BYTES:
+			qc = max(512, (qc // 2 + 255) // 256 * 256)
+		val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
+		idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
+		for q0 in range(0, Q, qc):   # (a chunk of 512 queries is accepted whatever its workspace size)
+			part = score_topk_fused(Xp[q0:q0 + qc], Etp, I, k, leading_sample=leading_sample, item_ids=item_ids)
+			val[q0:q0 + qc], idx[q0:q0 + qc] = part.values, part.indices
+		return TopK(val, idx)
 	if workspace is None:
 		ws = _Workspace.get(nbytes, Xp.device)
 	else:

@@ -389,3 +389,12 @@ def test_fused_wrong_index_hint_is_still_exact(ops):
 	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
 	torch.testing.assert_close(torch.gather(S, 1, i.cpu().long()), v.cpu().double(), rtol=1e-4, atol=1e-4)
 	assert sum(set(a.tolist()) == set(b.tolist()) for a, b in zip(i.cpu(), ri)) >= Q - 2
+
+
+def test_fused_row_chunking_when_the_workspace_would_be_huge(ops, monkeypatch):
+	X, E, Xp, Etp = _fused_case(ops, 2100, 40000, 128, 50, seed=5)
+	v0, i0 = ops.score_topk_fused(Xp, Etp, 40000, 50)
+	full = ops._lib.load().anncur_score_topk_workspace_bytes(2100, 40000, 128, 50)
+	monkeypatch.setattr(ops, "FUSED_WS_LIMIT_BYTES", full // 3)          # forces three or more row chunks
+	v1, i1 = ops.score_topk_fused(Xp, Etp, 40000, 50)
+	assert torch.equal(v0, v1) and torch.equal(i0, i1)

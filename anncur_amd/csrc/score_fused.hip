@@ -345,7 +345,10 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		uint32_t aoff[KSTEPS];       // LDS byte address of this lane's A fragment of k-step s in tile buffer 0
 #pragma unroll
 		for (int s = 0; s < KSTEPS; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
-		int flush_in2 = p.flush_tiles;
+		// norm-ordered rows: the survivors crowd into the leading tiles (several times the average density), i.e. into the first
+		// item splits of the first stage, and a wrapped ring costs a repair of the whole split: those splits drain every tile
+		const int flush_period = (p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;
+		int flush_in2 = flush_period;
 		// stagger_tile() counts LDS reads with lgkmcnt(n): no scalar load of the prologue may still be in flight (scalar loads share
 		// the counter and return out of order)
 		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		do {                                                                                                                    \
 			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
 			if (--flush_in2 == 0) {                                                                                             \
-				flush_in2 = p.flush_tiles;                                                                                      \
+				flush_in2 = flush_period;                                                                                       \
 				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);                        \
 				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I);               \
 			}                                                                                                                   \
@@ -373,7 +376,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
 	} else {
-	int flush_in = p.flush_tiles;
+	const int flush_period_p = (MODE == 1 && p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;  // (see the staggered path)
+	int flush_in = flush_period_p;
 	for (int j = j_begin; j < j_end; ++j) {
 		const int cur = (j - j_begin) & 1;
 		const int tile = tile_of(j);
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 		if (MODE == 1) {
 			// drain the hit queues of the previous tiles right behind the DMA: the stores get the whole MFMA phase to retire
 			if (--flush_in == 0) {
-				flush_in = p.flush_tiles;
+				flush_in = flush_period_p;
 #pragma unroll
 				for (int t = 0; t < QT; ++t) flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I);
 			}

@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libanncur_hip.so")
+# ANNCUR_LIB: measurement scripts point this at the -DANNCUR_TIMING_EXPERIMENTS build (`make -C anncur_amd/csrc experiments`)
+LIB_PATH = os.environ.get("ANNCUR_LIB") or os.path.join(_HERE, "lib", "libanncur_hip.so")
 
 F32, BF16 = 0, 1
 TOPK_LEADING_SAMPLE = 1

@@ -13,6 +13,10 @@ int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int
 int anncur_internal_approx_error_acc(const void *X, int x_dtype, int64_t ldx, const void *Et, int e_dtype, int64_t lde, const void *Aex, int a_dtype,
 									 int64_t lda, int64_t Q, int64_t I, int64_t K, float *err_sq, float *norm_sq, void *stream);
 
+// misc.hip: per-device caches (one process may drive several GPUs)
+int anncur_ensure_dyn_lds(const void *fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device)
+int anncur_num_cu();                                   // CU count of the current device
+
 #define ANNCUR_REQUIRE(cond, code, ...)                 \
 	do {                                                \
 		if (!(cond)) {                                  \

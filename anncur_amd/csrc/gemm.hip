@@ -173,8 +173,8 @@ extern "C" int anncur_gemm_ex(const void *A, int a_dtype, int64_t a_sm, int64_t 
 							  int64_t N, int64_t K, float alpha, float beta, const float *Cin, int64_t i_sm, int64_t i_sn, void *stream) {
 	ANNCUR_REQUIRE(dtype_ok(a_dtype) && dtype_ok(b_dtype) && dtype_ok(c_dtype), ANNCUR_E_INVALID, "gemm: bad dtype");
 	ANNCUR_REQUIRE(M >= 0 && N >= 0 && K >= 0, ANNCUR_E_INVALID, "gemm: negative dimension");
-	ANNCUR_REQUIRE(A && B && C, ANNCUR_E_INVALID, "gemm: null pointer");
-	if (M == 0 || N == 0) return ANNCUR_OK;
+	if (M == 0 || N == 0) return ANNCUR_OK;  // (empty tensors have null data pointers: nothing to do comes first)
+	ANNCUR_REQUIRE(C && (K == 0 || (A && B)), ANNCUR_E_INVALID, "gemm: null pointer");
 	const int64_t gx = ceil_div64(N, BN), gy = ceil_div64(M, BM);
 	ANNCUR_REQUIRE(gy <= 65535 && gx < (int64_t)0x7fffffff, ANNCUR_E_INVALID, "gemm: M too large for one launch (M <= %d)", 65535 * BM);
 	hipStream_t st = (hipStream_t)stream;
@@ -202,8 +202,8 @@ int anncur_internal_approx_error_acc(const void *X, int x_dtype, int64_t ldx, co
 									 float *norm_sq, void *stream) {
 	ANNCUR_REQUIRE(dtype_ok(x_dtype) && dtype_ok(e_dtype) && dtype_ok(a_dtype), ANNCUR_E_INVALID, "approx_error: bad dtype");
 	ANNCUR_REQUIRE(Q >= 0 && I >= 1 && K >= 1 && ldx >= K && lde >= K && lda >= I, ANNCUR_E_INVALID, "approx_error: bad shape");
-	ANNCUR_REQUIRE(X && Et && Aex && err_sq && norm_sq, ANNCUR_E_INVALID, "approx_error: null pointer");
 	if (Q == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(X && Et && Aex && err_sq && norm_sq, ANNCUR_E_INVALID, "approx_error: null pointer");
 	const int64_t gx = ceil_div64(I, BN), gy = ceil_div64(Q, BM);
 	ANNCUR_REQUIRE(gy <= 65535, ANNCUR_E_INVALID, "approx_error: Q too large for one launch");
 	hipStream_t st = (hipStream_t)stream;

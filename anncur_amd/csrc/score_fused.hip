@@ -816,18 +816,7 @@ struct FusedPlan {
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, total;
 };
 
-int g_num_cu = 0;
-int num_cu() {
-	if (g_num_cu == 0) {
-		int dev = 0;
-		hipDeviceProp_t prop;
-		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-			g_num_cu = prop.multiProcessorCount;
-		else
-			g_num_cu = 256;  // MI355X
-	}
-	return g_num_cu;
-}
+int num_cu() { return anncur_num_cu(); }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -907,6 +896,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 				}
 			}
 		}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
 		if (const char *dbg = getenv("ANNCUR_DEBUG_STAGES")) {  // tuning knob "f1,f2" or "f1" (>= 1: single stage)
 			double f1 = 0, f2 = 0;
 			const int n = sscanf(dbg, "%lf,%lf", &f1, &f2);
@@ -914,6 +904,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 			else if (staged && n == 1 && f1 > 0 && f1 < 1) { frac[0] = f1; frac[1] = 1.0; P.n_stages = 2; }
 			else if (n == 1 && f1 >= 1) P.n_stages = 1;
 		}
+#endif
 		double rate = exp_hits / ((double)P.n_tiles * 2.0);  // expected hits per (query half, tile) in the first stage
 		int prev = 0;
 		for (int i = 0; i < P.n_stages; ++i) {
@@ -958,8 +949,11 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	int32_t *tidx = (int32_t *)(ws + P.off_tidx);
 	p.tau = tval + (k - 1); p.tau_stride = k;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
+	p.tau_bias = 0.f;
+#ifdef ANNCUR_TIMING_EXPERIMENTS  // (the -DANNCUR_TIMING_EXPERIMENTS build of scripts/fused_microbench.py only: results become wrong)
 	{ const char *dbg = getenv("ANNCUR_DEBUG_TAU_BIAS"); p.tau_bias = dbg ? (float)atof(dbg) : 0.f; }
-	if (getenv("ANNCUR_DEBUG_NOSTORE")) p.capg = 0;  // timing experiment: every candidate is dropped at the store (results invalid)
+	if (getenv("ANNCUR_DEBUG_NOSTORE")) p.capg = 0;  // every candidate is dropped at the store
+#endif
 
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
 	EV(0);
@@ -984,27 +978,24 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	EV(2);
 	// 3. sweep, in stages; between stages the thresholds are raised from the candidates collected so far
 	p.n_wg = P.n_rb * P.S;
-	{
-		static bool attr_set = false;
-		if (!attr_set) {
-			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)score_kernel<KP, 1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WaveSelLayout<WQ_CAP>::BYTES));
-			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WaveSelLayout<WQ_CAP>::BYTES));
-			attr_set = true;
-		}
-	}
+	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+	if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<true>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
+	if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<false>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
 		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
 		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
-		if (getenv("ANNCUR_DEBUG_GEMM_NOSYNC")) {  // timing experiment only: MFMA + LDS fragment reads, no staging, no barriers
+		if (getenv("ANNCUR_DEBUG_GEMM_NOSYNC")) {  // MFMA + LDS fragment reads, no staging, no barriers
+			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 3, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 			hipLaunchKernelGGL((score_kernel<KP, 3, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
-		} else if (getenv("ANNCUR_DEBUG_GEMM_ONLY")) {  // timing experiment only (no candidates are produced)
+		} else if (getenv("ANNCUR_DEBUG_GEMM_ONLY")) {  // no candidates are produced
+			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 2, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 			hipLaunchKernelGGL((score_kernel<KP, 2, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
-		} else {
-			hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
-		}
+		} else
+#endif
+		hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
 		if (stg + 1 < P.n_stages && k <= WSEL_K) {
@@ -1015,12 +1006,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		} else if (stg + 1 < P.n_stages) {
 #define LAUNCH_TAU(KM)                                                                                                        \
 			do {                                                                                                              \
-				static bool attr_done = false;                                                                                \
-				if (!attr_done) {                                                                                             \
-					ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)tau_block_kernel<KM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-													  (int)SelCfg<KM>::LDS_BYTES));                                           \
-					attr_done = true;                                                                                         \
-				}                                                                                                             \
+				if ((rc = anncur_ensure_dyn_lds((const void *)tau_block_kernel<KM>, (int)SelCfg<KM>::LDS_BYTES)) != ANNCUR_OK) return rc; \
 				hipLaunchKernelGGL((tau_block_kernel<KM>), dim3((unsigned)Q), dim3(SEL_THREADS), SelCfg<KM>::LDS_BYTES, st, p.cand, p.seg_cnt, \
 								   2 * P.S, P.capg, (uint32_t)k, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0);  \
 			} while (0)
@@ -1038,12 +1024,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 #define LAUNCH_SELECT(KM)                                                                                              \
 	do {                                                                                                               \
 		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)KP * 4 + 32;                                                \
-		static size_t attr_lds = 0;                                                                                    \
-		if (attr_lds < lds) {                                                                                          \
-			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)select_candidates_kernel<KM>,                              \
-											  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-			attr_lds = lds;                                                                                            \
-		}                                                                                                              \
+		if ((rc = anncur_ensure_dyn_lds((const void *)select_candidates_kernel<KM>, (int)lds)) != ANNCUR_OK) return rc; \
 		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, p.cand, p.seg_cnt, nseg, \
 						   P.S, stages, P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt,      \
 						   P.n_stages > 1 ? p.tau : (const float *)nullptr, p.tau_stride);                                                   \

@@ -520,24 +520,25 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 	const int kc = kmax_class(k);
 #define LAUNCH_ROWTOPK(T, KM)                                                                                   \
 	do {                                                                                                        \
-		static bool attr_done = false;                                                                          \
-		if (!attr_done) {                                                                                       \
-			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)rowwise_topk_kernel<T, KM, (KM == 128)>,            \
-											  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SelCfg<KM, SCAN_PASS>::LDS_BYTES))); \
-			attr_done = true;                                                                                   \
-		}                                                                                                       \
+		{ const int rc_ = anncur_ensure_dyn_lds((const void *)rowwise_topk_kernel<T, KM, (KM == 128)>, (int)(SelCfg<KM, SCAN_PASS>::LDS_BYTES)); if (rc_ != ANNCUR_OK) return rc_; } \
 		hipLaunchKernelGGL((rowwise_topk_kernel<T, KM, (KM == 128)>), dim3((unsigned)Q), dim3(SEL_THREADS), (SelCfg<KM, SCAN_PASS>::LDS_BYTES), st, \
 						   (const T *)A, I, lda, (uint32_t)k, out_val, out_idx);                                \
 	} while (0)
 	ANNCUR_REQUIRE(Q < (int64_t)0x7fffffff, ANNCUR_E_INVALID, "rowwise_topk: Q too large");
-	if (k <= WSEL_K && !getenv("ANNCUR_DEBUG_BLOCK_SCAN")) {  // barrier-free path: one wave per row
+	bool wave_scan = k <= WSEL_K;  // barrier-free path: one wave per row
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (getenv("ANNCUR_DEBUG_BLOCK_SCAN")) wave_scan = false;
+#endif
+	if (wave_scan) {
 		const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
 		const unsigned grid = (unsigned)ceil_div64(Q, 4);
 		uint32_t trig = ws_trigger((uint32_t)k);
+#ifdef ANNCUR_TIMING_EXPERIMENTS
 		if (const char *dbg = getenv("ANNCUR_DEBUG_SCAN_TRIGGER")) {  // tuning knob: any value in (k, 512] is exact
 			const int t = atoi(dbg);
 			if (t > k && t <= 512) trig = (uint32_t)t;
 		}
+#endif
 		if (dtype == ANNCUR_F32)
 			hipLaunchKernelGGL((rowwise_topk_wave_kernel<float>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
 		else
@@ -568,12 +569,7 @@ extern "C" int anncur_rerank(const void *A, int dtype, int64_t Q, int64_t I, int
 	const int kc = kmax_class(k_out);
 #define LAUNCH_RERANK(T, KM)                                                                                    \
 	do {                                                                                                        \
-		static bool attr_done = false;                                                                          \
-		if (!attr_done) {                                                                                       \
-			ANNCUR_HIP_OK(hipFuncSetAttribute((const void *)rerank_kernel<T, KM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-											  (int)SelCfg<KM>::LDS_BYTES));                                     \
-			attr_done = true;                                                                                   \
-		}                                                                                                       \
+		{ const int rc_ = anncur_ensure_dyn_lds((const void *)rerank_kernel<T, KM>, (int)SelCfg<KM>::LDS_BYTES); if (rc_ != ANNCUR_OK) return rc_; } \
 		hipLaunchKernelGGL((rerank_kernel<T, KM>), dim3((unsigned)Q), dim3(SEL_THREADS), SelCfg<KM>::LDS_BYTES, st, \
 						   (const T *)A, I, lda, approx_idx, ld_idx, (uint32_t)k_retvr, (uint32_t)k_out, rerank_val, rerank_idx); \
 	} while (0)
@@ -618,8 +614,8 @@ extern "C" int anncur_gather_cols(const void *A, int dtype, int64_t n_rows, int6
 	ANNCUR_REQUIRE(dtype_ok(dtype) && dtype_ok(dst_dtype), ANNCUR_E_INVALID, "gather_cols: bad dtype");
 	ANNCUR_REQUIRE(n_rows >= 0 && n_cols >= 1 && lda >= n_cols && n_idx >= 0 && ldo >= n_idx && n_rows < (int64_t)0x7fffffff,
 				   ANNCUR_E_INVALID, "gather_cols: bad shape");
+	if (n_rows == 0 || n_idx == 0) return ANNCUR_OK;  // (empty tensors have null data pointers: nothing to do comes first)
 	ANNCUR_REQUIRE(A && col_idx && out, ANNCUR_E_INVALID, "gather_cols: null pointer");
-	if (n_rows == 0 || n_idx == 0) return ANNCUR_OK;
 	hipStream_t st = (hipStream_t)stream;
 	const int rc = dispatch2(dtype, dst_dtype, [&](auto *s, auto *d) {
 		using TS = std::remove_cv_t<std::remove_pointer_t<decltype(s)>>;
@@ -638,8 +634,8 @@ extern "C" int anncur_gather_rows(const void *A, int dtype, int64_t n_rows, int6
 	ANNCUR_REQUIRE(dtype_ok(dtype) && dtype_ok(dst_dtype), ANNCUR_E_INVALID, "gather_rows: bad dtype");
 	ANNCUR_REQUIRE(n_rows >= 1 && n_cols >= 0 && lda >= n_cols && n_idx >= 0 && ldo >= n_cols && n_idx <= 65535,
 				   ANNCUR_E_INVALID, "gather_rows: bad shape (n_idx <= 65535)");
-	ANNCUR_REQUIRE(A && row_idx && out, ANNCUR_E_INVALID, "gather_rows: null pointer");
 	if (n_cols == 0 || n_idx == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(A && row_idx && out, ANNCUR_E_INVALID, "gather_rows: null pointer");
 	hipStream_t st = (hipStream_t)stream;
 	dispatch2(dtype, dst_dtype, [&](auto *s, auto *d) {
 		using TS = std::remove_cv_t<std::remove_pointer_t<decltype(s)>>;
@@ -656,8 +652,8 @@ extern "C" int anncur_convert(const void *src, int src_dtype, int64_t lds_, void
 							  int64_t n_rows, int64_t n_cols, void *stream) {
 	ANNCUR_REQUIRE(dtype_ok(src_dtype) && dtype_ok(dst_dtype), ANNCUR_E_INVALID, "convert: bad dtype");
 	ANNCUR_REQUIRE(n_rows >= 0 && n_cols >= 0 && lds_ >= n_cols && ldd >= n_cols && n_rows <= 65535 * 1024LL, ANNCUR_E_INVALID, "convert: bad shape");
-	ANNCUR_REQUIRE(src && dst, ANNCUR_E_INVALID, "convert: null pointer");
 	if (n_rows == 0 || n_cols == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(src && dst, ANNCUR_E_INVALID, "convert: null pointer");
 	hipStream_t st = (hipStream_t)stream;
 	// grid.y is limited to 65535: loop over row chunks
 	for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
@@ -675,9 +671,9 @@ extern "C" int anncur_convert(const void *src, int src_dtype, int64_t lds_, void
 }
 
 extern "C" int anncur_copy_bytes(const void *src, void *dst, size_t nbytes, void *stream) {
+	if (nbytes == 0) return ANNCUR_OK;
 	ANNCUR_REQUIRE(src && dst, ANNCUR_E_INVALID, "copy_bytes: null pointer");
 	ANNCUR_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, ANNCUR_E_INVALID, "copy_bytes: pointers must be 16-byte aligned");
-	if (nbytes == 0) return ANNCUR_OK;
 	const size_t n16 = nbytes / 16;
 	const int n_tail = (int)(nbytes % 16);
 	const size_t blocks = (n16 + 255) / 256;

@@ -49,7 +49,12 @@ def _pinv(M, device, backend):
 
 
 def _is_full_range(idx, n):
-	return len(idx) == n and n > 0 and int(idx[0]) == 0 and int(idx[-1]) == n - 1
+	"""idx is exactly 0..n-1 in order (a permutation or a list with repeats is NOT the identity: the reference's
+	latent_rows[row_idxs, :] honours order and duplicates)."""
+	if torch.is_tensor(idx):
+		idx = idx.detach().cpu().numpy()
+	a = np.asarray(idx)
+	return a.ndim == 1 and a.shape[0] == n and n > 0 and bool(np.array_equal(a, np.arange(n)))
 
 
 class CURApprox(object):
@@ -66,35 +71,53 @@ class CURApprox(object):
 		self.m = rows.shape[1]
 		self.row_idxs = row_idxs
 		self.col_idxs = col_idxs
-		self.C = self._to_dev(cols)  # n x kc
-		self.R = self._to_dev(rows)  # kr x m
+		# device-resident operands (underscore names); the reference's attribute names C / R / U / latent_rows / latent_cols are
+		# properties that hand out tensors on the device the caller's matrices live on (CPU in -> CPU attributes)
+		self._C = self._to_dev(cols)  # n x kc
+		self._R = self._to_dev(rows)  # kr x m
+		self._home_cache = {}
 		self.approx_preference = approx_preference
 		if compute_dtype is None:
-			compute_dtype = "bf16" if self.R.dtype == torch.bfloat16 else "fp32"
+			compute_dtype = "bf16" if self._R.dtype == torch.bfloat16 else "fp32"
 		if compute_dtype not in ("fp32", "bf16"):
 			raise ValueError(f"compute_dtype = {compute_dtype} not supported")
 		self.compute_dtype = compute_dtype
 
 		assert _is_sorted(self.row_idxs), "row_idxs should be sorted"
 		assert _is_sorted(self.col_idxs), "col_idxs should be sorted"
-		assert len(row_idxs) == self.R.shape[0]
-		assert len(col_idxs) == self.C.shape[1]
+		assert len(row_idxs) == self._R.shape[0]
+		assert len(col_idxs) == self._C.shape[1]
 
-		intersect_mat = ops.gather_rows(self.C, row_idxs)  # kr x kc
-		assert torch.equal(intersect_mat, ops.gather_cols(self.R, col_idxs)), \
+		intersect_mat = ops.gather_rows(self._C, row_idxs)  # kr x kc
+		assert torch.equal(intersect_mat, ops.gather_cols(self._R, col_idxs)), \
 			"Invalid rows and cols as their intersection does not match"
 
 		if A is not None:  # oracle U = C^+ A R^+  (:46-47), products left to right on the GPU
 			A_dev = self._to_dev(A)
-			CpA = ops.gemm(_pinv(self.C, self.device, pinv_backend), A_dev)       # kc x m
-			self.U = ops.gemm(CpA, _pinv(self.R, self.device, pinv_backend))     # kc x kr
+			CpA = ops.gemm(_pinv(self._C, self.device, pinv_backend), A_dev)       # kc x m
+			self._U = ops.gemm(CpA, _pinv(self._R, self.device, pinv_backend))     # kc x kr
 		else:
-			self.U = _pinv(intersect_mat, self.device, pinv_backend)             # kc x kr  (:49)
+			self._U = _pinv(intersect_mat, self.device, pinv_backend)             # kc x kr  (:49)
 
 		self._Et = None   # [m x kc] fp32: latent_cols transposed ("rows" preference)
 		self._Etp = None  # bf16 packed copy for the fused kernel
 		self._Etp_sorted = self._item_ids = None
-		self.latent_rows, self.latent_cols = self._build_latent_row_cols(self.C, self.U, self.R, self.approx_preference)
+		self._latent_rows, self._latent_cols = self._build_latent_row_cols(self._C, self._U, self._R, self.approx_preference)
+
+	# ------------------------------------------------------------------ the reference's attributes (matrix_approx_zeshel.py:36-51)
+	def _attr(self, name):
+		t = getattr(self, "_" + name)
+		if t.device == self._home:
+			return t
+		if name not in self._home_cache:
+			self._home_cache[name] = t.to(self._home)
+		return self._home_cache[name]
+
+	C = property(lambda self: self._attr("C"))
+	R = property(lambda self: self._attr("R"))
+	U = property(lambda self: self._attr("U"))
+	latent_rows = property(lambda self: self._attr("latent_rows"))
+	latent_cols = property(lambda self: self._attr("latent_cols"))
 
 	# ------------------------------------------------------------------ helpers
 	def _to_dev(self, t):
@@ -142,33 +165,33 @@ class CURApprox(object):
 
 	# ------------------------------------------------------------------ reconstruction (a6)
 	def get_rows(self, row_idxs):
-		ans = ops.gemm(self._take_rows(self.latent_rows, row_idxs), self.latent_cols)
+		ans = ops.gemm(self._take_rows(self._latent_rows, row_idxs), self._latent_cols)
 		return self._back(ans, self._home)
 
 	def get_cols(self, col_idxs):
-		ans = ops.gemm(self.latent_rows, self._take_cols(self.latent_cols, col_idxs))
+		ans = ops.gemm(self._latent_rows, self._take_cols(self._latent_cols, col_idxs))
 		return self._back(ans, self._home)
 
 	def get(self, row_idxs, col_idxs):
-		ans = ops.gemm(self._take_rows(self.latent_rows, row_idxs), self._take_cols(self.latent_cols, col_idxs))
+		ans = ops.gemm(self._take_rows(self._latent_rows, row_idxs), self._take_cols(self._latent_cols, col_idxs))
 		return self._back(ans, self._home)
 
 	def get_complete_col(self, sparse_cols):
 		if self.approx_preference != "cols":
 			raise NotImplementedError("This is not designed to give good approx of cols as U matrix is multiplied w/ R matrix. Build index w/ approx_preference = cols instead.")
-		return self._back(ops.gemm(self.latent_rows, self._to_dev(sparse_cols)), sparse_cols)
+		return self._back(ops.gemm(self._latent_rows, self._to_dev(sparse_cols)), sparse_cols)
 
 	def topk_in_col(self, sparse_cols, k):
 		if self.approx_preference != "cols":
 			raise NotImplementedError("This is not designed to give good approx of cols as U matrix is multiplied w/ R matrix. Build index w/ approx_preference = cols instead.")
-		dense = ops.gemm(self.latent_rows, self._to_dev(sparse_cols))
+		dense = ops.gemm(self._latent_rows, self._to_dev(sparse_cols))
 		v, i = ops.rowwise_topk(dense, k)
 		return TopK(self._back(v, sparse_cols), self._back(i.long(), sparse_cols))
 
 	def get_complete_row(self, sparse_rows):
 		if self.approx_preference != "rows":
 			raise NotImplementedError("This is not designed to give good approx of rows as C and U matrix are multiplied together. Build index w/ approx_preference = rows instead.")
-		return self._back(ops.gemm(self._to_dev(sparse_rows), self.latent_cols), sparse_rows)
+		return self._back(ops.gemm(self._to_dev(sparse_rows), self._latent_cols), sparse_rows)
 
 	# ------------------------------------------------------------------ retrieval (a6 + a7)
 	def topk_in_row_device(self, sparse_rows, k):

@@ -98,9 +98,20 @@ def allgather_anchor_rows(A_train_local, Kq, rank, world, group=None):
 
 
 def gather_rows_to_rank0(local, n_rows, group=None):
-	"""Ordered concatenation of per-rank [n_local x c] results on rank 0 (None elsewhere)."""
+	"""Ordered concatenation of per-rank [n_local x c] results on rank 0 (None elsewhere): ONE gather (padded to the largest
+	block), nothing is delivered to the ranks that would throw it away."""
 	world = dist.get_world_size(group)
 	rank = dist.get_rank(group)
 	counts = [shard_bounds(n_rows, r, world)[1] - shard_bounds(n_rows, r, world)[0] for r in range(world)]
-	full = allgather_rows(local, counts, group)
-	return full if rank == 0 else None
+	cmax, c = max(counts), local.shape[1]
+	send = local.new_zeros((cmax, c))
+	send[:counts[rank]] = local
+	staged = local.is_cuda and dist.get_backend(group) == "gloo"   # (see allgather_rows)
+	if staged:
+		send = send.cpu()
+	recv = [send.new_empty((cmax, c)) for _ in range(world)] if rank == 0 else None
+	dist.gather(send, recv, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+	if rank != 0:
+		return None
+	full = torch.cat([recv[r][:counts[r]] for r in range(world)], dim=0)
+	return full.to(local.device) if staged else full

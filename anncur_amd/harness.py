@@ -227,6 +227,14 @@ def run_eval_method_cur(A_test_dev, A_train_dev, seed, grids, compute_dtype=None
 		anc = _select(rng, n_ent, n_anc)
 		if progress:
 			progress(j, len(anc_vals))
+		if n_anc == 0:
+			# the reference's own grid holds n_ent_anchors = int(1 * 0.1) = 0 (splits.py:241,250): C is [n x 0], U = pinv of an
+			# empty block, S_hat = 0 everywhere.  Every item ties; under this build's tie order (score desc, index asc) the
+			# retrieved list is 0..k_retvr-1 for every query (torch.topk leaves the order of an all-equal row unspecified).
+			approx_idx = torch.arange(kr_max, dtype=torch.int32, device=A_test_dev.device).expand(A_test_dev.shape[0], kr_max).contiguous()
+			for (k, kr), metrics in _sweep_cells(A_test_dev, approx_idx, exact, top_k_vals, retr_vals, n_ent).items():
+				res[f"top_k={k}"][f"k_retvr={kr}"][f"anc_n_m={n_train if key_n_m is None else key_n_m}_anc_n_e={n_anc}"] = metrics
+			continue
 		cur = CURApprox(rows=A_train_dev, cols=ops.gather_cols(A_train_dev, anc), row_idxs=np.arange(n_train), col_idxs=anc,
 						approx_preference="rows", compute_dtype=compute_dtype, pinv_backend=pinv_backend)
 		approx = cur.topk_in_row_device(ops.gather_cols(A_test_dev, anc), kr_max)

@@ -5,6 +5,8 @@ Every function takes CUDA(HIP) tensors and raises on CPU tensors: there is no CP
 """
 from collections import namedtuple
 import ctypes
+import functools
+import itertools
 
 import numpy as np
 import torch
@@ -34,6 +36,27 @@ def _stream():
 	return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_device(fn):
+	"""Run the op with its tensors' GPU as the current device: the launch stream (_stream()), the library's per-device caches
+	(dynamic-LDS attribute, CU count) and torch's own allocations / fills inside the op then all belong to the device that holds
+	the operands, whatever the process' current device is (CURApprox(device=...), --device cuda:N).  Operands on two different
+	GPUs are an error."""
+	@functools.wraps(fn)
+	def wrapped(*args, **kwargs):
+		dev = None
+		for a in itertools.chain(args, kwargs.values()):
+			if torch.is_tensor(a) and a.is_cuda:
+				if dev is None:
+					dev = a.device
+				elif a.device != dev:
+					raise _lib.AnncurHipError(f"{fn.__name__}: operands live on different devices ({dev} and {a.device})")
+		if dev is None or dev.index == torch.cuda.current_device():
+			return fn(*args, **kwargs)
+		with torch.cuda.device(dev):
+			return fn(*args, **kwargs)
+	return wrapped
+
+
 def _p(t):
 	return ctypes.c_void_p(t.data_ptr())
 
@@ -53,30 +76,43 @@ def _ld(t):
 	return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
-def as_index(idx, device):
-	"""Python list / numpy / tensor of indices -> int32 device tensor."""
-	if torch.is_tensor(idx):
+def as_index(idx, device, n=None):
+	"""Python list / numpy / tensor of indices -> int32 device tensor.  With `n` (the size of the indexed dimension) host-side
+	indices get torch's indexing semantics: negative values wrap, anything outside [-n, n) raises IndexError (the kernels' own
+	clamp -- zeros for a bad index -- is only a safety net).  Indices that already live on the GPU are taken as they are: checking
+	them would cost a device synchronisation."""
+	if torch.is_tensor(idx) and idx.is_cuda:
 		return idx.to(device=device, dtype=torch.int32).contiguous()
-	return torch.as_tensor(np.asarray(idx, dtype=np.int64), dtype=torch.int32).to(device)
+	a = idx.detach().numpy() if torch.is_tensor(idx) else np.asarray(idx)
+	a = a.astype(np.int64, copy=False).reshape(-1)
+	if n is not None and a.size:
+		lo, hi = int(a.min()), int(a.max())
+		if lo < -n or hi >= n:
+			raise IndexError(f"index {lo if lo < -n else hi} is out of bounds for dimension with size {n}")
+		if lo < 0:
+			a = np.where(a < 0, a + n, a)
+	return torch.as_tensor(a, dtype=torch.int32).to(device)
 
 
 # ------------------------------------------------------------------ a2
+@_on_device
 def gather_cols(A, col_idx, out_dtype=None):
 	"""A[:, col_idx]  (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:74)."""
 	_dev(A)
 	A = _rowmajor(A)
-	idx = as_index(col_idx, A.device)
+	idx = as_index(col_idx, A.device, A.shape[1])
 	out = torch.empty((A.shape[0], idx.numel()), dtype=out_dtype or A.dtype, device=A.device)
 	check(_lib.load().anncur_gather_cols(_p(A), _dt(A), A.shape[0], A.shape[1], _ld(A), _p(idx), idx.numel(), _p(out), _dt(out),
 										 max(idx.numel(), 1), _stream()), "gather_cols")
 	return out
 
 
+@_on_device
 def gather_rows(A, row_idx, out_dtype=None):
 	"""A[row_idx, :]  (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:73)."""
 	_dev(A)
 	A = _rowmajor(A)
-	idx = as_index(row_idx, A.device)
+	idx = as_index(row_idx, A.device, A.shape[0])
 	out = torch.empty((idx.numel(), A.shape[1]), dtype=out_dtype or A.dtype, device=A.device)
 	n = idx.numel()
 	for s in range(0, n, 65535):  # grid.y limit
@@ -86,6 +122,7 @@ def gather_rows(A, row_idx, out_dtype=None):
 	return out
 
 
+@_on_device
 def convert(src, dtype):
 	_dev(src)
 	src = _rowmajor(src)
@@ -96,6 +133,7 @@ def convert(src, dtype):
 
 
 # ------------------------------------------------------------------ a4/a5/a6
+@_on_device
 def gemm(A, B, out=None, out_dtype=torch.float32, alpha=1.0, beta=0.0, cin=None):
 	"""C = alpha * A @ B (+ beta * cin) for 2-D tensors with ARBITRARY strides (transposed views cost nothing);
 	fp32 products and sums (exact fmaf chains on the matrix cores).  cin: fp32 [M, N], may be `out` itself."""
@@ -126,6 +164,7 @@ def gemm(A, B, out=None, out_dtype=torch.float32, alpha=1.0, beta=0.0, cin=None)
 	return out
 
 
+@_on_device
 def sumsq(A, out=None):
 	"""Frobenius norm squared of an fp32 matrix -> 1-element device tensor (no host sync)."""
 	_dev(A)
@@ -137,6 +176,7 @@ def sumsq(A, out=None):
 	return out
 
 
+@_on_device
 def scale_copy(src, dst, alpha=1.0, divide_by=None):
 	"""dst[i, j] = alpha / divide_by[0] * src[i, j] for fp32 2-D tensors with arbitrary strides (e.g. a scaled transpose)."""
 	_dev(src, dst)
@@ -147,6 +187,7 @@ def scale_copy(src, dst, alpha=1.0, divide_by=None):
 	return dst
 
 
+@_on_device
 def approx_error(X, Et, A_exact):
 	"""Per-row sum_i (X.E - A)^2 and sum_i A^2 without materialising X.E
 	(reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:146-147)."""
@@ -173,6 +214,7 @@ def approx_error_packed_ok(Kp, A_exact):
 			and _ld(A_exact) >= A_exact.shape[1] and A_exact.data_ptr() % 16 == 0)
 
 
+@_on_device
 def approx_error_packed(Xp, Etp, A_exact, n_items):
 	"""a11 on the fused path's operands: Xp [Q x Kp] packed bf16, Etp [ceil32(I) x Kp] packed bf16, A_exact [Q x I] fp32 / bf16."""
 	_dev(Xp, Etp, A_exact)
@@ -189,6 +231,7 @@ def approx_error_packed(Xp, Etp, A_exact, n_items):
 
 
 # ------------------------------------------------------------------ a7/a8
+@_on_device
 def rowwise_topk(A, k):
 	"""Exact torch.topk(A, k, dim=1) on the device: (values f32 [Q,k], indices int32 [Q,k]),
 	sorted descending, ties -> smaller index."""
@@ -211,6 +254,7 @@ def padded_k(K):
 	return None
 
 
+@_on_device
 def pack_bf16(M, Kp, row_multiple=1):
 	"""[n x K] (f32/bf16) -> zero-padded bf16 [ceil(n/row_multiple)*row_multiple x Kp], packed."""
 	_dev(M)
@@ -263,6 +307,7 @@ def _item_ids_arg(item_ids, I, device):
 	return item_ids
 
 
+@_on_device
 def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None):
 	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16).
 	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time).
@@ -306,6 +351,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 	return TopK(val, idx)
 
 
+@_on_device
 def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None):
 	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches]) in ms,
 	from HIP events on the launch stream."""
@@ -342,6 +388,7 @@ def _dense_scores(X, Et):
 	return gemm(X, Et.t())
 
 
+@_on_device
 def score_topk_dense(X, Et, k, max_bytes=2 << 30):
 	"""Unfused route: S = X @ Et^T in fp32 (row chunks), then the exact scan.  Any K, any dtype."""
 	_dev(X, Et)
@@ -357,6 +404,7 @@ def score_topk_dense(X, Et, k, max_bytes=2 << 30):
 	return TopK(val, idx)
 
 
+@_on_device
 def rerank(A, approx_idx, k_retvr, k_out):
 	"""The k_out best of approx_idx[:, :k_retvr] by exact score A (reference: ..._splits.py:93-96)."""
 	_dev(A, approx_idx)
@@ -371,6 +419,7 @@ def rerank(A, approx_idx, k_retvr, k_out):
 	return TopK(val, idx)
 
 
+@_on_device
 def overlap_counts(a, b, pairs):
 	"""common[p, q] = |set(a[q, :ka_p]) & set(b[q, :kb_p])| for pairs = [(ka, kb), ...] -> int32 [n_pairs, Q]."""
 	_dev(a, b)
@@ -388,6 +437,7 @@ def overlap_counts(a, b, pairs):
 	return out
 
 
+@_on_device
 def copy_to_mapped_host(src, pinned_host):
 	"""Device kernel copy of `src` (CUDA tensor) into a PINNED host tensor (mapped into the device address space by the HIP
 	runtime): graph-capturable, no copy engine.  The caller synchronises (event) before reading `pinned_host`."""

@@ -106,6 +106,8 @@ def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overri
 			if eval_res is None:          # ranks > 0 are done
 				return res_dir
 		else:
+			if torch.device(device).type == "cuda":
+				torch.cuda.set_device(device)   # the launch stream and torch's allocations follow --device
 			A_dev = chunked["A_local"] if chunked is not None else harness.to_device_matrix(scores, device, dtype)
 			eval_res = harness.run_entry_A(A_dev, grids, n_seeds, progress, pinv_backend)
 		eval_res["other_args"] = other_args

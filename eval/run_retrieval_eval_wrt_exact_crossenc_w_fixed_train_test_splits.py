@@ -83,6 +83,8 @@ def run_eval_method(curr_method, test_data_file, train_data_file, args, seed, de
 
 def run(args, device):
 	eval_method, n_seeds = args.eval_method, args.n_seeds
+	if device.type == "cuda":
+		torch.cuda.set_device(device)   # the launch stream and torch's allocations follow --device
 	assert eval_method == "cur" or n_seeds == 1, f"n_seed = {n_seeds} only allowed for eval_method = cur "
 	if args.use_wandb:
 		LOGGER.info("--use_wandb: wandb logging is optional and not configured in this build; continuing without it")

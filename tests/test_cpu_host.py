@@ -211,3 +211,23 @@ def test_chunk_ingestion_names_shards_and_schema(tmp_path):
 		ingest.load_score_chunks(bad, "cpu", "fp32", upload=up)
 	with pytest.raises(ValueError, match="empty"):
 		ingest.load_score_chunks([], "cpu")
+
+
+# ------------------------------------------------------------------ index handling (torch indexing semantics on the host side)
+def test_as_index_wraps_negatives_and_rejects_out_of_range():
+	from anncur_amd import ops
+	cpu = torch.device("cpu")
+	assert ops.as_index([0, 2, -1], cpu, n=5).tolist() == [0, 2, 4]          # negative indices wrap like torch indexing
+	assert ops.as_index(np.array([3, 1]), cpu, n=4).dtype == torch.int32
+	assert ops.as_index([], cpu, n=4).numel() == 0
+	for bad in ([0, 5], [-6], [2 ** 31]):
+		with pytest.raises(IndexError):
+			ops.as_index(bad, cpu, n=5)
+
+
+def test_full_range_shortcut_is_the_identity_only():
+	from anncur_amd.cur import _is_full_range
+	assert _is_full_range([0, 1, 2, 3], 4) and _is_full_range(np.arange(7), 7) and _is_full_range(torch.arange(3), 3)
+	assert not _is_full_range([0, 2, 1, 3], 4)      # a permutation with the right ends
+	assert not _is_full_range([0, 1, 1, 3], 4)      # a repeat with the right ends
+	assert not _is_full_range([0, 1, 2], 4) and not _is_full_range([], 0)

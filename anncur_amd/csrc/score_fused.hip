@@ -807,6 +807,12 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 	wsel_finish(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
 
+}  // namespace
+namespace {
+#include "score_wide.hpp"
+}
+namespace {
+
 // ------------------------------------------------------------------ host-side plan
 struct FusedPlan {
 	bool ok;
@@ -820,6 +826,59 @@ int num_cu() { return anncur_num_cu(); }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// Sweep stages: between stages the threshold is raised to the k-th best candidate seen so far, which cuts the survivors of the
+// remaining tiles from H0 to ~1.2 k / (fraction seen).  Any split is exact; the split is picked by a small cost model with
+// constants measured on MI355X (cfg2, round 1): ~2.4e-11 s of chip time per survivor, ~25 us + 3 ns per query per extra stage
+// (threshold kernel + launch ramp) with the wave-level refinement kernel (k <= 128, <= 64 segments), ~1.4e-11 s per candidate
+// read with the workgroup-level one.  `unit_items` = items per tile unit of P.n_tiles (32, or 256 for the wide kernel).
+void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, double fmin, int unit_items) {
+	double frac[3] = {1.0, 1.0, 1.0};
+	P.n_stages = 1;
+	if (staged) {
+		const double H0 = exp_hits, c_hit = 2.4e-11 * (double)Q;
+		const double c_stage = k <= WSEL_K ? 25e-6 + 3e-9 * (double)Q : 25e-6 + 1.4e-11 * (double)Q * 0.3 * H0;
+		auto later = [&](double f) { const double h = 1.2 * k / f; return h < H0 ? h : H0; };
+		double best = H0 * c_hit;
+		static const double grid[] = {0.02, 0.03, 0.04, 0.06, 0.08, 0.10, 0.12, 0.15, 0.18, 0.22, 0.26, 0.30, 0.35, 0.40, 0.50};
+		const int ng = (int)(sizeof(grid) / sizeof(grid[0]));
+		for (int i = 0; i < ng; ++i) {
+			const double f1 = grid[i];
+			if (f1 < fmin) continue;
+			const double c2 = (f1 * H0 + (1 - f1) * later(f1)) * c_hit + c_stage;
+			if (c2 < best) { best = c2; P.n_stages = 2; frac[0] = f1; frac[1] = 1.0; }
+			for (int j = i + 1; j < ng; ++j) {
+				const double f2 = grid[j];
+				if (f2 - f1 < fmin) continue;
+				const double c3 = (f1 * H0 + (f2 - f1) * later(f1) + (1 - f2) * later(f2)) * c_hit + 2 * c_stage;
+				if (c3 < best) { best = c3; P.n_stages = 3; frac[0] = f1; frac[1] = f2; }
+			}
+		}
+	}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_STAGES")) {  // tuning knob "f1,f2" or "f1" (>= 1: single stage)
+		double f1 = 0, f2 = 0;
+		const int n = sscanf(dbg, "%lf,%lf", &f1, &f2);
+		if (staged && n == 2 && f1 > 0 && f2 > f1 && f2 < 1) { frac[0] = f1; frac[1] = f2; P.n_stages = 3; }
+		else if (staged && n == 1 && f1 > 0 && f1 < 1) { frac[0] = f1; frac[1] = 1.0; P.n_stages = 2; }
+		else if (n == 1 && f1 >= 1) P.n_stages = 1;
+	}
+#endif
+	double rate = exp_hits / ((double)P.n_tiles * 2.0);  // expected hits per (query half, tile) in the first stage
+	int prev = 0;
+	for (int i = 0; i < P.n_stages; ++i) {
+		int end = (int)(frac[i] * P.n_tiles + 0.5);
+		if (i == P.n_stages - 1 || end > P.n_tiles) end = P.n_tiles;
+		if (end <= prev) end = prev + 1 < P.n_tiles ? prev + 1 : P.n_tiles;
+		P.stage_end[i] = end;
+		P.stage_tps[i] = (end - prev + P.S - 1) / P.S;
+		int ft = (int)(0.5 / (rate > 1e-9 ? rate : 1e-9));
+		P.stage_flush[i] = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
+		// next stage: threshold = k-th best of the fraction seen so far
+		rate = (double)k / ((double)end * unit_items) * 16.0 * 1.2;
+		prev = end;
+	}
+}
 
 FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
 	FusedPlan P{};
@@ -866,60 +925,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
 	int ft = (int)(0.5 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-	// sweep stages: between stages the threshold is raised to the k-th best candidate seen so far (wave-level kernel), which cuts
-	// the survivors of the remaining tiles from H0 to ~1.2 k / (fraction seen).  Any split is exact; the split is picked by a small
-	// cost model with constants measured on MI355X (cfg2, round 1): ~2.4e-11 s of chip time per survivor, ~25 us + 3 ns per query
-	// per extra stage (threshold kernel + launch ramp).  Needs the wave-level selector (k <= 128, <= 64 segments).
-	{
-		double frac[3] = {1.0, 1.0, 1.0};
-		// k <= 128: wave-level refinement kernel (<= 64 segments); larger k: workgroup-level one (dearer: ~1.4e-11 s per candidate read)
-		const bool staged = (k <= WSEL_K ? 2 * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S;
-		P.n_stages = 1;
-		if (staged) {
-			const double H0 = exp_hits, c_hit = 2.4e-11 * (double)Q;
-			const double c_stage = k <= WSEL_K ? 25e-6 + 3e-9 * (double)Q : 25e-6 + 1.4e-11 * (double)Q * 0.3 * H0;
-			auto later = [&](double f) { const double h = 1.2 * k / f; return h < H0 ? h : H0; };
-			double best = H0 * c_hit;
-			static const double grid[] = {0.02, 0.03, 0.04, 0.06, 0.08, 0.10, 0.12, 0.15, 0.18, 0.22, 0.26, 0.30, 0.35, 0.40, 0.50};
-			const int ng = (int)(sizeof(grid) / sizeof(grid[0]));
-			const double fmin = 4.0 * P.S / P.n_tiles;  // at least four tiles per split and stage
-			for (int i = 0; i < ng; ++i) {
-				const double f1 = grid[i];
-				if (f1 < fmin) continue;
-				const double c2 = (f1 * H0 + (1 - f1) * later(f1)) * c_hit + c_stage;
-				if (c2 < best) { best = c2; P.n_stages = 2; frac[0] = f1; frac[1] = 1.0; }
-				for (int j = i + 1; j < ng; ++j) {
-					const double f2 = grid[j];
-					if (f2 - f1 < fmin) continue;
-					const double c3 = (f1 * H0 + (f2 - f1) * later(f1) + (1 - f2) * later(f2)) * c_hit + 2 * c_stage;
-					if (c3 < best) { best = c3; P.n_stages = 3; frac[0] = f1; frac[1] = f2; }
-				}
-			}
-		}
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-		if (const char *dbg = getenv("ANNCUR_DEBUG_STAGES")) {  // tuning knob "f1,f2" or "f1" (>= 1: single stage)
-			double f1 = 0, f2 = 0;
-			const int n = sscanf(dbg, "%lf,%lf", &f1, &f2);
-			if (staged && n == 2 && f1 > 0 && f2 > f1 && f2 < 1) { frac[0] = f1; frac[1] = f2; P.n_stages = 3; }
-			else if (staged && n == 1 && f1 > 0 && f1 < 1) { frac[0] = f1; frac[1] = 1.0; P.n_stages = 2; }
-			else if (n == 1 && f1 >= 1) P.n_stages = 1;
-		}
-#endif
-		double rate = exp_hits / ((double)P.n_tiles * 2.0);  // expected hits per (query half, tile) in the first stage
-		int prev = 0;
-		for (int i = 0; i < P.n_stages; ++i) {
-			int end = (int)(frac[i] * P.n_tiles + 0.5);
-			if (i == P.n_stages - 1 || end > P.n_tiles) end = P.n_tiles;
-			if (end <= prev) end = prev + 1 < P.n_tiles ? prev + 1 : P.n_tiles;
-			P.stage_end[i] = end;
-			P.stage_tps[i] = (end - prev + P.S - 1) / P.S;
-			int ft = (int)(0.5 / (rate > 1e-9 ? rate : 1e-9));
-			P.stage_flush[i] = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-			// next stage: threshold = k-th best of the fraction seen so far
-			rate = (double)k / ((double)end * TILE_I) * 16.0 * 1.2;
-			prev = end;
-		}
-	}
+	plan_stages(P, Q, k, exp_hits, (k <= WSEL_K ? 2 * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
@@ -934,20 +940,88 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 	return P;
 }
 
+#define EV(i) do { if (ev) ANNCUR_HIP_OK(hipEventRecord(ev[i], st)); } while (0)
+
+// Threshold refinement between two sweep stages: tau[q] = max(tau[q], k-th best candidate collected so far).
+int launch_tau_refine(const uint2 *cand, const uint32_t *seg_cnt, int nseg, int capg, int64_t Q, int k, int kmax, float *tau, int tau_stride,
+					  int prefilter, hipStream_t st) {
+	int rc;
+	if (k <= WSEL_K && nseg <= WAVE) {
+		if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<true>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
+		hipLaunchKernelGGL((select_wave_kernel<true>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, cand,
+						   seg_cnt, nseg, capg, Q, (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
+						   (int32_t *)nullptr, tau, tau_stride, prefilter);
+	} else {
+#define LAUNCH_TAU(KM)                                                                                                        \
+		do {                                                                                                                  \
+			if ((rc = anncur_ensure_dyn_lds((const void *)tau_block_kernel<KM>, (int)SelCfg<KM>::LDS_BYTES)) != ANNCUR_OK) return rc; \
+			hipLaunchKernelGGL((tau_block_kernel<KM>), dim3((unsigned)Q), dim3(SEL_THREADS), SelCfg<KM>::LDS_BYTES, st, cand, seg_cnt, \
+							   nseg, capg, (uint32_t)k, tau, tau_stride, prefilter);                                           \
+		} while (0)
+		if (kmax == 128) LAUNCH_TAU(128); else if (kmax == 512) LAUNCH_TAU(512); else LAUNCH_TAU(2048);
+#undef LAUNCH_TAU
+	}
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+// Per-query exact top-k of the collected candidates.  Fast path: one wave per query (k <= 128, <= 64 segments); what it cannot
+// take (overflowed segment, fewer than k candidates) lands in hard_list for the workgroup-level kernel, which repairs it exactly.
+int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const uint2 *cand, const uint32_t *seg_cnt, const uint16_t *X, int64_t ldx,
+				  const uint16_t *Et, int64_t Q, int64_t I, int KP, int k, float *out_val, int32_t *out_idx, unsigned char *ws, const float *tau,
+				  int tau_stride, hipStream_t st) {
+	int rc;
+#define LAUNCH_SELECT(KM)                                                                                              \
+	do {                                                                                                               \
+		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)KP * 4 + 32;                                                \
+		if ((rc = anncur_ensure_dyn_lds((const void *)select_candidates_kernel<KM>, (int)lds)) != ANNCUR_OK) return rc; \
+		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, cand, seg_cnt, nseg, \
+						   P.S, stages, P.capg, X, ldx, Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt,      \
+						   P.n_stages > 1 ? tau : (const float *)nullptr, tau_stride);                                                   \
+	} while (0)
+	const int32_t *hard_list = nullptr;
+	const uint32_t *hard_cnt = nullptr;
+	unsigned sel_grid = (unsigned)Q;
+	if (k <= WSEL_K && nseg <= WAVE) {
+		int32_t *hl = (int32_t *)(ws + P.off_hard);
+		uint32_t *hc = (uint32_t *)(ws + 4);
+		if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<false>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
+		hipLaunchKernelGGL((select_wave_kernel<false>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, cand,
+						   seg_cnt, nseg, P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride,
+						   P.n_stages > 1 ? 1 : 0);
+		ANNCUR_LAUNCH_OK();
+		hard_list = hl; hard_cnt = hc;
+		sel_grid = (unsigned)(Q < 1024 ? Q : 1024);
+	}
+	if (P.kmax == 128) LAUNCH_SELECT(128); else if (P.kmax == 512) LAUNCH_SELECT(512); else LAUNCH_SELECT(2048);
+#undef LAUNCH_SELECT
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+// tau = k-th largest group maximum of the prepass (a valid lower bound on the query's k-th best score)
+int launch_threshold(const FusedPlan &P, const float *gmax, int64_t Q, int k, unsigned char *ws, const float *&tau, int &tau_stride, hipStream_t st) {
+	if (P.n_groups <= 2048) {  // one wave per query, keys in registers
+		float *t = (float *)(ws + P.off_tau);
+		const int rc = anncur_internal_kth_value(gmax, Q, P.n_groups, P.n_groups, k, t, 1, st);
+		tau = t; tau_stride = 1;
+		return rc;
+	}
+	float *tval = (float *)(ws + P.off_tval);
+	tau = tval + (k - 1); tau_stride = k;
+	return anncur_rowwise_topk(gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, (int32_t *)(ws + P.off_tidx), st);
+}
+
 template <int KP>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
 				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev) {
 	using Cfg = FusedCfg<KP>;
-#define EV(i) do { if (ev) ANNCUR_HIP_OK(hipEventRecord(ev[i], st)); } while (0)
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
 	p.n_tiles = P.n_tiles; p.n_full_tiles = P.n_full; p.S = P.S; p.tiles_per_split = P.tiles_per_split;
 	p.tile_begin = 0; p.tile_end = P.n_tiles; p.carry = 0;
 	p.n_st = P.n_st; p.S0 = P.S0; p.st_per_split = P.st_per_split; p.sample_leading = P.leading;
 	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
-	float *tval = (float *)(ws + P.off_tval);
-	int32_t *tidx = (int32_t *)(ws + P.off_tidx);
-	p.tau = tval + (k - 1); p.tau_stride = k;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	p.tau_bias = 0.f;
 #ifdef ANNCUR_TIMING_EXPERIMENTS  // (the -DANNCUR_TIMING_EXPERIMENTS build of scripts/fused_microbench.py only: results become wrong)
@@ -966,21 +1040,12 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	ANNCUR_LAUNCH_OK();
 	EV(1);
 	// 2. tau = k-th largest group maximum
-	int rc;
-	if (P.n_groups <= 2048) {  // one wave per query, keys in registers
-		float *tau = (float *)(ws + P.off_tau);
-		rc = anncur_internal_kth_value(p.gmax, Q, P.n_groups, P.n_groups, k, tau, 1, st);
-		p.tau = tau; p.tau_stride = 1;
-	} else {
-		rc = anncur_rowwise_topk(p.gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, tidx, st);
-	}
+	int rc = launch_threshold(P, p.gmax, Q, k, ws, p.tau, p.tau_stride, st);
 	if (rc != ANNCUR_OK) return rc;
 	EV(2);
 	// 3. sweep, in stages; between stages the thresholds are raised from the candidates collected so far
 	p.n_wg = P.n_rb * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
-	if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<true>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
-	if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<false>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
 		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
@@ -998,68 +1063,147 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
-		if (stg + 1 < P.n_stages && k <= WSEL_K) {
-			hipLaunchKernelGGL((select_wave_kernel<true>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
-							   p.seg_cnt, 2 * P.S, P.capg, Q, (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
-							   (int32_t *)nullptr, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0);
-			ANNCUR_LAUNCH_OK();
-		} else if (stg + 1 < P.n_stages) {
-#define LAUNCH_TAU(KM)                                                                                                        \
-			do {                                                                                                              \
-				if ((rc = anncur_ensure_dyn_lds((const void *)tau_block_kernel<KM>, (int)SelCfg<KM>::LDS_BYTES)) != ANNCUR_OK) return rc; \
-				hipLaunchKernelGGL((tau_block_kernel<KM>), dim3((unsigned)Q), dim3(SEL_THREADS), SelCfg<KM>::LDS_BYTES, st, p.cand, p.seg_cnt, \
-								   2 * P.S, P.capg, (uint32_t)k, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0);  \
-			} while (0)
-			if (P.kmax == 512) LAUNCH_TAU(512); else LAUNCH_TAU(2048);
-#undef LAUNCH_TAU
-			ANNCUR_LAUNCH_OK();
-		}
+		if (stg + 1 < P.n_stages &&
+			(rc = launch_tau_refine(p.cand, p.seg_cnt, 2 * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
+			return rc;
 	}
 	EV(3);
 	// 4. select
-	const int nseg = 2 * P.S;
 	SweepStages stages{};
 	stages.n = P.n_stages;
 	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) { stages.begin[g] = prev; stages.end[g] = P.stage_end[g]; stages.tps[g] = P.stage_tps[g]; }
-#define LAUNCH_SELECT(KM)                                                                                              \
-	do {                                                                                                               \
-		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)KP * 4 + 32;                                                \
-		if ((rc = anncur_ensure_dyn_lds((const void *)select_candidates_kernel<KM>, (int)lds)) != ANNCUR_OK) return rc; \
-		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, p.cand, p.seg_cnt, nseg, \
-						   P.S, stages, P.capg, p.X, ldx, p.Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt,      \
-						   P.n_stages > 1 ? p.tau : (const float *)nullptr, p.tau_stride);                                                   \
-	} while (0)
-	// fast path: one wave per query; what it cannot take lands in hard_list for the workgroup-level kernel
-	const int32_t *hard_list = nullptr;
-	const uint32_t *hard_cnt = nullptr;
-	unsigned sel_grid = (unsigned)Q;
-	if (k <= 128 && nseg <= WAVE) {
-		int32_t *hl = (int32_t *)(ws + P.off_hard);
-		uint32_t *hc = (uint32_t *)(ws + 4);
-		hipLaunchKernelGGL((select_wave_kernel<false>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, p.cand,
-						   p.seg_cnt, nseg, P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(p.tau), p.tau_stride,
-						   P.n_stages > 1 ? 1 : 0);
-		ANNCUR_LAUNCH_OK();
-		hard_list = hl; hard_cnt = hc;
-		sel_grid = (unsigned)(Q < 1024 ? Q : 1024);
-	}
-	if (P.kmax == 128) LAUNCH_SELECT(128); else if (P.kmax == 512) LAUNCH_SELECT(512); else LAUNCH_SELECT(2048);
-#undef LAUNCH_SELECT
-	ANNCUR_LAUNCH_OK();
+	if ((rc = launch_select(P, 2 * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
 	EV(4);
-#undef EV
 	return ANNCUR_OK;
+}
+
+// ------------------------------------------------------------------ wide inner dimension (Kp > 512): score_wide.hpp
+constexpr int WIDE_KP_MAX = 4096;
+bool wide_kp(int KP) { return KP > 512 && KP <= WIDE_KP_MAX && (KP % 128) == 0; }
+
+// Same plan structure in units of 256-item block tiles (P.n_tiles, stage_end, tiles_per_split); candidate segments per query:
+// 4 S = lane half x wave item half x item split.
+FusedPlan plan_wide(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
+	FusedPlan P{};
+	P.ok = false;
+	P.leading = leading ? 1 : 0;
+	if (!wide_kp(KP)) return P;
+	if (k < 1 || k > ANNCUR_MAX_TOPK || Q < 1 || I < 1 || I >= (int64_t)0x7fffffff - 512 || k > I) return P;
+	P.QT = 2;
+	P.BQ = WBN;
+	P.n_rb = (int)ceil_div64(Q, WBN);
+	P.n_tiles = (int)ceil_div64(I, WBM);
+	P.n_full = (int)(I / WBM);
+	const int target = (4 * k > 512) ? 4 * k : 512;  // groups: enough that the k-th largest group maximum is a tight bound
+	const int n16 = (target + 15) / 16;               // 16 groups of 16 items per sampled block tile
+	if ((int64_t)n16 * 8 <= P.n_full) { P.group = 16; P.n_st = n16; }
+	else { P.group = 4; P.n_st = (target + 63) / 64; }
+	if ((int64_t)P.n_st * 2 > P.n_full) return P;     // problem too small for a sampled threshold: dense GEMM + scan
+	P.n_groups = P.n_st * (P.group == 16 ? 16 : 64);
+	if (P.n_groups < k) return P;
+	const int slots = num_cu();                        // one 512-thread workgroup (128 KiB of LDS) per CU
+	int S = slots / P.n_rb;
+	if (S < 1) S = 1;
+	if (S > 64) S = 64;
+	if (k <= WSEL_K && S > 16) S = 16;                 // 4 S <= 64 segments: wave-level refinement / select kernels
+	if (S > P.n_tiles) S = P.n_tiles;
+	P.tiles_per_split = (P.n_tiles + S - 1) / S;
+	P.S = (P.n_tiles + P.tiles_per_split - 1) / P.tiles_per_split;
+	int S0 = slots / P.n_rb;
+	if (S0 < 1) S0 = 1;
+	if (S0 > P.n_st) S0 = P.n_st;
+	P.st_per_split = (P.n_st + S0 - 1) / S0;
+	P.S0 = (P.n_st + P.st_per_split - 1) / P.st_per_split;
+	const double exp_hits_cap = 1.3 * k * ((double)P.n_tiles / P.n_st);
+	const double exp_hits = (leading ? 0.65 : 1.0) * exp_hits_cap;
+	const double per_seg = exp_hits_cap / (4.0 * P.S);
+	int capg = next_pow2((int)(4.0 * per_seg) + 32);
+	if (capg < 64) capg = 64;
+	if (capg > 16384) capg = 16384;
+	P.capg = capg;
+	P.flush_tiles = 1;
+	plan_stages(P, Q, k, exp_hits, (k <= WSEL_K ? 4 * P.S <= WAVE : true) && P.n_tiles >= 4 * P.S, 1.0 * P.S / P.n_tiles, WBM);
+	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
+	size_t off = 256;
+	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
+	P.off_tval = off;   off = align256(off + (size_t)Q * k * 4);
+	P.off_tidx = off;   off = align256(off + (size_t)Q * k * 4);
+	P.off_segcnt = off; off = align256(off + (size_t)Q * 4 * P.S * 4);
+	P.off_tau = off;    off = align256(off + (size_t)Q * 4);
+	P.off_hard = off;   off = align256(off + (size_t)Q * 4);
+	P.off_cand = off;   off = align256(off + (size_t)Q * 4 * P.S * (size_t)P.capg * 8);
+	P.total = off;
+	P.ok = true;
+	return P;
+}
+
+int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int KP, int k, float *out_val,
+				int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev) {
+	WideParams p{};
+	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.et_rows = ceil_div64(I, TILE_I) * TILE_I; p.Q = Q; p.I = I; p.Kp = KP;
+	p.n_rb = P.n_rb; p.S = P.S;
+	p.n_st = P.n_st; p.S0 = P.S0; p.st_per_split = P.st_per_split; p.sample_leading = P.leading; p.n_bt_full = P.n_full;
+	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
+	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg;
+	int rc;
+	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
+	EV(0);
+	// 1. prepass over the sampled block tiles
+	p.n_wg = P.n_rb * P.S0;
+	if (P.group == 16) {
+		if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<0, 16>, W_LDS_BYTES)) != ANNCUR_OK) return rc;
+		hipLaunchKernelGGL((wide_kernel<0, 16>), dim3(p.n_wg), dim3(512), W_LDS_BYTES, st, p);
+	} else {
+		if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<0, 4>, W_LDS_BYTES)) != ANNCUR_OK) return rc;
+		hipLaunchKernelGGL((wide_kernel<0, 4>), dim3(p.n_wg), dim3(512), W_LDS_BYTES, st, p);
+	}
+	ANNCUR_LAUNCH_OK();
+	EV(1);
+	// 2. threshold
+	if ((rc = launch_threshold(P, p.gmax, Q, k, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
+	EV(2);
+	// 3. sweep in stages
+	p.n_wg = P.n_rb * P.S;
+	if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<1, 16>, W_LDS_BYTES)) != ANNCUR_OK) return rc;
+	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
+		EV(5 + 2 * stg);
+		p.bt_begin = prev; p.bt_end = P.stage_end[stg]; p.bt_per_split = P.stage_tps[stg]; p.carry = stg > 0;
+		hipLaunchKernelGGL((wide_kernel<1, 16>), dim3(p.n_wg), dim3(512), W_LDS_BYTES, st, p);
+		ANNCUR_LAUNCH_OK();
+		EV(6 + 2 * stg);
+		if (stg + 1 < P.n_stages &&
+			(rc = launch_tau_refine(p.cand, p.seg_cnt, 4 * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
+			return rc;
+	}
+	EV(3);
+	// 4. select (stage ranges in 32-item tiles for the repair path)
+	SweepStages stages{};
+	stages.n = P.n_stages;
+	const int n_tiles32 = (int)ceil_div64(I, TILE_I), u = WBM / TILE_I;
+	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) {
+		stages.begin[g] = prev * u;
+		stages.end[g] = P.stage_end[g] * u < n_tiles32 ? P.stage_end[g] * u : n_tiles32;
+		stages.tps[g] = P.stage_tps[g] * u;
+	}
+	if ((rc = launch_select(P, 4 * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
+	EV(4);
+	return ANNCUR_OK;
+}
+#undef EV
+
+FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
+	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading);
 }
 
 }  // namespace
 
 extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
-	const FusedPlan P = plan_fused(Q, I, Kp, k);
+	const FusedPlan P = plan_any(Q, I, Kp, k);
 	return P.ok ? P.total : 0;
 }
 
 extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
-	return plan_fused(Q, I, Kp, k).ok ? 1 : 0;
+	return plan_any(Q, I, Kp, k).ok ? 1 : 0;
 }
 
 // out_idx[i] = item_ids[out_idx[i]] (rows of Et -> the caller's item ids; -1 stays -1)
@@ -1075,11 +1219,11 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr) {
 	ANNCUR_REQUIRE((flags & ~ANNCUR_TOPK_LEADING_SAMPLE) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
-	const FusedPlan P = plan_fused(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0);
+	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
-				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512}, 1<=k<=%d, I large "
-				   "enough for a sampled threshold); use anncur_gemm + anncur_rowwise_topk",
-				   (long long)Q, (long long)I, Kp, k, ANNCUR_MAX_TOPK);
+				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512} or a multiple of 128 up to %d, "
+				   "1<=k<=%d, I large enough for a sampled threshold); use anncur_gemm + anncur_rowwise_topk",
+				   (long long)Q, (long long)I, Kp, k, WIDE_KP_MAX, ANNCUR_MAX_TOPK);
 	ANNCUR_REQUIRE(X && Et && out_val && out_idx, ANNCUR_E_INVALID, "score_topk: null pointer");
 	ANNCUR_REQUIRE(lde == Kp, ANNCUR_E_INVALID, "score_topk: Et must be packed (lde == Kp), got lde=%lld", (long long)lde);
 	ANNCUR_REQUIRE(ldx >= Kp && (ldx % 8) == 0, ANNCUR_E_INVALID, "score_topk: ldx must be >= Kp and a multiple of 8");
@@ -1093,7 +1237,8 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
 		case 128: rc = launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
 		case 256: rc = launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
-		default: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
+		case 512: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
+		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev); break;
 	}
 	if (rc == ANNCUR_OK && item_ids) {
 		const int64_t n = Q * (int64_t)k;
@@ -1122,7 +1267,7 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 	constexpr int NEV = 11;  // 0..4 stage boundaries, 5..10 begin/end of up to three sweep launches
 	hipEvent_t ev[NEV];
 	for (int i = 0; i < NEV; ++i) ANNCUR_HIP_OK(hipEventCreate(&ev[i]));
-	const FusedPlan P = plan_fused(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0);
+	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0);
 	int rc = score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, ev, flags, item_ids);
 	if (rc == ANNCUR_OK) {
 		hipError_t e = hipEventSynchronize(ev[4]);
@@ -1141,9 +1286,9 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 	return rc;
 }
 
-/* plan introspection for benchmarks / DESIGN.md: n_sample_tiles, n_tiles, S, capg, group */
+/* plan introspection for benchmarks / DESIGN.md: n_sample_tiles, n_tiles, S, capg, group (tiles of 32 items, or of 256 for Kp > 512) */
 extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t *out5) {
-	const FusedPlan P = plan_fused(Q, I, Kp, k);
+	const FusedPlan P = plan_any(Q, I, Kp, k);
 	ANNCUR_REQUIRE(P.ok && out5, ANNCUR_E_UNSUPPORTED, "score_topk_plan: unsupported shape");
 	out5[0] = P.n_st; out5[1] = P.n_tiles; out5[2] = P.S; out5[3] = P.capg; out5[4] = P.group;
 	return ANNCUR_OK;

@@ -244,14 +244,21 @@ def rowwise_topk(A, k):
 	return TopK(val, idx)
 
 
-_KP_CHOICES = (64, 128, 256, 512)
+_KP_CHOICES = (64, 128, 256, 512)   # query operand resident in registers (score_kernel)
+_KP_WIDE_MAX = 4096                  # beyond: LDS-tiled K-general kernel (wide_kernel), Kp a multiple of 128
 
 
 def padded_k(K):
+	"""Inner dimension the fused kernels take for a logical K (zero-padded), or None if K is too wide for them."""
 	for kp in _KP_CHOICES:
 		if K <= kp:
 			return kp
-	return None
+	kp = -(-K // 128) * 128
+	return kp if kp <= _KP_WIDE_MAX else None
+
+
+def _kp_ok(Kp):
+	return Kp in _KP_CHOICES or (512 < Kp <= _KP_WIDE_MAX and Kp % 128 == 0)
 
 
 @_on_device
@@ -285,7 +292,7 @@ class _Workspace:
 
 
 def fused_supported(Q, I, Kp, k):
-	return Kp in _KP_CHOICES and bool(_lib.load().anncur_score_topk_supported(Q, I, Kp, k))
+	return _kp_ok(Kp) and bool(_lib.load().anncur_score_topk_supported(Q, I, Kp, k))
 
 
 def fused_workspace(Q, I, Kp, k, device):
@@ -379,18 +386,16 @@ def fused_plan(Q, I, Kp, k):
 
 
 def _dense_scores(X, Et):
-	"""S = X @ Et^T with fp32 sums.  bf16 x bf16 operands of GEMM size go to the library GEMM (hipBLASLt through torch.mm, fp32
-	output: a plain GEMM, ~750 TFLOP/s); everything else to the strided fp32-MFMA kernel (exact fp32 products, any strides)."""
-	K = X.shape[1]
-	if (X.dtype == torch.bfloat16 and Et.dtype == torch.bfloat16 and K >= 128 and X.shape[0] * Et.shape[0] >= (1 << 20)
-			and X.stride(1) == 1 and Et.stride(1) == 1):
-		return torch.mm(X, Et.t(), out_dtype=torch.float32)
+	"""S = X @ Et^T with fp32 products and sums: the strided fp32-MFMA kernel of this library (any strides, fp32 or bf16 operands).
+	No vendor GEMM anywhere on the path."""
 	return gemm(X, Et.t())
 
 
 @_on_device
 def score_topk_dense(X, Et, k, max_bytes=2 << 30):
-	"""Unfused route: S = X @ Et^T in fp32 (row chunks), then the exact scan.  Any K, any dtype."""
+	"""Unfused route: S = X @ Et^T in fp32 (row chunks), then the exact scan.  Any K, any dtype.  bf16 operands of a shape the
+	fused kernels take never come here from the index classes (cur.py / nearest_nbr.py try score_topk_fused first); what is left
+	are the fp32 route, tiny item sets and tests that want the unfused answer."""
 	_dev(X, Et)
 	Q, I = X.shape[0], Et.shape[0]
 	val = torch.empty((Q, k), dtype=torch.float32, device=X.device)

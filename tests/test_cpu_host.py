@@ -43,7 +43,10 @@ def test_no_compute_without_gpu_and_plan_queries_work():
 		ops.rowwise_topk(torch.zeros(4, 10), 2)                               # CPU tensor: there is no CPU fallback
 	with pytest.raises(_lib.AnncurHipError):
 		ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
-	assert ops.padded_k(200) == 256 and ops.padded_k(513) is None
+	assert ops.padded_k(200) == 256 and ops.padded_k(513) == 640 and ops.padded_k(768) == 768 and ops.padded_k(4097) is None
+	assert lib.anncur_score_topk_supported(10000, 100000, 1024, 100) == 1    # wide inner dimension: the LDS-tiled K-general kernel
+	assert lib.anncur_score_topk_supported(10000, 100000, 1000, 100) == 0    # ... takes multiples of 128 (the caller zero-pads)
+	assert lib.anncur_score_topk_workspace_bytes(1200, 15603, 1024, 100) > 0
 
 
 def test_product_never_imports_the_oracle():

@@ -1120,6 +1120,7 @@ FusedPlan plan_wide(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
 	int capg = next_pow2((int)(4.0 * per_seg) + 32);
 	if (capg < 64) capg = 64;
 	if (capg > 16384) capg = 16384;
+	while (capg > 64 && (int64_t)capg * 4 * P.S >= (1 << 21)) capg >>= 1;  // a workgroup's 256 x 4 S segments span < 4 GiB (32-bit store offsets)
 	P.capg = capg;
 	P.flush_tiles = 1;
 	plan_stages(P, Q, k, exp_hits, (k <= WSEL_K ? 4 * P.S <= WAVE : true) && P.n_tiles >= 4 * P.S, 1.0 * P.S / P.n_tiles, WBM);
@@ -1145,17 +1146,21 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 	p.n_st = P.n_st; p.S0 = P.S0; p.st_per_split = P.st_per_split; p.sample_leading = P.leading; p.n_bt_full = P.n_full;
 	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg;
+	p.tau_bias = 0.f;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	{ const char *dbg = getenv("ANNCUR_DEBUG_TAU_BIAS"); p.tau_bias = dbg ? (float)atof(dbg) : 0.f; }
+#endif
 	int rc;
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
 	EV(0);
 	// 1. prepass over the sampled block tiles
 	p.n_wg = P.n_rb * P.S0;
 	if (P.group == 16) {
-		if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<0, 16>, W_LDS_BYTES)) != ANNCUR_OK) return rc;
-		hipLaunchKernelGGL((wide_kernel<0, 16>), dim3(p.n_wg), dim3(512), W_LDS_BYTES, st, p);
+		if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<0, 16>, W_LDS_TOTAL)) != ANNCUR_OK) return rc;
+		hipLaunchKernelGGL((wide_kernel<0, 16>), dim3(p.n_wg), dim3(512), W_LDS_TOTAL, st, p);
 	} else {
-		if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<0, 4>, W_LDS_BYTES)) != ANNCUR_OK) return rc;
-		hipLaunchKernelGGL((wide_kernel<0, 4>), dim3(p.n_wg), dim3(512), W_LDS_BYTES, st, p);
+		if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<0, 4>, W_LDS_TOTAL)) != ANNCUR_OK) return rc;
+		hipLaunchKernelGGL((wide_kernel<0, 4>), dim3(p.n_wg), dim3(512), W_LDS_TOTAL, st, p);
 	}
 	ANNCUR_LAUNCH_OK();
 	EV(1);
@@ -1164,11 +1169,11 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 	EV(2);
 	// 3. sweep in stages
 	p.n_wg = P.n_rb * P.S;
-	if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<1, 16>, W_LDS_BYTES)) != ANNCUR_OK) return rc;
+	if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<1, 16>, W_LDS_TOTAL)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
 		EV(5 + 2 * stg);
 		p.bt_begin = prev; p.bt_end = P.stage_end[stg]; p.bt_per_split = P.stage_tps[stg]; p.carry = stg > 0;
-		hipLaunchKernelGGL((wide_kernel<1, 16>), dim3(p.n_wg), dim3(512), W_LDS_BYTES, st, p);
+		hipLaunchKernelGGL((wide_kernel<1, 16>), dim3(p.n_wg), dim3(512), W_LDS_TOTAL, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
 		if (stg + 1 < P.n_stages &&

@@ -21,6 +21,7 @@ constexpr int WBM = 256, WBN = 256;             // items per block tile, queries
 constexpr int W_TILE_BYTES = 256 * 128;         // one operand tile of one 64-wide k-tile
 constexpr int W_STAGE_BYTES = 2 * W_TILE_BYTES; // items + queries
 constexpr int W_LDS_BYTES = 2 * W_STAGE_BYTES;  // two stages
+constexpr int W_LDS_TOTAL = W_LDS_BYTES;
 
 struct WideParams {
 	const uint16_t *X; int64_t ldx;
@@ -34,6 +35,7 @@ struct WideParams {
 	const float *tau; int tau_stride;
 	uint2 *cand; uint32_t *seg_cnt; int capg;
 	int n_wg;
+	float tau_bias;  // 0 in production (ANNCUR_DEBUG_TAU_BIAS of the timing-experiment build: results become wrong)
 };
 
 // work id -> (query block, item split).  Consecutive ids (= one XCD after xcd_remap) cover a compact rectangle of
@@ -54,13 +56,16 @@ __device__ __forceinline__ void wide_map(int wid, int n_rb, int nsplit, int &rb,
 	}
 }
 
-// The wave's four 1 KiB pieces (8 rows x 128 B each) of one operand tile: LDS destination = wave-uniform base + lane * 16.
-__device__ __forceinline__ void wide_dma(const unsigned char *const (&src)[4], int k_bytes, unsigned char *tile, int wave) {
+// The wave's four 1 KiB pieces (8 rows x 128 B each) of one operand tile: LDS destination = wave-uniform base + lane * 16,
+// source = wave-uniform base (SGPR pair) + the lane's 32-bit byte offset of its (row, chunk).
+__device__ __forceinline__ void wide_dma(const unsigned char *base, const uint32_t (&off)[4], unsigned char *tile, int wave) {
 #pragma unroll
 	for (int i = 0; i < 4; ++i)
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + k_bytes),
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off[i]),
 										 (__attribute__((address_space(3))) void *)(tile + (wave * 4 + i) * 1024), 16, 0, 0);
 }
+
+struct WideFrag { bf16x8 a[4], b[2]; };
 
 // MODE 0: prepass (group maxima, GROUP = 16 or 4 items).  MODE 1: filter sweep.
 template <int MODE, int GROUP>
@@ -80,39 +85,40 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 	const int nk = p.Kp >> 6;  // 64-wide k-tiles (even: Kp is a multiple of 128)
 	const int64_t row_bytes = (int64_t)p.Kp * 2;
 
-	// ---- DMA sources: piece (wave * 4 + i) = tile rows 8 (wave * 4 + i) .. + 8, this lane: row + (lane >> 3), chunk lane & 7
-	const unsigned char *asrc[4], *bsrc[4];
-	int prow[4], pchunk[4];
+	// ---- DMA sources: piece (wave * 4 + i) = tile rows 8 (wave * 4 + i) .. + 8, this lane: row + (lane >> 3), chunk lane & 7.
+	// Offsets are relative to the tile's first row (uniform base): < 256 rows x 8 KiB.
+	const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.X) + qb * p.ldx * 2;
+	const unsigned char *abase;
+	uint32_t aoff[4], boff[4];
+	const int q_rows = (int)min((int64_t)WBN, p.Q - qb);  // rows past Q re-read the block's last query (their lanes carry tau = +inf)
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		prow[i] = (wave * 4 + i) * 8 + (lane >> 3);
-		pchunk[i] = (lane & 7) ^ ((prow[i] >> 1) & 7);
-		int64_t q = qb + prow[i];
-		if (q > p.Q - 1) q = p.Q - 1;  // rows past Q re-read the last query (their lanes carry tau = +inf / are never stored)
-		bsrc[i] = reinterpret_cast<const unsigned char *>(p.X) + q * p.ldx * 2 + pchunk[i] * 16;
+		const int prow = (wave * 4 + i) * 8 + (lane >> 3), pchunk = (lane & 7) ^ ((prow >> 1) & 7);
+		boff[i] = (uint32_t)min(prow, q_rows - 1) * (uint32_t)(p.ldx * 2) + (uint32_t)pchunk * 16u;
 	}
 	auto set_asrc = [&](int bt) {
+		abase = reinterpret_cast<const unsigned char *>(p.Et) + (int64_t)bt * WBM * row_bytes;
+		const int rows = (int)min((int64_t)WBM, p.et_rows - (int64_t)bt * WBM);  // block tiles past Et's last row re-read it (items >= I are dropped)
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			int64_t row = (int64_t)bt * WBM + prow[i];
-			if (row > p.et_rows - 1) row = p.et_rows - 1;  // (items >= I are dropped by the filter / never sampled)
-			asrc[i] = reinterpret_cast<const unsigned char *>(p.Et) + row * row_bytes + pchunk[i] * 16;
+			const int prow = (wave * 4 + i) * 8 + (lane >> 3), pchunk = (lane & 7) ^ ((prow >> 1) & 7);
+			aoff[i] = (uint32_t)min(prow, rows - 1) * (uint32_t)row_bytes + (uint32_t)pchunk * 16u;
 		}
 	};
 
 	// ---- this lane's queries
 	int64_t qv[2];
 	float tau[2];
-	uint32_t ncand[2];
-	uint2 *seg[2];
+	uint32_t ncand[2], segoff[2];  // candidate segment of (query, h, wi, split): byte offset from the workgroup's first segment
 	const int nseg = 4 * p.S, sg = (h * 2 + wi) * p.S + split;
+	unsigned char *cbase = reinterpret_cast<unsigned char *>(p.cand + qb * nseg * (int64_t)p.capg);  // (256 nseg capg 8 < 4 GiB: plan_wide)
 #pragma unroll
 	for (int t = 0; t < 2; ++t) {
 		qv[t] = qb + wq * 64 + 32 * t + r;
 		const bool ok = qv[t] < p.Q;
-		tau[t] = (MODE == 1 && ok) ? p.tau[qv[t] * p.tau_stride] : INFINITY;
+		tau[t] = (MODE == 1 && ok) ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
 		ncand[t] = (MODE == 1 && p.carry && ok) ? p.seg_cnt[qv[t] * nseg + sg] : 0u;
-		seg[t] = (MODE == 1) ? p.cand + ((ok ? qv[t] : 0) * nseg + sg) * (int64_t)p.capg : nullptr;
+		segoff[t] = (uint32_t)(((wq * 64 + 32 * t + r) * nseg + sg) * p.capg) * 8u;
 	}
 
 	// ---- fragment addresses: row * 128 + ((2 s + h) ^ x) * 16, x = (row >> 1) & 7 = (r >> 1) & 7 for every sub-tile
@@ -124,14 +130,14 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 
 	if (j_begin < j_end) {
 		set_asrc(bt_of(j_begin));
-		wide_dma(asrc, 0, smem, wave);
-		wide_dma(bsrc, 0, smem + W_TILE_BYTES, wave);
+		wide_dma(abase, aoff, smem, wave);
+		wide_dma(xbase, boff, smem + W_TILE_BYTES, wave);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 	__syncthreads();
 
 	for (int j = j_begin; j < j_end; ++j) {
-		const int bt = bt_of(j);
+		const int bt = bt_of(j), bt_next = j + 1 < j_end ? bt_of(j + 1) : bt;
 		f32x16 acc[4][2];
 #pragma unroll
 		for (int m = 0; m < 4; ++m)
@@ -140,37 +146,76 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 #pragma unroll
 				for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
 
+		// One 64-wide k-tile = 4 k-steps of 6 fragment reads + 8 MFMAs; the fragments of step s + 1 are requested before the
+		// MFMAs of step s (two register sets), so only the first read of a k-tile exposes its LDS latency.
+#define WIDE_LOAD(F, STAGE, s)                                                                                    \
+		do {                                                                                                      \
+			const unsigned char *sb = smem + (STAGE) * W_STAGE_BYTES + coff[s];                                   \
+			_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                         \
+				F.a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(sb + a_base + m * 4096));    \
+			_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
+				F.b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(sb + b_base + t * 4096));    \
+		} while (0)
+#define WIDE_MFMA(F)                                                                                              \
+		do {                                                                                                      \
+			_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                         \
+				_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                     \
+					acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[m], F.b[t], acc[m][t], 0, 0, 0);      \
+		} while (0)
+		// The wave's DMA pieces of the next k-tile have landed, its fragment reads are done: raw barrier.
+		// (Tried and dropped: warming the XCD's L2 two k-tiles ahead with one 4-byte load per 128-byte line and thread, excluded
+		//  from the wait by a counted vmcnt: 907 vs 960 TFLOP/s at 10k x 100k x 1024 -- the loop is not waiting on misses.)
+#define WIDE_SYNC()                                                                                               \
+		do {                                                                                                      \
+			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+			__builtin_amdgcn_s_barrier();                                                                         \
+			asm volatile("" ::: "memory");                                                                        \
+		} while (0)
+		// DMA of the next k-tile: two of the wave's eight 1 KiB pieces per k-step, issued between the fragment reads and the MFMAs
+		// of the step (eight back-to-back issues at the head of the k-tile kept both waves of a SIMD off the matrix pipe together).
+#define WIDE_PIECE(BASE, OFF, TILE, i)                                                                            \
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((BASE) + (OFF)[i]),      \
+										 (__attribute__((address_space(3))) void *)((TILE) + (wave * 4 + (i)) * 1024), 16, 0, 0)
+#define WIDE_DMA2(s)                                                                                              \
+		do {                                                                                                      \
+			if (den) {                                                                                            \
+				if ((s) < 2) { WIDE_PIECE(da, aoff, dd, 2 * ((s) & 1)); WIDE_PIECE(da, aoff, dd, 2 * ((s) & 1) + 1); } \
+				else { WIDE_PIECE(db, boff, dd + W_TILE_BYTES, 2 * ((s) & 1)); WIDE_PIECE(db, boff, dd + W_TILE_BYTES, 2 * ((s) & 1) + 1); } \
+			}                                                                                                     \
+		} while (0)
+#ifdef WIDE_SETPRIO
+#define WIDE_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define WIDE_PRIO(x) do {} while (0)
+#endif
 #define WIDE_COMPUTE(STAGE)                                                                                       \
 		do {                                                                                                      \
-			const unsigned char *sb = smem + (STAGE) * W_STAGE_BYTES;                                             \
-			_Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                       \
-				bf16x8 af[4], bfr[2];                                                                             \
-				_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                     \
-					af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(sb + a_base + m * 4096 + coff[s])); \
-				_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                     \
-					bfr[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(sb + b_base + t * 4096 + coff[s])); \
-				_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                     \
-					_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                 \
-						acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[t], acc[m][t], 0, 0, 0);   \
-			}                                                                                                     \
+			WideFrag f0, f1;                                                                                      \
+			WIDE_LOAD(f0, STAGE, 0);                                                                              \
+			__builtin_amdgcn_sched_barrier(0);                                                                    \
+			WIDE_LOAD(f1, STAGE, 1); WIDE_DMA2(0); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f0); WIDE_PRIO(0); __builtin_amdgcn_sched_barrier(0); \
+			WIDE_LOAD(f0, STAGE, 2); WIDE_DMA2(1); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f1); WIDE_PRIO(0); __builtin_amdgcn_sched_barrier(0); \
+			WIDE_LOAD(f1, STAGE, 3); WIDE_DMA2(2); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f0); WIDE_PRIO(0); __builtin_amdgcn_sched_barrier(0); \
+			WIDE_DMA2(3); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f1); WIDE_PRIO(0);           \
 		} while (0)
 
 		for (int kt = 0; kt < nk; kt += 2) {
 			// stage 0 holds k-tile kt: fetch kt + 1 into stage 1 while it is consumed
-			wide_dma(asrc, (kt + 1) * 128, smem + W_STAGE_BYTES, wave);
-			wide_dma(bsrc, (kt + 1) * 128, smem + W_STAGE_BYTES + W_TILE_BYTES, wave);
+			const unsigned char *da = abase + (kt + 1) * 128, *db = xbase + (kt + 1) * 128;
+			unsigned char *dd = smem + W_STAGE_BYTES;
+			bool den = true;
 			WIDE_COMPUTE(0);
-			__builtin_amdgcn_s_waitcnt(0x0F70);
-			__syncthreads();
+			WIDE_SYNC();
 			// stage 1 holds k-tile kt + 1: fetch kt + 2 (or the first k-tile of the next block tile) into stage 0
 			const bool last = kt + 2 >= nk;
+			dd = smem;
 			if (!last) {
-				wide_dma(asrc, (kt + 2) * 128, smem, wave);
-				wide_dma(bsrc, (kt + 2) * 128, smem + W_TILE_BYTES, wave);
+				da = abase + (kt + 2) * 128; db = xbase + (kt + 2) * 128;
 			} else if (j + 1 < j_end) {
-				set_asrc(bt_of(j + 1));
-				wide_dma(asrc, 0, smem, wave);
-				wide_dma(bsrc, 0, smem + W_TILE_BYTES, wave);
+				set_asrc(bt_next);
+				da = abase; db = xbase;
+			} else {
+				den = false;
 			}
 			WIDE_COMPUTE(1);
 			if (last) {
@@ -198,18 +243,25 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 							}
 						}
 				} else {
+					const uint32_t item_wave = (uint32_t)bt * WBM + (uint32_t)(wi * 128 + 4 * h);
 #pragma unroll
 					for (int t = 0; t < 2; ++t)
 #pragma unroll
 						for (int m = 0; m < 4; ++m) {
-							const uint32_t item0 = (uint32_t)bt * WBM + (uint32_t)(wi * 128 + m * 32 + 4 * h);
 #pragma unroll
 							for (int e = 0; e < 16; ++e) {
 								const float v = acc[m][t][e];
 								if (__builtin_expect(__ballot(v >= tau[t]) != 0ull, 0)) {
-									const uint32_t item = item0 + (uint32_t)((e & 3) + 8 * (e >> 2));
+									// (the item id is made opaque HERE: hipcc otherwise precomputes all 128 ids and their
+									//  "item < I" masks once per block tile and spills them)
+									uint32_t item = item_wave;
+#if defined(__HIP_DEVICE_COMPILE__)
+									asm volatile("" : "+v"(item));
+#endif
+									item += (uint32_t)(m * 32 + (e & 3) + 8 * (e >> 2));
 									if (v >= tau[t] && item < (uint32_t)p.I) {
-										if (ncand[t] < (uint32_t)p.capg) seg[t][ncand[t]] = make_uint2(__float_as_uint(v), item);
+										if (ncand[t] < (uint32_t)p.capg)
+											*reinterpret_cast<uint2 *>(cbase + (segoff[t] + ncand[t] * 8u)) = make_uint2(__float_as_uint(v), item);
 										ncand[t]++;  // (a count above capg marks the overflow: the select kernel repairs this split)
 									}
 								}
@@ -217,10 +269,15 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 						}
 				}
 			}
-			__builtin_amdgcn_s_waitcnt(0x0F70);
-			__syncthreads();
+			WIDE_SYNC();
 		}
 #undef WIDE_COMPUTE
+#undef WIDE_MFMA
+#undef WIDE_LOAD
+#undef WIDE_SYNC
+#undef WIDE_PIECE
+#undef WIDE_DMA2
+#undef WIDE_PRIO
 	}
 #undef bt_of
 	if (MODE == 1) {

@@ -50,16 +50,18 @@ def allgather_rows(local_block, counts, group=None):
 	send[:counts[rank]] = local_block
 	# RCCL ("nccl") moves device tensors directly over xGMI.  The gloo backend (CPU tests, and the 2-ranks-on-one-GPU rehearsal)
 	# cannot: stage through the host there.
-	staged = local_block.is_cuda and dist.get_backend(group) == "gloo"
+	gloo = dist.get_backend(group) == "gloo"
+	staged = local_block.is_cuda and gloo
+	as_bytes = gloo and local_block.dtype == torch.bfloat16   # gloo moves bytes: it has no bf16 (nor int16) type
 	if staged:
 		send = send.cpu()
-		if send.dtype == torch.bfloat16:
-			send = send.view(torch.int16)
-	recv = send.new_empty((world * cmax, I))
+	if as_bytes:
+		send = send.view(torch.uint8)
+	recv = send.new_empty((world * cmax, send.shape[1]))
 	dist.all_gather_into_tensor(recv, send, group=group)
+	if as_bytes:
+		recv = recv.view(torch.bfloat16)
 	if staged:
-		if local_block.dtype == torch.bfloat16:
-			recv = recv.view(torch.bfloat16)
 		recv = recv.to(local_block.device)
 	if all(c == cmax for c in counts):
 		return recv
@@ -107,11 +109,17 @@ def gather_rows_to_rank0(local, n_rows, group=None):
 	send = local.new_zeros((cmax, c))
 	send[:counts[rank]] = local
 	staged = local.is_cuda and dist.get_backend(group) == "gloo"   # (see allgather_rows)
+	as_bytes = local.dtype == torch.bfloat16 and dist.get_backend(group) == "gloo"
 	if staged:
 		send = send.cpu()
+	if as_bytes:
+		send = send.view(torch.uint8)
+		c = send.shape[1]
 	recv = [send.new_empty((cmax, c)) for _ in range(world)] if rank == 0 else None
 	dist.gather(send, recv, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
 	if rank != 0:
 		return None
 	full = torch.cat([recv[r][:counts[r]] for r in range(world)], dim=0)
+	if as_bytes:
+		full = full.view(torch.bfloat16)
 	return full.to(local.device) if staged else full

@@ -10,8 +10,14 @@ value = queries / second over all ranks (weak scaling: every rank evaluates its 
 
     python bench.py --gpus N --steps K --warmup W
 prints ONE JSON line on rank 0 (metric, value, roofline, cpu_baseline, ...).
+
+N > 1: one process per GPU.  Under torchrun (RANK / WORLD_SIZE in the environment) this process is one of the ranks; started
+plainly with --gpus N > 1 it launches the N ranks itself (torch.distributed.run, before any GPU call) and relays their result.
+The multi-GPU workload is BASELINE.json configs[3] (cfg4: 50k x 1M bf16, 512 anchors) at its per-GPU shape -- 6 250 query rows
+per rank whatever N is (weak scaling) -- with the anchor rows assembled by ONE RCCL all-gather (timed as allgather_ms).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -45,18 +51,49 @@ def synth_device(cfg, device, seed, row_seed=None):
 	return protocol_b(cfg["Kq"], cfg["Q"], cfg["I"], device, seed=seed, row_seed=row_seed)
 
 
+def self_launch(args):
+	"""--gpus N > 1 without a torchrun environment: start the N ranks as children of this process -- which has not touched the GPU
+	and never will -- relay rank 0's JSON line and exit with the launcher's code.  (A process that has initialised the GPU must
+	not exec or re-launch itself on this pool.)"""
+	import socket
+	import subprocess
+	with socket.socket() as sk:
+		sk.bind(("127.0.0.1", 0))
+		port = sk.getsockname()[1]
+	cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+		   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+	env = dict(os.environ)
+	env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / cross-process device memory on this host
+	proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+	out = proc.stdout.decode(errors="replace")
+	lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+	if lines:
+		print(lines[-1], flush=True)
+	else:
+		sys.stderr.write(out)
+	raise SystemExit(proc.returncode if proc.returncode != 0 or lines else 1)
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=30)
 	ap.add_argument("--warmup", type=int, default=5)
-	ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+	ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg2 on one GPU, cfg4_per_gpu on several")
+	ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-rank path with ranks sharing GPUs")
+	ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses GPU r %% device_count (RCCL cannot; use --backend gloo)")
+	ap.add_argument("--sustained-seconds", type=float, default=2.0, help="also loop the same step for this long and report it (DVFS-settled rate); 0 = skip")
 	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
 	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
 	ap.add_argument("--seed", type=int, default=0)
 	ap.add_argument("--no-overlap", action="store_true", help="run the exact scan on the same stream as the retrieval instead of a second one")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
+	if args.gpus > 1 and os.environ.get("RANK") is None:
+		self_launch(args)
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if args.config is None:
+		args.config = "cfg2" if world == 1 else "cfg4_per_gpu"
 	cfg = CONFIGS[args.config]
 	# stdout carries exactly ONE line (the result JSON): libraries that print banners to fd 1 (RCCL at communicator creation
 	# does) are sent to stderr for the whole run, the JSON goes to the saved descriptor at the end
@@ -64,20 +101,25 @@ def main():
 	result_fd = os.dup(1)
 	os.dup2(2, 1)
 
-	world = int(os.environ.get("WORLD_SIZE", "1"))
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	if not torch.cuda.is_available():
 		raise SystemExit("bench.py needs an MI355X: anncur_amd has no CPU path")
 	torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
+	if args.share_gpu:
+		local_rank %= torch.cuda.device_count()
 	torch.cuda.set_device(local_rank)
 	device = torch.device("cuda", local_rank)
 	use_dist = world > 1 or (os.environ.get("RANK") is not None and os.environ.get("ANNCUR_BENCH_FORCE_DIST"))
 	if use_dist:
 		import torch.distributed as dist
-		dist.init_process_group("nccl", device_id=device)  # RCCL
-	if args.gpus != world and rank == 0:
-		print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+		if args.backend == "nccl":
+			dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+		else:
+			dist.init_process_group("gloo")
+	ranks_seen = torch.distributed.get_world_size() if use_dist else 1
+	if args.gpus != world:
+		raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
 	from anncur_amd import _lib, ops
 	from anncur_amd.cur import CURApprox
@@ -90,8 +132,17 @@ def main():
 	# assembled the way a row-sharded score matrix delivers it: each rank contributes Kq/N anchor rows, one all-gather.
 	# one score model for the whole job (item factors from --seed); every rank draws its own queries and its own share of the anchor rows
 	A_train, A_test = synth_device(cfg, device, args.seed, row_seed=None if world == 1 else args.seed * 1000 + rank + 1)
+	allgather_ms = None
 	if use_dist:
+		# the path's ONE collective: every rank owns Kq / N of the anchor rows, an all-gather assembles R [Kq x I] everywhere
+		allgather_anchor_rows(A_train, cfg["Kq"], rank, world)   # warm-up (communicator set-up, buffers)
+		torch.distributed.barrier(); torch.cuda.synchronize()
+		t0 = time.perf_counter()
 		A_train = allgather_anchor_rows(A_train, cfg["Kq"], rank, world)
+		torch.cuda.synchronize()
+		t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+		torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+		allgather_ms = 1e3 * t.item()
 	rng = np.random.default_rng(args.seed)
 	anc = sorted(rng.choice(cfg["I"], size=cfg["Ki"], replace=False))
 	anc_dev = ops.as_index(anc, device)
@@ -202,11 +253,40 @@ def main():
 		print(f"[bench debug] per step: launch {1e3 * prof['launch'] / (args.steps + args.warmup):.3f} ms, "
 			  f"finish {1e3 * prof['finish'] / (args.steps + args.warmup):.3f} ms (of which event wait {1e3 * prof.get('wait', 0) / (args.steps + args.warmup):.3f} ms, pinned memcpy {1e3 * prof.get('memcpy', 0) / (args.steps + args.warmup):.3f} ms)", file=sys.stderr)
 	if use_dist:
-		t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+		t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
 		torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
 		elapsed = t.item()
 	ms_per_step = 1e3 * elapsed / args.steps
 	value = world * Q * args.steps / elapsed
+
+	# the same K steps on rank 0 ALONE (the other ranks wait): the single-GPU rate of this very workload inside the same job, so that
+	# weak-scaling efficiency = value / (N x solo) can be read off one line
+	solo = None
+	if use_dist:
+		barrier()
+		if rank == 0:
+			t0 = time.perf_counter(); run_steps(args.steps); torch.cuda.synchronize()
+			solo = Q * args.steps / (time.perf_counter() - t0)
+		barrier()
+	# sustained: the same step looped for >= 2 s (the timed region above is a burst of K steps; under a long MFMA load the chip
+	# lowers its clock -- MI355X_MICROARCH.md 'DVFS give-back')
+	sustained = None
+	if args.sustained_seconds > 0:
+		barrier()
+		t0 = time.perf_counter(); n_sus = 0
+		while True:
+			run_steps(20); n_sus += 20
+			torch.cuda.synchronize()
+			if time.perf_counter() - t0 >= args.sustained_seconds:
+				break
+		sus_s = time.perf_counter() - t0
+		if use_dist:
+			t = torch.tensor([sus_s / n_sus], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+			torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+			sus_step = t.item()
+		else:
+			sus_step = sus_s / n_sus
+		sustained = {"value": world * Q / sus_step, "unit": "queries/s", "ms_per_step": 1e3 * sus_step, "seconds": sus_s, "steps": n_sus}
 
 	# ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
 	stage = np.zeros(6)
@@ -246,13 +326,17 @@ def main():
 	sweep_ms = stage[4] / n_sweep                          # average launch duration of score_kernel<Kp,sweep>
 	sweep_tflops = sweep_flops / (sweep_ms * 1e-3) / 1e12
 	scan_bytes = Q * I * 2 + Q * k * 8
-	traffic = None
-	tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-	if os.path.isfile(tfile):
+	# HBM bytes per launch of the sweep from the PMC passes of THIS config (scripts/profile_round.sh -> profiles/); null if this
+	# config has not been profiled -- never another shape's number
+	traffic = traffic_src = None
+	for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{args.config}.json")), reverse=True):
 		try:
-			traffic = json.load(open(tfile)).get("score_kernel_sweep_hbm_bytes_per_launch")
+			d = json.load(open(tfile))
+			if d.get("config") == args.config and d.get("Q") == Q and d.get("I") == I and d.get("Kp") == Kp:
+				traffic, traffic_src = d.get("score_kernel_sweep_hbm_bytes_per_launch"), os.path.basename(tfile)
+				break
 		except Exception:
-			traffic = None
+			pass
 
 	out = None
 	if rank == 0:
@@ -270,7 +354,7 @@ def main():
 			"roofline": {"bound": "mfma", "kernel": f"score_kernel<{Kp},sweep> (fused S_hat GEMM + threshold filter)",
 						 "achieved": sweep_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": sweep_tflops / PEAK_BF16_TFLOPS,
 						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(sweep_ms), "launches_per_step": n_sweep},
-			"roofline_scan": {"bound": "hbm", "kernel": "rowwise_topk_kernel<bf16,128> (exact top-k scan)",
+			"roofline_scan": {"bound": "hbm", "kernel": "rowwise_topk_wave_kernel<bf16> (exact top-k scan, one wave per row)",
 							  "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
 							  "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
 			"stage_ms": {"gather_cols": gath_ms, "prepass": float(stage[0]), "threshold": float(stage[1]), "sweep": float(stage[2]), "sweep_kernels_only": float(stage[4]),
@@ -281,6 +365,8 @@ def main():
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
 			"fused_plan": ops.fused_plan(Q, I, Kp, kr),
 			"launch_mode": "eager" if graphs is None else "hipGraph replay (the step's launches captured once per result slot)",
+			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
+			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),
 		}
 
 	# ------------------------------------------------------------------ CPU baseline: the oracle (reference-faithful loop) on a bounded sample

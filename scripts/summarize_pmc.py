@@ -1,9 +1,20 @@
-"""Dev tool: average the rocprofv3 --pmc counter rows per kernel (our kernels only) -> JSON on stdout.
-usage: python scripts/summarize_pmc.py gpurun_out/prof_<tag>"""
-import csv, collections, glob, json, re, sys
+"""Dev tool: average the rocprofv3 --pmc counter rows per kernel (our kernels only) -> JSON on stdout, including the
+`profiles/rNN_pmc_traffic_<config>.json` block bench.py reads for roofline.traffic (HBM bytes per launch of the sweep kernel).
+usage: python scripts/summarize_pmc.py gpurun_out/prof_<tag> [cfg2|cfg4_per_gpu]
+
+Corrections per MI355X_MICROARCH.md 'HBM': FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports exactly half the bytes
+of wide coalesced streaming reads (16 B per lane, global_load and direct-to-LDS alike), so read bytes = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE * 1024 is exact for 16-byte streaming stores (sparse 8-byte candidate stores are counted with their partial-line
+amplification).  Each counter group was collected in its own run (--kernel-trace + --pmc only)."""
+import csv, collections, glob, json, os, sys
 root = sys.argv[1]
-names = ["score_kernel<256, 1, 16>", "score_kernel<256, 0, 16>", "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false>",
-		 "select_wave_kernel<true>", "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel"]
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+SHAPES = {"cfg2": dict(Q=10000, I=100000, Kp=256, k=100), "cfg4_per_gpu": dict(Q=6250, I=1000000, Kp=512, k=100)}
+shape = SHAPES[cfg]
+kp = shape["Kp"]
+sweep, prepass = f"score_kernel<{kp}, 1, 16>", f"score_kernel<{kp}, 0, 16>"
+names = [sweep, prepass, "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false>", "select_wave_kernel<true>",
+		 "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/pmc_*/*counter_collection.csv"):
 	for r in csv.DictReader(open(f)):
@@ -19,4 +30,18 @@ for f in glob.glob(root + "/stats/*kernel_stats.csv"):
 	for r in csv.DictReader(open(f)):
 		for n in names:
 			if n in r["Name"]: stats[n] = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2)}
-print(json.dumps({"pmc_avg_per_launch": out, "kernel_stats": stats}, indent=1))
+res = {"config": cfg, **shape, "pmc_avg_per_launch": out, "kernel_stats": stats}
+sw = out.get(sweep)
+if sw and "FETCH_SIZE" in sw and "WRITE_SIZE" in sw:
+	rd, wr = 2 * sw["FETCH_SIZE"] * 1024, sw["WRITE_SIZE"] * 1024
+	res["score_kernel_sweep_read_bytes_per_launch"] = round(rd)
+	res["score_kernel_sweep_write_bytes_per_launch"] = round(wr)
+	res["score_kernel_sweep_hbm_bytes_per_launch"] = round(rd + wr)
+	if "GRBM_GUI_ACTIVE" in sw and sweep in stats:
+		clk = sw["GRBM_GUI_ACTIVE"] / 8 / (stats[sweep]["avg_us"] * 1e-6)
+		res["score_kernel_sweep_clock_ghz"] = round(clk / 1e9, 3)
+		res["score_kernel_sweep_mfma_pipe_busy"] = round(sw.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (sw["GRBM_GUI_ACTIVE"] / 8), 3)
+sc = out.get("rowwise_topk_wave_kernel<unsigned short>")
+if sc and "FETCH_SIZE" in sc:
+	res["exact_scan_hbm_bytes_per_launch"] = round(2 * sc["FETCH_SIZE"] * 1024 + sc.get("WRITE_SIZE", 0) * 1024)
+print(json.dumps(res, indent=1))

@@ -118,6 +118,13 @@ def _shard_worker(rank, world, port, n_rows, row_idxs, q):
 	full = gather_rows_to_rank0(local_result.contiguous(), n_rows)
 	if rank == 0:
 		ok = ok and torch.equal(full, A[:, :3] * 2)
+	# bf16 rows (the storage type of cfg2 / cfg4): gloo has no bf16, the rows travel as bytes
+	Ab = A.bfloat16()
+	smb = ShardedScoreMatrix(Ab[s:e].clone(), n_rows, pack=lambda local, idx: local[torch.as_tensor(np.asarray(idx), dtype=torch.long)])
+	ok = ok and torch.equal(smb.anchor_rows(row_idxs), Ab[row_idxs])
+	fb = gather_rows_to_rank0(Ab[s:e, :5].contiguous(), n_rows)
+	if rank == 0:
+		ok = ok and torch.equal(fb, Ab[:, :5])
 	q.put((rank, bool(ok)))
 	dist.destroy_process_group()
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ANNCUR_LIB: measurement scripts point this at the -DANNCUR_TIMING_EXPERIMENTS build (`make -C anncur_amd/csrc experiments`)
 LIB_PATH = os.environ.get("ANNCUR_LIB") or os.path.join(_HERE, "lib", "libanncur_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F64 = 0, 1, 2
 TOPK_LEADING_SAMPLE = 1
 MAX_TOPK = 2048
 
@@ -31,6 +31,10 @@ SIGNATURES = {
 							   c_int64, c_int64, c_int64, ctypes.c_float, ctypes.c_float, c_void_p, c_int64, c_int64, c_void_p]),
 	"anncur_sumsq": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
 	"anncur_scale_copy": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, ctypes.c_float, c_void_p, c_void_p]),
+	"anncur_gemm_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+								ctypes.c_double, ctypes.c_double, c_void_p, c_int64, c_int64, c_void_p]),
+	"anncur_convert_f64": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, ctypes.c_double, c_void_p, c_void_p]),
+	"anncur_diff_sumsq_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
 	"anncur_approx_error_packed": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_approx_error": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64,
 									c_int64, c_void_p, c_void_p, c_void_p]),

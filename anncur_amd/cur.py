@@ -12,8 +12,10 @@ Differences from the reference, all deliberate:
     tensor passed to the call (CPU in -> CPU out), so reference call sites run unchanged;
   * ``compute_dtype``: "fp32" (default for fp32 inputs: 1e-4 score parity with the CPU path)
     or "bf16" (default for bf16 inputs: the fused MFMA score+top-k kernel).
-U = pinv(W) is computed with the same ``numpy.linalg.pinv`` call on the host as the reference
-(:47,:49; W is kr x kc, tiny) so that U is bit-identical; every product runs on the GPU.
+U = pinv(W) (:47,:49): ``pinv_backend="numpy"`` is the reference's own ``numpy.linalg.pinv`` call on the
+host (U bit-identical); the default "auto" computes it on the GPU in fp64 (exact pseudo-inverse of the
+fp32 block, within 1e-5 of numpy's on the golden cases) and keeps the host call for ill-conditioned
+blocks, whose numpy result is an inverse of fp32 round-off.  Every product runs on the GPU.
 """
 import logging
 
@@ -37,12 +39,31 @@ def _pinv_host(M):
 	return torch.from_numpy(np.linalg.pinv(M.detach().float().cpu().numpy()))
 
 
+AUTO_COND_LIMIT = 1e3   # pinv_backend "auto": the device result is taken while cond_F(W) stays below this
+
+
 def _pinv(M, device, backend):
 	"""backend "numpy": the reference's own call on the host (U bit-identical to the reference).
-	backend "device": Newton-Schulz on the GPU (anncur_amd/pinv.py), for large anchor counts."""
+	backend "device": Newton-Schulz in fp64 on the GPU (anncur_amd/pinv.py), rounded to fp32 once: the exact pseudo-inverse of the
+	  fp32 matrix; differs from numpy's fp32 LAPACK SVD by numpy's own round-off, ~cond(W) * 6e-8 (measured 1e-6..1e-5 on the
+	  golden cases).  A block that is singular to fp32 precision (no convergence within the iteration budget) goes to the host
+	  call: what numpy returns there is an inverse of round-off noise that no other algorithm reproduces.
+	backend "auto": the device route, kept only where it is as good as pinned -- cond_F(W) = ||W||_F ||W^+||_F <= 1e3, where
+	  the two agree far inside the 1e-4 score tolerance; an ill-conditioned block (e.g. as many anchor rows as anchor columns:
+	  numpy inverts singular values that are fp32 noise, and the reference's numbers are made of that noise) goes to the host call.
+	backend "device32": the fp32 iteration of round 1 (fast, ~1e-3)."""
 	if backend == "numpy":
 		return _pinv_host(M).to(device)
-	if backend == "device":
+	if backend in ("device", "auto"):
+		from .pinv import pinv_newton_schulz_f64
+		if min(M.shape) == 0:
+			return torch.zeros((M.shape[1], M.shape[0]), dtype=torch.float32, device=device)
+		X, info = pinv_newton_schulz_f64(M.to(device), return_info=True)
+		if info["converged"] and (backend == "device" or info["cond_F"] <= AUTO_COND_LIMIT):
+			return X
+		LOGGER.info("pinv %s: cond_F = %.3g after %d iterations (converged: %s) -> host numpy.linalg.pinv", backend, info["cond_F"], info["iterations"], info["converged"])
+		return _pinv_host(M).to(device)
+	if backend == "device32":
 		from .pinv import pinv_newton_schulz
 		return pinv_newton_schulz(M.to(device))
 	raise ValueError(f"pinv_backend = {backend} not supported")
@@ -59,7 +80,7 @@ def _is_full_range(idx, n):
 
 class CURApprox(object):
 
-	def __init__(self, rows, cols, row_idxs, col_idxs, approx_preference, A=None, compute_dtype=None, device=None, pinv_backend="numpy"):
+	def __init__(self, rows, cols, row_idxs, col_idxs, approx_preference, A=None, compute_dtype=None, device=None, pinv_backend="auto"):
 		super(CURApprox, self).__init__()
 		self.pinv_backend = pinv_backend
 		if device is None:
@@ -236,7 +257,7 @@ class CURRowIndex(object):
 	all-gather, U = pinv(R[:, col_idxs]) and E = U.R replicated, its own queries' anchor scores gathered locally.
 	Same arithmetic as CURApprox(rows=R, cols=A[:, col_idxs], ...) (eval/matrix_approx_zeshel.py:42-65)."""
 
-	def __init__(self, rows, col_idxs, compute_dtype=None, pinv_backend="numpy"):
+	def __init__(self, rows, col_idxs, compute_dtype=None, pinv_backend="auto"):
 		self.R = rows
 		self.m = rows.shape[1]
 		self.col_idxs = col_idxs

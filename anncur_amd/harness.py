@@ -47,7 +47,7 @@ def _subset_metrics(counts_row, rows, k):
 
 
 # ------------------------------------------------------------------------------------------------ entry point A
-def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed, exact_cache=None, pinv_backend="numpy"):
+def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed, exact_cache=None, pinv_backend="auto"):
 	"""One seed of one grid cell -> {"anchor": {...}, "non_anchor": {...}, "all": {...}} (crossenc.py:47-158)."""
 	n_ments, n_ents = A_dev.shape
 	rng = np.random.default_rng(seed=seed)
@@ -85,7 +85,7 @@ def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, 
 	return {"anchor": score(row_idxs), "non_anchor": score(non_anchor), "all": score(list(range(n_ments)))}
 
 
-def run_approx_eval(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, n_seeds, exact_cache=None, pinv_backend="numpy"):
+def run_approx_eval(approx_method, A_dev, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, n_seeds, exact_cache=None, pinv_backend="auto"):
 	"""Mean over seeds (crossenc.py:162-200)."""
 	acc = defaultdict(lambda: defaultdict(list))
 	for seed in range(n_seeds):
@@ -173,7 +173,7 @@ def default_grids_A(total_n_ment, total_n_ent):
 	}
 
 
-def run_entry_A(A_dev, grids, n_seeds, progress=None, pinv_backend="numpy"):
+def run_entry_A(A_dev, grids, n_seeds, progress=None, pinv_backend="auto"):
 	"""-> res[method]["top_k=.."]["k_retvr=.."]["anc_n_m=..~anc_n_e=.."][anchor|non_anchor|all][metric]  (crossenc.py:349-383)."""
 	total_n_ment, total_n_ent = A_dev.shape
 	res = defaultdict(lambda: defaultdict(lambda: defaultdict(dict)))
@@ -212,7 +212,7 @@ def _sweep_cells(A_test_dev, approx_idx, exact, top_k_vals, top_k_retr_vals, n_e
 	return {cell: flatten_overlap(overlap_stats_from_counts(counts[j], cell[0])) for j, cell in enumerate(cells)}
 
 
-def run_eval_method_cur(A_test_dev, A_train_dev, seed, grids, compute_dtype=None, progress=None, key_n_m=None, pinv_backend="numpy"):
+def run_eval_method_cur(A_test_dev, A_train_dev, seed, grids, compute_dtype=None, progress=None, key_n_m=None, pinv_backend="auto"):
 	"""eval_method == "cur" of entry point B for one seed (splits.py:286-303 + 399-429)."""
 	n_train, n_ent = A_train_dev.shape
 	top_k_vals, retr_vals, anc_vals = grids["top_k_vals"], grids["top_k_retr_vals"], grids["n_ent_anchors_vals"]

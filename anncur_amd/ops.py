@@ -187,6 +187,50 @@ def scale_copy(src, dst, alpha=1.0, divide_by=None):
 	return dst
 
 
+# ------------------------------------------------------------------ fp64 helpers of the on-device pseudo-inverse
+@_on_device
+def gemm_f64(A, B, out=None, alpha=1.0, beta=0.0, cin=None):
+	"""C = alpha * A @ B (+ beta * cin) in fp64 on the matrix cores, arbitrary strides."""
+	_dev(A, B)
+	if A.dtype != torch.float64 or B.dtype != torch.float64:
+		raise TypeError("gemm_f64 takes float64 tensors")
+	M, K = A.shape
+	K2, N = B.shape
+	if K != K2:
+		raise ValueError(f"gemm_f64: inner dimensions differ ({K} vs {K2})")
+	if out is None:
+		out = torch.empty((M, N), dtype=torch.float64, device=A.device)
+	check(_lib.load().anncur_gemm_f64(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(out), out.stride(0), out.stride(1),
+									  M, N, K, float(alpha), float(beta), _p(cin) if cin is not None else None,
+									  cin.stride(0) if cin is not None else 0, cin.stride(1) if cin is not None else 0, _stream()), "gemm_f64")
+	return out
+
+
+_DT64 = {torch.float32: F32, torch.bfloat16: BF16, torch.float64: _lib.F64}
+
+
+@_on_device
+def convert_f64(src, dst, alpha=1.0, divide_by=None):
+	"""dst[i, j] = alpha / divide_by[0] * src[i, j]; f32 / bf16 / f64 -> f64, or f64 -> f32 (one rounding); any strides."""
+	_dev(src, dst)
+	if tuple(src.shape) != tuple(dst.shape) or src.dim() != 2:
+		raise ValueError("convert_f64: 2-D tensors of equal shape")
+	check(_lib.load().anncur_convert_f64(_p(src), _DT64[src.dtype], src.stride(0), src.stride(1), _p(dst), _DT64[dst.dtype], dst.stride(0), dst.stride(1),
+										 src.shape[0], src.shape[1], float(alpha), _p(divide_by) if divide_by is not None else None, _stream()), "convert_f64")
+	return dst
+
+
+@_on_device
+def diff_sumsq_f64(X, Y=None, out=None):
+	"""-> device tensor [sum (X - Y)^2, sum X^2] (float64, no host sync); X, Y contiguous float64 of equal size."""
+	_dev(X)
+	if X.dtype != torch.float64 or not X.is_contiguous() or (Y is not None and (Y.dtype != torch.float64 or not Y.is_contiguous() or Y.numel() != X.numel())):
+		raise ValueError("diff_sumsq_f64: contiguous float64 tensors of equal size")
+	out = torch.empty(2, dtype=torch.float64, device=X.device) if out is None else out
+	check(_lib.load().anncur_diff_sumsq_f64(_p(X), _p(Y) if Y is not None else None, X.numel(), _p(out), _stream()), "diff_sumsq_f64")
+	return out
+
+
 @_on_device
 def approx_error(X, Et, A_exact):
 	"""Per-row sum_i (X.E - A)^2 and sum_i A^2 without materialising X.E

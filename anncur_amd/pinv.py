@@ -41,3 +41,50 @@ def pinv_newton_schulz(W, max_iters=80, check_every=4, rtol=1e-6):
 				break
 			prev = cur
 	return X
+
+
+def pinv_newton_schulz_f64(W, max_iters=64, check_from=6, rtol=1e-10, return_info=False):
+	"""Parity-grade pseudo-inverse: the same iteration in DOUBLE precision on the fp64 matrix cores (anncur_gemm_f64), the result
+	rounded to fp32 once.  W: [m x n] fp32 / bf16 on the GPU -> W^+ [n x m] fp32 on the GPU.
+
+	In fp64 the iteration resolves singular values down to ~2^-(iters/2) of the largest, i.e. it converges to the exact
+	pseudo-inverse of the fp32 matrix W for any conditioning the fp32 SVD of numpy.linalg.pinv can resolve; what separates the two
+	is then numpy's own fp32 round-off (~cond(W) * 6e-8).  Stops when ||X_k+1 - X_k||_F <= rtol ||X_k||_F (checked every second
+	iteration: one 16-byte D2H each), followed by one more (quadratically convergent) step.  64 iterations resolve cond(W) up to
+	~1e8: a block that has not converged by then is singular to fp32 precision (numpy then inverts singular values that are fp32
+	round-off, and so would this iteration, to different noise) -- info["converged"] is False and the caller (cur._pinv) hands such
+	a block to the host's LAPACK call, as the reference does.
+	info: iterations, cond_F = ||W||_F ||W^+||_F (>= cond_2: the caller's handle on how far numpy's fp32 SVD can be trusted)."""
+	m, n = W.shape
+	Wd = torch.empty((m, n), dtype=torch.float64, device=W.device)
+	ops.convert_f64(W, Wd)
+	norms = ops.diff_sumsq_f64(Wd)                          # [0, ||W||_F^2]
+	X = torch.empty((n, m), dtype=torch.float64, device=W.device)
+	ops.convert_f64(Wd.t(), X, 1.0, divide_by=norms[1:2])   # X_0 = W^T / ||W||_F^2
+	Xn = torch.empty_like(X)
+	tall = m >= n
+	P = torch.empty((n, n) if tall else (m, m), dtype=torch.float64, device=W.device)
+	chk = torch.empty(2, dtype=torch.float64, device=W.device)
+	w2 = None
+	its, final = 0, False
+	for it in range(max_iters):
+		if tall:
+			ops.gemm_f64(X, Wd, out=P)                                  # P = X W   [n x n]
+			ops.gemm_f64(P, X, out=Xn, alpha=-1.0, beta=2.0, cin=X)     # X' = 2 X - P X
+		else:
+			ops.gemm_f64(Wd, X, out=P)                                  # P = W X   [m x m]
+			ops.gemm_f64(X, P, out=Xn, alpha=-1.0, beta=2.0, cin=X)     # X' = 2 X - X P
+		X, Xn = Xn, X
+		its = it + 1
+		if final:
+			break
+		if it >= check_from and (it - check_from) % 2 == 0:
+			d2, x2 = ops.diff_sumsq_f64(X, Xn, out=chk).tolist()
+			if not (x2 > 0.0) or d2 <= (rtol * rtol) * x2:
+				final = True
+	out = torch.empty((n, m), dtype=torch.float32, device=W.device)
+	ops.convert_f64(X, out)
+	if return_info:
+		w2, x2 = float(norms[1].item()), float(ops.diff_sumsq_f64(X, out=chk)[1].item())
+		return out, {"iterations": its, "cond_F": (w2 * x2) ** 0.5, "converged": final}
+	return out

@@ -55,7 +55,7 @@ def plot(res_dir, method_vals):
 	return made
 
 
-def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overrides, dtype, device, pinv_backend="numpy", score_chunks=None):
+def run(base_res_dir, data_info, n_seeds, plot_only, misc, arg_dict, grid_overrides, dtype, device, pinv_backend="auto", score_chunks=None):
 	from anncur_amd import harness
 	data_name, data_fname = data_info
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,8 +144,9 @@ def main(argv=None):
 	parser.add_argument("--data_dir", type=str, default=data_dir)
 	parser.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"], help="storage/compute type of the score matrix on the GPU")
 	parser.add_argument("--device", type=str, default="cuda:0")
-	parser.add_argument("--pinv", type=str, default="numpy", choices=["numpy", "device"],
-						help="pseudo-inverse: the reference's numpy.linalg.pinv on the host (bit-identical U) or Newton-Schulz on the GPU")
+	parser.add_argument("--pinv", type=str, default="auto", choices=["numpy", "device", "auto", "device32"],
+						help="pseudo-inverse: numpy = the reference's numpy.linalg.pinv on the host (bit-identical U); device = fp64 Newton-Schulz on the GPU "
+							 "(exact pseudo-inverse of the fp32 block, rounded once); auto = device while the block is well conditioned, else numpy")
 	parser.add_argument("--score_chunks", type=str, nargs="+", default=None,
 						help="the producer's per-chunk score pickles (mention order) instead of the combined file: ingested chunk by chunk, row-sharded under torchrun")
 	args = parser.parse_args(argv)

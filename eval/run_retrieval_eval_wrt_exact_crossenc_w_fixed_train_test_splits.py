@@ -130,8 +130,9 @@ def main(argv=None):
 	parser.add_argument("--entity_embeds_file", type=str, default="")
 	parser.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "bf16"])
 	parser.add_argument("--device", type=str, default="cuda:0")
-	parser.add_argument("--pinv", type=str, default="numpy", choices=["numpy", "device"],
-						help="pseudo-inverse: the reference's numpy.linalg.pinv on the host (bit-identical U) or Newton-Schulz on the GPU")
+	parser.add_argument("--pinv", type=str, default="auto", choices=["numpy", "device", "auto", "device32"],
+						help="pseudo-inverse: numpy = the reference's numpy.linalg.pinv on the host (bit-identical U); device = fp64 Newton-Schulz on the GPU "
+							 "(exact pseudo-inverse of the fp32 block, rounded once); auto = device while the block is well conditioned, else numpy")
 	args = parser.parse_args(argv)
 	_ = get_dataset_info(data_dir="../../data/zeshel", res_dir=args.res_dir, worlds=worlds)  # kept for parity with the reference's main()
 	LOGGER.info(f"Running inference for world = {args.data_name}")

@@ -30,6 +30,7 @@ extern "C" {
 
 #define ANNCUR_F32  0
 #define ANNCUR_BF16 1
+#define ANNCUR_F64  2            /* only the fp64 helpers of the on-device pseudo-inverse take it */
 
 #define ANNCUR_OK            0
 #define ANNCUR_E_INVALID    -1   /* bad argument (shape, dtype, alignment, k range) */
@@ -87,6 +88,20 @@ int anncur_gemm_ex(const void *A, int a_dtype, int64_t a_sm, int64_t a_sk,
 int anncur_sumsq(const float *A, int64_t n_rows, int64_t n_cols, int64_t lda, float *out, void *stream);
 int anncur_scale_copy(const float *src, int64_t s0, int64_t s1, float *dst, int64_t d0, int64_t d1, int64_t M, int64_t N,
                       float alpha, const float *divide_by, void *stream);
+
+/* fp64 building blocks of the PARITY-GRADE on-device pseudo-inverse (anncur_amd/pinv.py, Newton-Schulz X <- X (2 I - W X) in
+ * double precision, rounded to fp32 once at the end): replaces the host call
+ *   U = numpy.linalg.pinv(W)                 eval/matrix_approx_zeshel.py:47,49
+ * when the caller asks for it (pinv_backend "device" / "auto").  Strided like anncur_gemm_ex; products and sums in fp64 on
+ * v_mfma_f64_16x16x4_f64.  anncur_convert_f64: dst(i,j) = alpha / (divide_by ? divide_by[0] : 1) * src(i,j) for the dtype pairs
+ * F32->F64, BF16->F64, F64->F64 (scaled copy / transpose) and F64->F32 (one rounding).  anncur_diff_sumsq_f64:
+ * out2 = {sum (x - y)^2, sum x^2} over n contiguous doubles (y may be NULL), device doubles, no host synchronisation. */
+int anncur_gemm_f64(const double *A, int64_t a_sm, int64_t a_sk, const double *B, int64_t b_sk, int64_t b_sn,
+                    double *C, int64_t c_sm, int64_t c_sn, int64_t M, int64_t N, int64_t K,
+                    double alpha, double beta, const double *Cin, int64_t i_sm, int64_t i_sn, void *stream);
+int anncur_convert_f64(const void *src, int src_dtype, int64_t s0, int64_t s1, void *dst, int dst_dtype, int64_t d0, int64_t d1,
+                       int64_t M, int64_t N, double alpha, const double *divide_by, void *stream);
+int anncur_diff_sumsq_f64(const double *X, const double *Y, int64_t n, double *out2, void *stream);
 
 /* a11: approximation error without materialising S_hat ------------------------------
  * err_sq[q] = sum_i (X[q,:].E[:,i] - A[q,i])^2 , norm_sq[q] = sum_i A[q,i]^2

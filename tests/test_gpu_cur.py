@@ -129,20 +129,98 @@ def test_protocol_b_golden_fp32_and_bf16(CUR, golden_dir, golden_meta):
 		assert gotb[(k, 100)][key] == pytest.approx(gold[str(k)][key], abs=5e-3), k
 
 
-@pytest.mark.parametrize("m,n,rank,noise", [(512, 256, 64, 0.05), (256, 512, 64, 0.05), (300, 120, 300, 1.0), (200, 200, 20, 0.0)])
-def test_device_pinv_newton_schulz_matches_numpy(CUR, m, n, rank, noise):
-	"""On-device pseudo-inverse vs numpy.linalg.pinv: well-conditioned tall / wide / full-rank cases to ~cond*eps, and an exactly
-	rank-deficient case (rank 20 of 200) against numpy's pinv with the matching cut-off."""
-	from anncur_amd.pinv import pinv_newton_schulz
+def test_gemm_f64_exact_on_integers_any_strides(CUR):
+	"""fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64): exact on integer data with an ASYMMETRIC right operand (a transposed C/D map would
+	show), transposed views, alpha / beta / cin, ragged edges."""
+	from anncur_amd import ops
+	g = torch.Generator().manual_seed(1)
+	A = torch.randint(-9, 10, (150, 77), generator=g).double().cuda()
+	B = (torch.arange(77 * 130).reshape(77, 130) % 23 - 7).double().cuda()        # B[i][j] depends on i and j differently
+	want = A @ B
+	assert torch.equal(ops.gemm_f64(A, B), want)
+	assert torch.equal(ops.gemm_f64(B.t(), A.t()), want.t())                       # both operands as transposed views
+	Cin = torch.randint(-5, 6, (150, 130), generator=g).double().cuda()
+	assert torch.equal(ops.gemm_f64(A, B, alpha=-1.0, beta=2.0, cin=Cin), 2 * Cin - want)
+	out = torch.zeros(130, 150, dtype=torch.float64, device="cuda")
+	ops.gemm_f64(A, B, out=out.t())                                               # transposed output view
+	assert torch.equal(out, want.t())
+	X = torch.randn(64, 64, generator=g).double().cuda()
+	torch.testing.assert_close(ops.gemm_f64(X, X), X @ X, rtol=1e-13, atol=1e-13)
+	d = ops.diff_sumsq_f64(A.contiguous(), (A + 1).contiguous()).cpu()
+	assert d[0].item() == A.numel() and d[1].item() == (A * A).sum().item()
+	f32 = torch.empty(150, 77, dtype=torch.float32, device="cuda")
+	ops.convert_f64(A / 3, f32)
+	assert torch.equal(f32, (A / 3).float())                                       # one round-to-nearest
+
+
+@pytest.mark.parametrize("m,n,rank,noise", [(512, 256, 64, 0.05), (256, 512, 64, 0.05), (300, 120, 300, 1.0), (200, 200, 20, 0.0), (2048, 1024, 64, 0.05)])
+def test_device_pinv_f64_is_the_exact_pseudo_inverse(CUR, m, n, rank, noise):
+	"""fp64 Newton-Schulz vs the pseudo-inverse of the SAME fp32 matrix computed in fp64 by LAPACK: agreement to fp32 rounding
+	of the result (1e-7), for tall / wide / full-rank / exactly rank-deficient blocks and the 2048 x 1024 block of cfg5."""
+	from anncur_amd.pinv import pinv_newton_schulz_f64
 	g = torch.Generator().manual_seed(m + n)
-	W = torch.randn(m, min(rank, m, n), generator=g) @ torch.randn(min(rank, m, n), n, generator=g) / rank ** 0.5 + noise * torch.randn(m, n, generator=g)
-	X = pinv_newton_schulz(W.cuda()).cpu().double()
-	rc = 1e-15 if noise > 0 else 1e-5
-	ref = torch.from_numpy(np.linalg.pinv(W.double().numpy(), rcond=rc))
+	r = min(rank, m, n)
+	W = torch.randn(m, r, generator=g) @ torch.randn(r, n, generator=g) / rank ** 0.5 + noise * torch.randn(m, n, generator=g)
+	X, info = pinv_newton_schulz_f64(W.cuda(), return_info=True)
+	X = X.cpu().double()
+	if noise == 0:
+		# rank 20 of 200, stored in fp32: the other 180 singular values are round-off (1e-8 sigma_max).  The iteration reports
+		# "not converged" and the operator hands the block to the host call (bit-identical to the reference by construction)
+		assert not info["converged"]
+		ri = list(range(m)); ci = list(range(n))
+		a = CUR(rows=W, cols=W, row_idxs=ri, col_idxs=ci, approx_preference="rows", pinv_backend="numpy")
+		b = CUR(rows=W, cols=W, row_idxs=ri, col_idxs=ci, approx_preference="rows", pinv_backend="device")
+		assert torch.equal(a.U, b.U)
+		return
+	ref = torch.from_numpy(np.linalg.pinv(W.double().numpy(), rcond=1e-15))
 	rel = ((X - ref).norm() / ref.norm()).item()
-	assert rel < 2e-3, rel
+	assert info["converged"] and rel < 2e-7, (rel, info)
 	Wd = W.double()
-	assert ((Wd @ X @ Wd - Wd).norm() / Wd.norm()).item() < 1e-4          # Moore-Penrose condition W X W = W
+	assert ((Wd @ X @ Wd - Wd).norm() / Wd.norm()).item() < 1e-6          # Moore-Penrose condition W X W = W
+
+
+@pytest.mark.parametrize("tag", ["lr_64x200", "lr_200x1000", "protoB"])
+def test_device_pinv_f64_meets_the_score_tolerance_on_the_goldens(CUR, golden_dir, tag):
+	"""||U_dev - U_numpy|| / ||U|| <= 1e-5 and S_hat within 1e-4 of the reference's on the golden cases, with
+	pinv_backend="device" and "auto" (which must keep the device result here: the blocks are well conditioned)."""
+	from oracle import cur_oracle as O
+	if tag == "protoB":
+		A_train, A_test = O.synth_protocol_b(500, 2000, 20000, rank=64, noise=0.05, seed=0)
+		g = np.load(os.path.join(golden_dir, "protoB_2000x20000.npz"))
+		anc = g["anc"].tolist()
+		ref = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(500), col_idxs=anc, approx_preference="rows", pinv_backend="numpy")
+		for backend in ("device", "auto"):
+			cur = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(500), col_idxs=anc, approx_preference="rows", pinv_backend=backend)
+			assert ((cur.U - ref.U).norm() / ref.U.norm()).item() <= 1e-5
+			_close(cur.U[:8, :8], g["U_sample"], atol=1e-5)
+			tv, ti = cur.topk_in_row(A_test[:, anc], 100)
+			_close(tv, g["approx_topk_val"], rtol=1e-4, atol=1e-4)
+			common = np.mean([len(set(a) & set(b)) / 100 for a, b in zip(ti.numpy().tolist(), g["approx_topk_idx"].tolist())])
+			assert common > 0.9995, common
+		return
+	g = np.load(os.path.join(golden_dir, f"{tag}.npz"))
+	A = torch.tensor(g["A"]); ri, ci = g["row_idxs"].tolist(), g["col_idxs"].tolist()
+	n, m = A.shape
+	for backend in ("device", "auto"):
+		for method, extra in (("cur", {}), ("cur_oracle", {"A": A})):
+			cur = CUR(rows=A[ri, :], cols=A[:, ci], row_idxs=ri, col_idxs=ci, approx_preference="rows", pinv_backend=backend, **extra)
+			relU = np.linalg.norm(cur.U.numpy() - g[f"{method}_U"]) / np.linalg.norm(g[f"{method}_U"])
+			S = cur.get(list(range(n)), list(range(m)))
+			relS = np.linalg.norm(S.numpy() - g[f"{method}_S"]) / np.linalg.norm(g[f"{method}_S"])
+			assert relU <= (1e-5 if method == "cur" else 1e-4), (backend, method, relU)   # (cur_oracle's U is a product of two pinvs with A)
+			assert relS < 1e-4, (backend, method, relS)
+
+
+def test_pinv_auto_goes_to_the_host_call_when_ill_conditioned(CUR):
+	"""As many anchor rows as anchor columns of a rank-32 + noise matrix: numpy inverts singular values that are fp32 noise and
+	the reference's numbers are made of that noise -- "auto" must return numpy's U bit for bit there."""
+	torch.manual_seed(0)
+	A = torch.randn(300, 32) @ torch.randn(32, 2000) / (32 ** 0.5) + 1e-4 * torch.randn(300, 2000)
+	rng = np.random.default_rng(0)
+	ri, ci = sorted(rng.choice(300, 64, replace=False)), sorted(rng.choice(2000, 64, replace=False))
+	a = CUR(rows=A[ri, :], cols=A[:, ci], row_idxs=ri, col_idxs=ci, approx_preference="rows", pinv_backend="numpy")
+	b = CUR(rows=A[ri, :], cols=A[:, ci], row_idxs=ri, col_idxs=ci, approx_preference="rows", pinv_backend="auto")
+	assert torch.equal(a.U, b.U)
 
 
 def test_device_pinv_backend_gives_same_retrieval(CUR):
@@ -151,8 +229,8 @@ def test_device_pinv_backend_gives_same_retrieval(CUR):
 	anc = sorted(np.random.default_rng(2).choice(20000, 192, replace=False))
 	a = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(400), col_idxs=anc, approx_preference="rows")
 	b = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(400), col_idxs=anc, approx_preference="rows", pinv_backend="device")
-	assert ((a.U - b.U).norm() / a.U.norm()).item() < 1e-3
+	assert ((a.U - b.U).norm() / a.U.norm()).item() < 1e-5
 	Sa, Sb = a.get_complete_row(A_test[:, anc]), b.get_complete_row(A_test[:, anc])
-	assert ((Sa - Sb).norm() / Sa.norm()).item() < 1e-3
+	assert ((Sa - Sb).norm() / Sa.norm()).item() < 1e-5
 	ia = a.topk_in_row(A_test[:, anc], 50).indices.numpy(); ib = b.topk_in_row(A_test[:, anc], 50).indices.numpy()
-	assert np.mean([len(set(x) & set(y)) / 50 for x, y in zip(ia.tolist(), ib.tolist())]) > 0.995
+	assert np.mean([len(set(x) & set(y)) / 50 for x, y in zip(ia.tolist(), ib.tolist())]) > 0.9995

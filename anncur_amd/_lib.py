@@ -51,6 +51,9 @@ SIGNATURES = {
 	"anncur_rerank": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_overlap_counts": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, _p32, _p32, c_int32, c_void_p, c_void_p]),
 	"anncur_copy_bytes": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+	"anncur_ivf_build_lists": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+	"anncur_ivf_list_means": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+	"anncur_ivf_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_convert": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p]),
 }
 

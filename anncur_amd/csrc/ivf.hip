@@ -1,0 +1,177 @@
+// IVF-flat inner-product index on the GPU: the branch of build_flat_or_ivff_index that the reference takes above 11 000 vectors
+//   nlist = floor(sqrt(n)); nprobe = floor(sqrt(nlist) * probe_mult_factor); faiss.IndexIVFFlat(IndexFlatIP(d), d, nlist,
+//   METRIC_INNER_PRODUCT); train / add / search                                   models/nearest_nbr.py:40-52
+// FAISS is a third-party dependency the reference neither vendors nor pins (parity unpinned): this restates the published
+// algorithm -- k-means coarse quantiser (assignment by maximum inner product, centroid = mean of its points), inverted lists,
+// search = exact inner products inside the nprobe best lists -- and is judged on recall against the exact search.
+// The dense steps (points x centroids, queries x centroids + top-nprobe) run on anncur_gemm / anncur_rowwise_topk; this file holds
+// what is particular to the inverted file: list construction, centroid update, list scan.
+#include "select.hpp"
+
+using namespace anncur;
+
+namespace {
+
+// counts[l] = #{i : assign[i] == l}; one workgroup per list, a plain pass over the assignment (n * nlist int reads in all:
+// n = 1e6, nlist = 1000 -> 4 GB out of L2; deterministic, no atomics)
+__global__ __launch_bounds__(256) void ivf_count_kernel(const int32_t *__restrict__ assign, int64_t n, int32_t *__restrict__ counts) {
+	const int32_t l = blockIdx.x;
+	uint32_t c = 0;
+	for (int64_t i = threadIdx.x; i < n; i += 256) c += assign[i] == l;
+	for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+	__shared__ uint32_t part[4];
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) counts[l] = (int32_t)(part[0] + part[1] + part[2] + part[3]);
+}
+
+// offsets[0..nlist] = exclusive prefix sum of counts (single workgroup; nlist is ~sqrt(n))
+__global__ __launch_bounds__(256) void ivf_scan_counts_kernel(const int32_t *__restrict__ counts, int32_t nlist, int32_t *__restrict__ offsets) {
+	__shared__ int32_t carry;
+	__shared__ int32_t wsum[4];
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int32_t b = 0; b < nlist; b += 256) {
+		const int32_t i = b + threadIdx.x;
+		const int32_t c = i < nlist ? counts[i] : 0;
+		int32_t inc = c;
+		for (int d = 1; d < WAVE; d <<= 1) {
+			const int32_t t = __shfl_up(inc, d);
+			if (lane_id() >= d) inc += t;
+		}
+		if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
+		__syncthreads();
+		int32_t base = carry;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+		if (i < nlist) offsets[i] = base + inc - c;
+		__syncthreads();
+		if (threadIdx.x == 255) carry = base + inc;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) offsets[nlist] = carry;
+}
+
+// ids[offsets[l] ..] = the points of list l in ascending id order (stable: one workgroup per list, ordered compaction)
+__global__ __launch_bounds__(256) void ivf_fill_kernel(const int32_t *__restrict__ assign, int64_t n, const int32_t *__restrict__ offsets,
+													   int32_t *__restrict__ ids) {
+	const int32_t l = blockIdx.x;
+	__shared__ uint32_t wcnt[4];
+	uint32_t pos = (uint32_t)offsets[l];
+	for (int64_t b = 0; b < n; b += 256) {
+		const int64_t i = b + threadIdx.x;
+		const bool hit = i < n && assign[i] == l;
+		const unsigned long long m = __ballot(hit);
+		if (lane_id() == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+		__syncthreads();
+		uint32_t base = pos;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wcnt[w];
+		if (hit) ids[base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull))] = (int32_t)i;
+		pos += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+		__syncthreads();
+	}
+}
+
+// centroid[l] = mean of the rows of list l of Xs (vectors stored in list order), summed in list order (deterministic);
+// an empty list keeps its centroid.
+__global__ __launch_bounds__(256) void ivf_means_kernel(const float *__restrict__ Xs, int64_t ldx, int32_t d, const int32_t *__restrict__ offsets,
+														float *__restrict__ C, int64_t ldc) {
+	const int32_t l = blockIdx.x;
+	const int32_t beg = offsets[l], end = offsets[l + 1];
+	if (end == beg) return;
+	const float inv = 1.0f / (float)(end - beg);
+	for (int32_t c = threadIdx.x; c < d; c += 256) {
+		float s = 0.f;
+		for (int32_t i = beg; i < end; ++i) s += Xs[(int64_t)i * ldx + c];
+		C[(int64_t)l * ldc + c] = s * inv;
+	}
+}
+
+// One workgroup per query: exact inner products with every vector of its nprobe lists, streamed through the workgroup-level
+// selector.  Vectors are stored in list order with a row pitch that is a multiple of 16 floats (zero padded), the query likewise:
+// four lanes share one vector (each reads 16 bytes per step: 16 vectors x 64 contiguous bytes per wave-instruction).
+template <int KMAX>
+__global__ __launch_bounds__(SEL_THREADS) void ivf_scan_kernel(const float *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
+															   const int32_t *__restrict__ ids, const float *__restrict__ Q, int64_t ldq,
+															   const int32_t *__restrict__ probe, int32_t nprobe, uint32_t k,
+															   float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const SelState s = sel_carve<KMAX>(smem);
+	float *qs = reinterpret_cast<float *>(smem + SelCfg<KMAX>::LDS_BYTES);  // [dp]
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 3, slot = lane >> 2;
+	const int64_t qi = blockIdx.x;
+	for (int c = tid; c < dp; c += SEL_THREADS) qs[c] = Q[qi * ldq + c];
+	sel_init(s);  // (barrier inside)
+	float tau = -INFINITY;
+	uint64_t tau_key = 0;
+	int since = 0;
+	for (int32_t p = 0; p < nprobe; ++p) {
+		const int32_t l = probe[qi * nprobe + p];
+		if (l < 0) continue;  // (uniform)
+		const int32_t beg = offsets[l], end = offsets[l + 1];
+		for (int32_t v0 = beg; v0 < end; v0 += 64) {  // 4 waves x 16 vectors
+			const int32_t v = v0 + wave * 16 + slot;
+			const bool in = v < end;
+			const float4 *row = reinterpret_cast<const float4 *>(Xs + (int64_t)(in ? v : beg) * ldx) + sub;
+			const float4 *qv = reinterpret_cast<const float4 *>(qs) + sub;
+			float acc = 0.f;
+			for (int c = 0; c < dp / 16; ++c) {
+				const float4 x = row[4 * c], y = qv[4 * c];
+				acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+			}
+			acc += __shfl_xor(acc, 1);
+			acc += __shfl_xor(acc, 2);
+			const bool offer = in && sub == 0 && !(acc != acc);  // NaN scores are never selected
+			sel_offer(s, offer, acc, offer ? (uint32_t)ids[v] : 0u, tau, tau_key);
+			if (++since == 32) {  // <= 2048 pushes since the last check
+				since = 0;
+				sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+			}
+		}
+	}
+	sel_finish<KMAX>(s, k, out_val + qi * (int64_t)k, out_idx + qi * (int64_t)k);
+}
+
+}  // namespace
+
+extern "C" int anncur_ivf_build_lists(const int32_t *assign, int64_t n, int32_t nlist, int32_t *counts, int32_t *offsets, int32_t *ids, void *stream) {
+	ANNCUR_REQUIRE(n >= 0 && n < (int64_t)0x7fffffff && nlist >= 1 && nlist <= 65535 * 16, ANNCUR_E_INVALID, "ivf_build_lists: bad sizes");
+	ANNCUR_REQUIRE(counts && offsets && (n == 0 || (assign && ids)), ANNCUR_E_INVALID, "ivf_build_lists: null pointer");
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL(ivf_count_kernel, dim3((unsigned)nlist), dim3(256), 0, st, assign, n, counts);
+	hipLaunchKernelGGL(ivf_scan_counts_kernel, dim3(1), dim3(256), 0, st, counts, nlist, offsets);
+	if (n > 0) hipLaunchKernelGGL(ivf_fill_kernel, dim3((unsigned)nlist), dim3(256), 0, st, assign, n, offsets, ids);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_ivf_list_means(const float *Xs, int64_t ldx, int32_t d, const int32_t *offsets, int32_t nlist, float *centroids, int64_t ldc,
+									 void *stream) {
+	ANNCUR_REQUIRE(nlist >= 1 && d >= 1 && ldx >= d && ldc >= d, ANNCUR_E_INVALID, "ivf_list_means: bad sizes");
+	ANNCUR_REQUIRE(Xs && offsets && centroids, ANNCUR_E_INVALID, "ivf_list_means: null pointer");
+	hipLaunchKernelGGL(ivf_means_kernel, dim3((unsigned)nlist), dim3(256), 0, (hipStream_t)stream, Xs, ldx, d, offsets, centroids, ldc);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_ivf_scan(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, const float *Q, int64_t ldq,
+							   int64_t nq, const int32_t *probe, int32_t nprobe, int32_t k, float *out_val, int32_t *out_idx, void *stream) {
+	ANNCUR_REQUIRE(dp >= 16 && (dp % 16) == 0 && dp <= 16384 && ldx >= dp && (ldx % 4) == 0 && ldq >= dp && (ldq % 4) == 0, ANNCUR_E_INVALID,
+				   "ivf_scan: vectors and queries must be zero-padded to a multiple of 16 floats (dp=%d)", dp);
+	ANNCUR_REQUIRE(nq >= 0 && nq < (int64_t)0x7fffffff && nprobe >= 1 && k >= 1 && k <= ANNCUR_MAX_TOPK, ANNCUR_E_INVALID, "ivf_scan: bad sizes");
+	if (nq == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(Xs && offsets && ids && Q && probe && out_val && out_idx, ANNCUR_E_INVALID, "ivf_scan: null pointer");
+	ANNCUR_REQUIRE(((uintptr_t)Xs % 16) == 0 && ((uintptr_t)Q % 16) == 0, ANNCUR_E_INVALID, "ivf_scan: Xs and Q must be 16-byte aligned");
+	hipStream_t st = (hipStream_t)stream;
+	int rc;
+#define LAUNCH_IVF(KM)                                                                                                       \
+	do {                                                                                                                     \
+		const size_t lds = SelCfg<KM>::LDS_BYTES + (size_t)dp * 4;                                                           \
+		if ((rc = anncur_ensure_dyn_lds((const void *)ivf_scan_kernel<KM>, (int)lds)) != ANNCUR_OK) return rc;               \
+		hipLaunchKernelGGL((ivf_scan_kernel<KM>), dim3((unsigned)nq), dim3(SEL_THREADS), lds, st, Xs, ldx, dp, offsets, ids, Q, ldq, probe, \
+						   nprobe, (uint32_t)k, out_val, out_idx);                                                            \
+	} while (0)
+	if (k <= 128) LAUNCH_IVF(128); else if (k <= 512) LAUNCH_IVF(512); else LAUNCH_IVF(2048);
+#undef LAUNCH_IVF
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}

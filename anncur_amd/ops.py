@@ -486,6 +486,45 @@ def overlap_counts(a, b, pairs):
 	return out
 
 
+# ------------------------------------------------------------------ f3: inverted file
+@_on_device
+def ivf_build_lists(assign, nlist):
+	"""assign int32 [n] -> (counts int32 [nlist], offsets int32 [nlist + 1], ids int32 [n]: the points of each list, ascending)."""
+	_dev(assign)
+	assign = assign.to(torch.int32).contiguous()
+	n = assign.numel()
+	counts = torch.empty(nlist, dtype=torch.int32, device=assign.device)
+	offsets = torch.empty(nlist + 1, dtype=torch.int32, device=assign.device)
+	ids = torch.empty(n, dtype=torch.int32, device=assign.device)
+	check(_lib.load().anncur_ivf_build_lists(_p(assign), n, nlist, _p(counts), _p(offsets), _p(ids), _stream()), "ivf_build_lists")
+	return counts, offsets, ids
+
+
+@_on_device
+def ivf_list_means(Xs, offsets, centroids):
+	"""centroids[l] <- mean of the rows of list l of Xs (list-ordered fp32 vectors); empty lists keep theirs.  In place."""
+	_dev(Xs, offsets, centroids)
+	Xs = _rowmajor(Xs)
+	if Xs.dtype != torch.float32 or centroids.dtype != torch.float32 or centroids.stride(1) != 1:
+		raise TypeError("ivf_list_means takes fp32 row-major tensors")
+	check(_lib.load().anncur_ivf_list_means(_p(Xs), _ld(Xs), centroids.shape[1], _p(offsets), centroids.shape[0], _p(centroids), _ld(centroids), _stream()),
+		  "ivf_list_means")
+	return centroids
+
+
+@_on_device
+def ivf_scan(Xs, offsets, ids, Q, probe, k):
+	"""Exact inner products inside the probed lists + top-k.  Xs [n x dp], Q [nq x dp] fp32 zero-padded to dp (multiple of 16)."""
+	_dev(Xs, offsets, ids, Q, probe)
+	nq, dp = Q.shape
+	probe = probe.to(torch.int32).contiguous()
+	val = torch.empty((nq, k), dtype=torch.float32, device=Q.device)
+	idx = torch.empty((nq, k), dtype=torch.int32, device=Q.device)
+	check(_lib.load().anncur_ivf_scan(_p(Xs), _ld(Xs), dp, _p(offsets), _p(ids), _p(Q), _ld(Q), nq, _p(probe), probe.shape[1], k, _p(val), _p(idx), _stream()),
+		  "ivf_scan")
+	return TopK(val, idx)
+
+
 @_on_device
 def copy_to_mapped_host(src, pinned_host):
 	"""Device kernel copy of `src` (CUDA tensor) into a PINNED host tensor (mapped into the device address space by the HIP

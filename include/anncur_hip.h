@@ -194,6 +194,23 @@ int anncur_overlap_counts(const int32_t *a, int32_t la, const int32_t *b, int32_
                           const int32_t *ka, const int32_t *kb, int32_t n_pairs,
                           int32_t *common, void *stream);
 
+/* f3: IVF-flat inner-product index (the branch of build_flat_or_ivff_index above 11 000 vectors) -------------------------------
+ *   faiss.IndexIVFFlat(IndexFlatIP(d), d, nlist, METRIC_INNER_PRODUCT).train / .add / .search     models/nearest_nbr.py:40-52
+ * FAISS is not vendored nor pinned by the reference (parity unpinned): restated from the published algorithm, judged on recall
+ * against the exact search.  The dense steps (points x centroids, queries x centroids -> top-nprobe) are anncur_gemm +
+ * anncur_rowwise_topk; these three hold what is particular to the inverted file.
+ *  anncur_ivf_build_lists: assign int32[n] (list of every point) -> counts int32[nlist], offsets int32[nlist+1] (exclusive prefix),
+ *    ids int32[n] (points of list l at ids[offsets[l] .. offsets[l+1]) in ascending id order; deterministic, no atomics);
+ *  anncur_ivf_list_means: centroids[l] = mean of rows offsets[l]..offsets[l+1] of Xs (vectors stored in list order), summed in
+ *    list order; an empty list keeps its centroid (k-means update step);
+ *  anncur_ivf_scan: per query, exact inner products with every vector of its nprobe lists (probe int32[nq x nprobe], -1 = skip)
+ *    and the k best: out_val float[nq x k] descending, out_idx int32[nq x k] (ids of the points; (-inf, -1) where the probed lists
+ *    hold fewer than k vectors).  Xs / Q rows zero-padded to dp floats, dp a multiple of 16, 16-byte aligned. */
+int anncur_ivf_build_lists(const int32_t *assign, int64_t n, int32_t nlist, int32_t *counts, int32_t *offsets, int32_t *ids, void *stream);
+int anncur_ivf_list_means(const float *Xs, int64_t ldx, int32_t d, const int32_t *offsets, int32_t nlist, float *centroids, int64_t ldc, void *stream);
+int anncur_ivf_scan(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, const float *Q, int64_t ldq, int64_t nq,
+                    const int32_t *probe, int32_t nprobe, int32_t k, float *out_val, int32_t *out_idx, void *stream);
+
 /* dtype plumbing: fp32 <-> bf16 (round-to-nearest-even), strided 2-D ------------------ */
 int anncur_convert(const void *src, int src_dtype, int64_t lds_, void *dst, int dst_dtype, int64_t ldd,
                    int64_t n_rows, int64_t n_cols, void *stream);

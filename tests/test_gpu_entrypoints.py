@@ -121,7 +121,7 @@ def test_flat_ip_index_matches_exact_search(gpu, n, d, nq, k, dtype):
 	X = g.standard_normal((n, d)).astype(np.float32); q = g.standard_normal((nq, d)).astype(np.float32)
 	if dtype == "bf16":
 		X = torch.tensor(X).bfloat16().float().numpy(); q = torch.tensor(q).bfloat16().float().numpy()
-	index = build_flat_or_ivff_index(torch.tensor(X), force_exact_search=False, dtype=dtype)
+	index = build_flat_or_ivff_index(torch.tensor(X), force_exact_search=n > 11000, dtype=dtype)   # (above 11 000 the default is IVF-flat)
 	D, I = index.search(q, k)
 	assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, k)
 	rD, rI = O.flat_ip_search(X, q, min(k, n))
@@ -130,6 +130,59 @@ def test_flat_ip_index_matches_exact_search(gpu, n, d, nq, k, dtype):
 	assert common > 0.999
 	if k > n:
 		assert (I[:, n:] == -1).all() and np.isinf(D[:, n:]).all()
+
+
+def test_ivf_flat_index_branch(gpu):
+	"""models/nearest_nbr.py:40-52: above 11 000 vectors the reference builds IndexIVFFlat(nlist = floor(sqrt(n)), nprobe =
+	floor(sqrt(nlist) * mult)).  FAISS is absent (parity unpinned): the GPU index is checked for its defining properties and
+	judged on recall against the exact search."""
+	from models.nearest_nbr import build_flat_or_ivff_index
+	from anncur_amd.nearest_nbr import IVFFlatIPIndex, FlatIPIndex
+	from oracle import cur_oracle as O
+	g = np.random.default_rng(7)
+	n, d, nq, k = 40000, 96, 200, 10
+	centers = g.standard_normal((64, d)).astype(np.float32) * 2                      # clustered data, like entity embeddings
+	X = (centers[g.integers(0, 64, n)] + g.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+	q = (centers[g.integers(0, 64, nq)] + g.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+	index = build_flat_or_ivff_index(X, force_exact_search=False)
+	assert isinstance(index, IVFFlatIPIndex) and index.nlist == 200 and index.nprobe == 14 and index.ntotal == n and index.is_trained
+	assert isinstance(build_flat_or_ivff_index(X, force_exact_search=True), FlatIPIndex)
+	assert isinstance(build_flat_or_ivff_index(X[:11000], force_exact_search=False), FlatIPIndex)
+	assert build_flat_or_ivff_index(X, False, probe_mult_factor=2).nprobe == 28
+	D, I = index.search(q, k)
+	assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, k) and (I >= 0).all()
+	assert (D[:, :-1] >= D[:, 1:]).all()
+	np.testing.assert_allclose(D, np.take_along_axis(q @ X.T, I, axis=1), rtol=1e-5, atol=1e-4)   # reported scores are the true inner products
+	# every list is complete and disjoint; the search equals a brute-force search restricted to the probed lists
+	off, ids = index._offsets.cpu().numpy(), index._ids.cpu().numpy()
+	assert off[0] == 0 and off[-1] == n and (np.sort(ids) == np.arange(n)).all()
+	C = index.centroids.cpu().numpy()
+	assign = np.empty(n, dtype=np.int64)
+	for l in range(index.nlist):
+		assign[ids[off[l]:off[l + 1]]] = l
+	assert (np.argmax(X @ C.T, axis=1) == assign).mean() > 0.999                       # each vector sits in its max-inner-product list (fp32 near-ties aside)
+	probe = np.argsort(-(q @ C.T), axis=1)[:, :index.nprobe]
+	for j in range(0, nq, 17):
+		cand = np.concatenate([ids[off[l]:off[l + 1]] for l in probe[j]])
+		want = cand[np.argsort(-(X[cand] @ q[j]), kind="stable")[:k]]
+		assert len(set(want.tolist()) & set(I[j].tolist())) >= k - 1                   # (a boundary near-tie may swap)
+	# recall against the exact search, and exact equality when every list is probed
+	rD, rI = O.flat_ip_search(X, q, k)
+	recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(I.tolist(), rI.tolist())])
+	assert recall > 0.9, recall
+	index.nprobe = index.nlist
+	D2, I2 = index.search(q, k)
+	np.testing.assert_allclose(D2, rD, rtol=1e-5, atol=1e-4)
+	assert np.mean([len(set(a) & set(b)) / k for a, b in zip(I2.tolist(), rI.tolist())]) > 0.999
+	# FAISS convention when the probed lists hold fewer than k vectors: (-inf, -1) padding
+	index.nprobe = 1
+	D3, I3 = index.search(q[:4], 1000)
+	sizes = np.diff(off)[probe[:4, 0]]
+	for j in range(4):
+		assert (I3[j, :sizes[j]] >= 0).all() and (I3[j, sizes[j]:] == -1).all() and np.isinf(D3[j, sizes[j]:]).all()
+	# determinism: the same seed builds the same index
+	again = build_flat_or_ivff_index(X, force_exact_search=False)
+	assert torch.equal(again.centroids, index.centroids) and torch.equal(again._ids, index._ids)
 
 
 # ------------------------------------------------------------------ row-sharded evaluation: 2 ranks sharing the one GPU, gloo

@@ -25,6 +25,7 @@
 //                  split swept; nothing leaves the call inexact.
 // Algorithmic work: 2*Q*Kp*I flops in (3) (+ sample fraction in (1)).
 #include <stdlib.h>
+#include <math.h>
 #include <type_traits>
 #include "select.hpp"
 #include "wave_select.hpp"
@@ -143,7 +144,7 @@ __device__ __forceinline__ void lds_store_2x32(uint32_t addr, uint32_t lo, uint3
 // (items past I of the matrix' last, partial tile; a count above D = the ring wrapped = overflow).
 // Measured on cfg2 (MI355X): branch version 0.58 ms per sweep, predicated version 0.655 ms independent of the hit rate (its
 // compare -> exec -> store chain sits in front of the wave's next MFMA) -> the branch version is the one in use.
-constexpr bool STAGGER_PREDICATED = false;
+// (plan_stages picks the variant per sweep stage from the expected hit rate: predicated above ~0.5 taken branches per compare)
 template <int D, bool FILTER_PREDICATED = false>
 __device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t item0, uint32_t lq, uint32_t &qcnt) {
 	static_assert((D & (D - 1)) == 0, "queue depth must be a power of two");
@@ -232,7 +233,7 @@ __device__ __forceinline__ void lds_wait_frag(u32x4 &frag, int pending) {  // `p
 //   steps K..2K-1  : acc1 (sub-tile 1 of this tile)  ||  filter of accA
 // The A fragments (same K fragments for both halves) stream through one ring of AR registers, AR-1 steps ahead, without a
 // break between the halves.  CUR = tile buffer parity (compile-time: an immediate offset of the LDS reads).
-template <int KP, int CUR>
+template <int KP, int CUR, bool PRED>
 __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>::KSTEPS], const bf16x8 (&xb)[2][FusedCfg<KP>::KSTEPS],
 											  f32x16 &acc1, float tau0, float tau1_prev, uint32_t item0, uint32_t item0_prev,
 											  uint32_t lq0, uint32_t lq1, uint32_t &q0, uint32_t &q1) {
@@ -261,21 +262,22 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 			accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][g], accA, 0, 0, 0);
 #pragma unroll
 			for (int e = (g == 1 ? 0 : g) * EPS; e < (g == 0 ? 0 : g + 1) * EPS; ++e)
-				filter_one<Cfg::QDEPTH, STAGGER_PREDICATED>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
+				filter_one<Cfg::QDEPTH, PRED>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
 		} else {
 			// no filter in the first step of the half: accA's last MFMA is still in the pipe (and the predicated filter is
 			// inline asm, invisible to the compiler's MFMA -> VALU hazard handling); step 1 takes two groups instead
 			accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[1][g - K], accB, 0, 0, 0);
 #pragma unroll
 			for (int e = (g - K == 1 ? 0 : g - K) * EPS; e < (g == K ? 0 : g - K + 1) * EPS; ++e)
-				filter_one<Cfg::QDEPTH, STAGGER_PREDICATED>(accA[e], e, tau0, item0, lq0, q0);
+				filter_one<Cfg::QDEPTH, PRED>(accA[e], e, tau0, item0, lq0, q0);
 		}
 	}
 	acc1 = accB;
 }
 
-// MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep.
-template <int KP, int MODE, int GROUP>
+// MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep (PRED: branch-free filter, for stages in
+// which most compares find a survivor in some lane -- large k).
+template <int KP, int MODE, int GROUP, bool PRED = false>
 __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	using Cfg = FusedCfg<KP>;
 	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I);               \
 			}                                                                                                                   \
 			const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * h;                                                              \
-			stagger_tile<KP, CUR>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1]);            \
+			stagger_tile<KP, CUR, PRED>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1]);            \
 			tau1_prev = tau[1]; item0_prev = item0;                                                                             \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
@@ -754,10 +756,12 @@ __global__ __launch_bounds__(SEL_THREADS) void tau_block_kernel(const uint2 *__r
 // No workgroup barrier.  Queries whose segments overflowed or that collected fewer than k candidates are appended to
 // hard_list for the workgroup-level kernel (which recomputes them exactly).
 constexpr int WQ_CAP = 1024;
-constexpr int WQ_TRIGGER = WQ_CAP - WAVE;
+constexpr int WQ_K2 = 512;  // largest k of the wave-level candidate select (8 keys per lane in the final sort, 2048-entry buffer)
+template <int KW> struct WqCfg { static constexpr int CAP = KW <= 128 ? WQ_CAP : 2048, TRIGGER = CAP - WAVE, E = KW / 64; };
 
 // TAU_ONLY (between sweep stages): no output, the query's threshold is raised to the k-th best candidate collected so far.
-template <bool TAU_ONLY>
+// KW = 128 or 512: capacity class of k.
+template <bool TAU_ONLY, int KW = 128>
 __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg,
 														   int capg, int64_t Q, uint32_t k, float *__restrict__ out_val,
 														   int32_t *__restrict__ out_idx, uint32_t *__restrict__ hard_cnt,
@@ -778,7 +782,8 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 		if (!TAU_ONLY && lane == 0) hard_list[atomicAdd(hard_cnt, 1u)] = (int32_t)q;
 		return;  // TAU_ONLY: keep the old (still valid) threshold
 	}
-	WaveSel w = wsel_init<WQ_CAP>(smem + wave * WaveSelLayout<WQ_CAP>::BYTES);
+	constexpr int CAP = WqCfg<KW>::CAP, TRIGGER = WqCfg<KW>::TRIGGER;
+	WaveSel w = wsel_init<CAP>(smem + wave * WaveSelLayout<CAP>::BYTES);
 	// the threshold the last sweep stage ran with is a valid lower bound on the k-th best: candidates of earlier stages below it
 	// are dropped at the load (at least k candidates are >= it by construction)
 	if (tau && prefilter) w.tau = tau[q * tau_stride];
@@ -797,14 +802,14 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 		const bool in = j < total;
 		const uint2 e = in ? qc[(int64_t)sg * capg + (j - ps)] : make_uint2(0u, 0u);
 		wsel_offer(w, in, __uint_as_float(e.x), e.y);
-		if (w.cnt > (uint32_t)WQ_TRIGGER) wsel_compact<4, false>(w, k);
+		if (w.cnt > (uint32_t)TRIGGER) wsel_compact<4, false>(w, k);
 	}
 	if (TAU_ONLY) {
 		if (w.cnt > k) wsel_compact<4, false>(w, k);
 		if (lane == 0 && w.cnt >= k) tau[q * tau_stride] = fmaxf(tau[q * tau_stride], w.tau);
 		return;
 	}
-	wsel_finish(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	wsel_finish<0, 4, WqCfg<KW>::E>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
 
 }  // namespace
@@ -817,7 +822,7 @@ namespace {
 struct FusedPlan {
 	bool ok;
 	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
-	int n_stages, stage_end[3], stage_tps[3], stage_flush[3];
+	int n_stages, stage_end[3], stage_tps[3], stage_flush[3], stage_pred[3];
 	int leading;
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, total;
 };
@@ -837,7 +842,7 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	P.n_stages = 1;
 	if (staged) {
 		const double H0 = exp_hits, c_hit = 2.4e-11 * (double)Q;
-		const double c_stage = k <= WSEL_K ? 25e-6 + 3e-9 * (double)Q : 25e-6 + 1.4e-11 * (double)Q * 0.3 * H0;
+		const double c_stage = k <= WSEL_K ? 25e-6 + 3e-9 * (double)Q : (k <= WQ_K2 ? 25e-6 + 1.2e-8 * (double)Q : 25e-6 + 1.4e-11 * (double)Q * 0.3 * H0);
 		auto later = [&](double f) { const double h = 1.2 * k / f; return h < H0 ? h : H0; };
 		double best = H0 * c_hit;
 		static const double grid[] = {0.02, 0.03, 0.04, 0.06, 0.08, 0.10, 0.12, 0.15, 0.18, 0.22, 0.26, 0.30, 0.35, 0.40, 0.50};
@@ -874,6 +879,10 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		P.stage_tps[i] = (end - prev + P.S - 1) / P.S;
 		int ft = (int)(0.5 / (rate > 1e-9 ? rate : 1e-9));
 		P.stage_flush[i] = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
+		// a compare covers 64 elements (32 queries x 2 items): with `rate` hits per 16 elements, 1 - exp(-4 rate) of the compares
+		// find a survivor in some lane.  Measured at cfg2 size: the branching filter costs 0.41 ms + ~0.5 ms per unit of that
+		// fraction, the predicated one 0.655 ms whatever the data -> predicated above 0.5 (k = 500: 0.82 -> 0.66 ms per sweep)
+		P.stage_pred[i] = (1.0 - exp(-4.0 * rate)) > 0.5 ? 1 : 0;
 		// next stage: threshold = k-th best of the fraction seen so far
 		rate = (double)k / ((double)end * unit_items) * 16.0 * 1.2;
 		prev = end;
@@ -925,7 +934,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
 	int ft = (int)(0.5 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-	plan_stages(P, Q, k, exp_hits, (k <= WSEL_K ? 2 * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
+	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? 2 * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
@@ -946,11 +955,16 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 int launch_tau_refine(const uint2 *cand, const uint32_t *seg_cnt, int nseg, int capg, int64_t Q, int k, int kmax, float *tau, int tau_stride,
 					  int prefilter, hipStream_t st) {
 	int rc;
-	if (k <= WSEL_K && nseg <= WAVE) {
-		if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<true>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
-		hipLaunchKernelGGL((select_wave_kernel<true>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, cand,
-						   seg_cnt, nseg, capg, Q, (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr,
-						   (int32_t *)nullptr, tau, tau_stride, prefilter);
+	if (k <= WQ_K2 && nseg <= WAVE) {
+#define LAUNCH_WTAU(KW)                                                                                                           \
+		do {                                                                                                                      \
+			constexpr int lds = 4 * WaveSelLayout<WqCfg<KW>::CAP>::BYTES;                                                         \
+			if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<true, KW>, lds)) != ANNCUR_OK) return rc;            \
+			hipLaunchKernelGGL((select_wave_kernel<true, KW>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, capg, Q, \
+							   (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, tau, tau_stride, prefilter); \
+		} while (0)
+		if (k <= WSEL_K) LAUNCH_WTAU(128); else LAUNCH_WTAU(512);
+#undef LAUNCH_WTAU
 	} else {
 #define LAUNCH_TAU(KM)                                                                                                        \
 		do {                                                                                                                  \
@@ -982,13 +996,18 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 	const int32_t *hard_list = nullptr;
 	const uint32_t *hard_cnt = nullptr;
 	unsigned sel_grid = (unsigned)Q;
-	if (k <= WSEL_K && nseg <= WAVE) {
+	if (k <= WQ_K2 && nseg <= WAVE) {
 		int32_t *hl = (int32_t *)(ws + P.off_hard);
 		uint32_t *hc = (uint32_t *)(ws + 4);
-		if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<false>, 4 * WaveSelLayout<WQ_CAP>::BYTES)) != ANNCUR_OK) return rc;
-		hipLaunchKernelGGL((select_wave_kernel<false>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), 4 * WaveSelLayout<WQ_CAP>::BYTES, st, cand,
-						   seg_cnt, nseg, P.capg, Q, (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride,
-						   P.n_stages > 1 ? 1 : 0);
+#define LAUNCH_WSEL(KW)                                                                                                           \
+		do {                                                                                                                      \
+			constexpr int lds = 4 * WaveSelLayout<WqCfg<KW>::CAP>::BYTES;                                                         \
+			if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<false, KW>, lds)) != ANNCUR_OK) return rc;           \
+			hipLaunchKernelGGL((select_wave_kernel<false, KW>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, P.capg, Q, \
+							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0); \
+		} while (0)
+		if (k <= WSEL_K) LAUNCH_WSEL(128); else LAUNCH_WSEL(512);
+#undef LAUNCH_WSEL
 		ANNCUR_LAUNCH_OK();
 		hard_list = hl; hard_cnt = hc;
 		sel_grid = (unsigned)(Q < 1024 ? Q : 1024);
@@ -1060,7 +1079,15 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			hipLaunchKernelGGL((score_kernel<KP, 2, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		} else
 #endif
-		hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+		bool launched = false;
+		if constexpr (Cfg::QT == 2) {  // (the predicated filter lives in the staggered path)
+			if (P.stage_pred[stg]) {
+				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score_kernel<KP, 1, 16, true>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+				launched = true;
+			}
+		}
+		if (!launched) hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
 		if (stg + 1 < P.n_stages &&
@@ -1105,7 +1132,7 @@ FusedPlan plan_wide(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
 	int S = slots / P.n_rb;
 	if (S < 1) S = 1;
 	if (S > 64) S = 64;
-	if (k <= WSEL_K && S > 16) S = 16;                 // 4 S <= 64 segments: wave-level refinement / select kernels
+	if (k <= WQ_K2 && S > 16) S = 16;                  // 4 S <= 64 segments: wave-level refinement / select kernels
 	if (S > P.n_tiles) S = P.n_tiles;
 	P.tiles_per_split = (P.n_tiles + S - 1) / S;
 	P.S = (P.n_tiles + P.tiles_per_split - 1) / P.tiles_per_split;
@@ -1123,7 +1150,7 @@ FusedPlan plan_wide(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
 	while (capg > 64 && (int64_t)capg * 4 * P.S >= (1 << 21)) capg >>= 1;  // a workgroup's 256 x 4 S segments span < 4 GiB (32-bit store offsets)
 	P.capg = capg;
 	P.flush_tiles = 1;
-	plan_stages(P, Q, k, exp_hits, (k <= WSEL_K ? 4 * P.S <= WAVE : true) && P.n_tiles >= 4 * P.S, 1.0 * P.S / P.n_tiles, WBM);
+	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? 4 * P.S <= WAVE : true) && P.n_tiles >= 4 * P.S, 1.0 * P.S / P.n_tiles, WBM);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);

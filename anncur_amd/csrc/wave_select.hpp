@@ -242,8 +242,49 @@ __device__ __forceinline__ void wave_sort128_desc(uint32_t (&hi)[2], uint32_t (&
 	}
 }
 
+// The same for E * 64 keys, E per lane (element i = e*64 + lane): strides below 64 are lane exchanges, strides of 64 and more
+// pair two registers of the same lane.  E = 8: the 512-key sort of the candidate select for 128 < k <= 512.
+template <int E>
+__device__ __forceinline__ void wave_sort_desc(uint32_t (&hi)[E], uint32_t (&lo)[E]) {
+	const int lane = lane_id();
+#pragma unroll
+	for (int size = 2; size <= E * 64; size <<= 1) {
+#pragma unroll
+		for (int stride = size >> 1; stride > 0; stride >>= 1) {
+			if (stride >= 64) {
+				const int es = stride >> 6;
+#pragma unroll
+				for (int e = 0; e < E; ++e) {
+					if ((e & es) == 0) {
+						const int f = e | es;
+						const bool desc = ((e * 64) & size) == 0;  // (bits of the lane are below `size` here)
+						const uint64_t a = ((uint64_t)hi[e] << 32) | lo[e], b = ((uint64_t)hi[f] << 32) | lo[f];
+						if (desc ? (a < b) : (a > b)) {
+							const uint32_t th = hi[e], tl = lo[e];
+							hi[e] = hi[f]; lo[e] = lo[f]; hi[f] = th; lo[f] = tl;
+						}
+					}
+				}
+			} else {
+#pragma unroll
+				for (int e = 0; e < E; ++e) {
+					const uint32_t oh = __shfl_xor(hi[e], stride), ol = __shfl_xor(lo[e], stride);
+					const uint64_t mine = ((uint64_t)hi[e] << 32) | lo[e], other = ((uint64_t)oh << 32) | ol;
+					const int i = e * 64 + lane;
+					const bool desc = (i & size) == 0;
+					const bool lower = (lane & stride) == 0;
+					const bool keep_max = (desc == lower);
+					const bool take_other = keep_max ? (other > mine) : (other < mine);
+					if (take_other) { hi[e] = oh; lo[e] = ol; }
+				}
+			}
+		}
+	}
+}
+
 // Reduce to the k best, sort them, write the output row.  Fewer than k candidates -> (-inf, -1) padding.
-template <int OUTLINED_CAP = 0, int HI_PASSES = 4>
+// E = keys per lane of the final sort (k <= 64 E).
+template <int OUTLINED_CAP = 0, int HI_PASSES = 4, int E = 2>
 __device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx) {
 	const int lane = lane_id();
 	if (w.cnt > k) {
@@ -251,17 +292,18 @@ __device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_v
 		else wsel_compact<HI_PASSES, false>(w, k);
 	}
 	__builtin_amdgcn_wave_barrier();
-	uint32_t sh[2], sl[2];
+	uint32_t sh[E], sl[E];
 #pragma unroll
-	for (int e = 0; e < 2; ++e) {
+	for (int e = 0; e < E; ++e) {
 		const uint32_t i = (uint32_t)(e * WAVE + lane);
 		const bool in = i < w.cnt;
 		sh[e] = in ? w.whi[i] : 0u;
 		sl[e] = in ? w.wlo[i] : 0u;
 	}
-	wave_sort128_desc(sh, sl);
+	if constexpr (E == 2) wave_sort128_desc(sh, sl);
+	else wave_sort_desc<E>(sh, sl);
 #pragma unroll
-	for (int e = 0; e < 2; ++e) {
+	for (int e = 0; e < E; ++e) {
 		const uint32_t i = (uint32_t)(e * WAVE + lane);
 		if (i < k) {
 			const bool real = i < w.cnt;

@@ -453,6 +453,8 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	}
 }
 
+#include "score16.hpp"
+
 // ------------------------------------------------------------------ a11: approximation error on the same MFMA loop
 // err_sq[q] += sum_i (S_hat[q,i] - A[q,i])^2, norm_sq[q] += sum_i A[q,i]^2 over this workgroup's item tiles; S_hat is never
 // written.  Same orientation as the sweep: lane = query, so both sums are lane-local accumulators and the exact matrix is read
@@ -824,6 +826,7 @@ struct FusedPlan {
 	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
 	int n_stages, stage_end[3], stage_tps[3], stage_flush[3], stage_pred[3];
 	int leading;
+	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves) or 4 (16x16x32 sweep: lane groups)
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, total;
 };
 
@@ -889,7 +892,7 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	}
 }
 
-FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
+FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false) {
 	FusedPlan P{};
 	P.ok = false;
 	P.leading = leading ? 1 : 0;
@@ -908,7 +911,10 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 	if ((int64_t)P.n_st * 4 > P.n_full) return P;  // problem too small for the fused path: use dense GEMM + scan
 	P.n_groups = P.n_st * (P.group == 16 ? 2 : 8);
 	if (P.n_groups < k) return P;
-	const int slots = 2 * num_cu();
+	int slots = 2 * num_cu();
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (getenv("ANNCUR_DEBUG_ONE_WG")) slots = num_cu();  // one sweep workgroup per CU (co-residence experiment)
+#endif
 	int S = slots / P.n_rb;
 	if (S < 1) S = 1;
 	if (S > 256) S = 256;
@@ -920,12 +926,19 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 	if (S0 > P.n_st) S0 = P.n_st;
 	P.st_per_split = (P.n_st + S0 - 1) / S0;
 	P.S0 = (P.n_st + P.st_per_split - 1) / P.st_per_split;
-	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over 2 S lane segments
+	// sweep variant: the 16x16x32 kernel (score16.hpp, ANNCUR_TOPK_MFMA16) where its four segments per split still fit the
+	// wave-level select; the default is the 32x32x16 kernel (measured on MI355X at cfg2 size: the 16x16 loop is 5.8 % faster
+	// without survivors, 1208 vs 1142 TFLOP/s, and level with them, 0.576-0.589 vs 0.574-0.579 ms: its flush serves four queries per lane)
+	P.lg = (mfma16 && KP <= 256 && I < (int64_t)(1 << 29) && (k > WQ_K2 || 4 * P.S <= WAVE)) ? 4 : 2;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (getenv("ANNCUR_DEBUG_MFMA16") && KP <= 256 && I < (int64_t)(1 << 29) && (k > WQ_K2 || 4 * P.S <= WAVE)) P.lg = 4;
+#endif
+	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over lg S lane segments
 	// (segment capacity -- hence the workspace size -- is planned for the strided sample whatever the hint; with item rows ordered
 	//  by descending norm the leading sample's threshold lets ~40 % fewer elements through: measured on the synthetic protocol)
 	const double exp_hits_cap = 1.3 * k * ((double)P.n_tiles / P.n_st);
 	const double exp_hits = (leading ? 0.65 : 1.0) * exp_hits_cap;
-	const double per_seg = exp_hits_cap / (2.0 * P.S);
+	const double per_seg = exp_hits_cap / ((double)P.lg * P.S);
 	int capg = next_pow2((int)(4.0 * per_seg) + 32);
 	if (capg < 64) capg = 64;
 	if (capg > 16384) capg = 16384;
@@ -934,16 +947,16 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false) 
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
 	int ft = (int)(0.5 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? 2 * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
+	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
 	P.off_tval = off;   off = align256(off + (size_t)Q * k * 4);
 	P.off_tidx = off;   off = align256(off + (size_t)Q * k * 4);
-	P.off_segcnt = off; off = align256(off + (size_t)Q * 2 * P.S * 4);
+	P.off_segcnt = off; off = align256(off + (size_t)Q * P.lg * P.S * 4);
 	P.off_tau = off;    off = align256(off + (size_t)Q * 4);
 	P.off_hard = off;   off = align256(off + (size_t)Q * 4);
-	P.off_cand = off;   off = align256(off + (size_t)Q * 2 * P.S * (size_t)P.capg * 8);
+	P.off_cand = off;   off = align256(off + (size_t)Q * P.lg * P.S * (size_t)P.capg * 8);
 	P.total = off;
 	P.ok = true;
 	return P;
@@ -1069,29 +1082,45 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
+		bool launched = false;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
 		if (getenv("ANNCUR_DEBUG_GEMM_NOSYNC")) {  // MFMA + LDS fragment reads, no staging, no barriers
 			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 3, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 			hipLaunchKernelGGL((score_kernel<KP, 3, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+			launched = true;
 		} else if (getenv("ANNCUR_DEBUG_GEMM_ONLY")) {  // no candidates are produced
 			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 2, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 			hipLaunchKernelGGL((score_kernel<KP, 2, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
-		} else
+			launched = true;
+		}
 #endif
-		bool launched = false;
+		if constexpr (KP <= 256) {  // 16x16x32 sweep (score16.hpp): four lane groups -> 4 S segments per query
+			if (!launched && P.lg == 4) {
+				if ((rc = anncur_ensure_dyn_lds((const void *)score16_kernel<KP>, Fused16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score16_kernel<KP>), dim3(p.n_wg), dim3(256), Fused16Cfg<KP>::LDS_BYTES, st, p);
+				launched = true;
+			}
+		}
 		if constexpr (Cfg::QT == 2) {  // (the predicated filter lives in the staggered path)
-			if (P.stage_pred[stg]) {
+			if (!launched && P.stage_pred[stg]) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((score_kernel<KP, 1, 16, true>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 				launched = true;
 			}
 		}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (!launched && getenv("ANNCUR_DEBUG_ONE_WG")) {  // padded LDS request: a second workgroup does not fit on the CU
+			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16>, 84 * 1024)) != ANNCUR_OK) return rc;
+			hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), 84 * 1024, st, p);
+			launched = true;
+		}
+#endif
 		if (!launched) hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
 		if (stg + 1 < P.n_stages &&
-			(rc = launch_tau_refine(p.cand, p.seg_cnt, 2 * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
+			(rc = launch_tau_refine(p.cand, p.seg_cnt, P.lg * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
 			return rc;
 	}
 	EV(3);
@@ -1099,7 +1128,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	SweepStages stages{};
 	stages.n = P.n_stages;
 	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) { stages.begin[g] = prev; stages.end[g] = P.stage_end[g]; stages.tps[g] = P.stage_tps[g]; }
-	if ((rc = launch_select(P, 2 * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
+	if ((rc = launch_select(P, P.lg * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
 	EV(4);
 	return ANNCUR_OK;
 }
@@ -1223,15 +1252,16 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 }
 #undef EV
 
-FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
-	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading);
+FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false) {
+	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16);
 }
 
 }  // namespace
 
 extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
-	const FusedPlan P = plan_any(Q, I, Kp, k);
-	return P.ok ? P.total : 0;
+	const FusedPlan P = plan_any(Q, I, Kp, k), P16 = plan_any(Q, I, Kp, k, false, true);  // (whatever flags the call will carry)
+	if (!P.ok) return 0;
+	return P16.ok && P16.total > P.total ? P16.total : P.total;
 }
 
 extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
@@ -1250,8 +1280,8 @@ __global__ __launch_bounds__(256) void remap_ids_kernel(int32_t *__restrict__ id
 static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr) {
-	ANNCUR_REQUIRE((flags & ~ANNCUR_TOPK_LEADING_SAMPLE) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
-	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0);
+	ANNCUR_REQUIRE((flags & ~(ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16)) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
+	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
 				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512} or a multiple of 128 up to %d, "
 				   "1<=k<=%d, I large enough for a sampled threshold); use anncur_gemm + anncur_rowwise_topk",
@@ -1299,7 +1329,7 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 	constexpr int NEV = 11;  // 0..4 stage boundaries, 5..10 begin/end of up to three sweep launches
 	hipEvent_t ev[NEV];
 	for (int i = 0; i < NEV; ++i) ANNCUR_HIP_OK(hipEventCreate(&ev[i]));
-	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0);
+	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0);
 	int rc = score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, ev, flags, item_ids);
 	if (rc == ANNCUR_OK) {
 		hipError_t e = hipEventSynchronize(ev[4]);

@@ -442,14 +442,16 @@ template <> __device__ __forceinline__ uint16_t cvt<uint16_t, uint16_t>(uint16_t
 template <> __device__ __forceinline__ float cvt<uint16_t, float>(uint16_t x) { return bf16_bits_to_f32(x); }
 template <> __device__ __forceinline__ uint16_t cvt<float, uint16_t>(float x) { return f32_to_bf16_bits(x); }
 
-// out[r, j] = A[r, col_idx[j]]; one workgroup handles GR rows; anchor indices staged in LDS.
+// out[r, j] = A[r, col_idx[j]]: one WAVE per row, four rows per workgroup (a workgroup per row made the launch dispatch-bound:
+// 10 000 workgroups of one load per thread); the anchor indices come out of L1/L2, the reads are strided element loads.
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void gather_cols_kernel(const TS *__restrict__ A, int64_t n_rows, int64_t n_cols,
 														   int64_t lda, const int32_t *__restrict__ col_idx,
 														   int32_t n_idx, TD *__restrict__ out, int64_t ldo) {
-	const int64_t r = blockIdx.x;
+	const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_rows) return;
 	const TS *row = A + r * lda;
-	for (int j = threadIdx.x; j < n_idx; j += 256) {
+	for (int j = threadIdx.x & 63; j < n_idx; j += 64) {
 		const int32_t c = col_idx[j];
 		const bool in = c >= 0 && (int64_t)c < n_cols;
 		out[r * ldo + j] = in ? cvt<TS, TD>(row[c]) : cvt<float, TD>(0.f);
@@ -530,7 +532,10 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 	if (getenv("ANNCUR_DEBUG_BLOCK_SCAN")) wave_scan = false;
 #endif
 	if (wave_scan) {
-		const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
+		size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (const char *dbg = getenv("ANNCUR_DEBUG_SCAN_LDS")) lds = (size_t)atoi(dbg);  // occupancy experiment: larger request = fewer waves per SIMD
+#endif
 		const unsigned grid = (unsigned)ceil_div64(Q, 4);
 		uint32_t trig = ws_trigger((uint32_t)k);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
@@ -620,7 +625,7 @@ extern "C" int anncur_gather_cols(const void *A, int dtype, int64_t n_rows, int6
 	const int rc = dispatch2(dtype, dst_dtype, [&](auto *s, auto *d) {
 		using TS = std::remove_cv_t<std::remove_pointer_t<decltype(s)>>;
 		using TD = std::remove_pointer_t<decltype(d)>;
-		hipLaunchKernelGGL((gather_cols_kernel<TS, TD>), dim3((unsigned)n_rows), dim3(256), 0, st, (const TS *)A, n_rows,
+		hipLaunchKernelGGL((gather_cols_kernel<TS, TD>), dim3((unsigned)ceil_div64(n_rows, 4)), dim3(256), 0, st, (const TS *)A, n_rows,
 						   n_cols, lda, col_idx, n_idx, (TD *)out, ldo);
 		return 0;
 	});

@@ -159,6 +159,10 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
  *  item_ids (int32[I], may be NULL): out_idx reports item_ids[row of Et] instead of the row (undoes such a reordering; score
  *    ties are then ordered by row, not by id).  Same workspace as anncur_score_topk. */
 #define ANNCUR_TOPK_LEADING_SAMPLE 1
+/*  ANNCUR_TOPK_MFMA16 (Kp <= 256): run the sweep on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same result bit for bit up to
+ *    the order of exact score ties; the chip holds a higher clock on that shape: +6 % on the bare GEMM loop, level with the
+ *    default once survivors are collected -- kept selectable for A/B measurements on other devices). */
+#define ANNCUR_TOPK_MFMA16 2
 int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde,
                          int64_t Q, int64_t I, int32_t Kp, int32_t k,
                          float *out_val, int32_t *out_idx,

@@ -175,6 +175,37 @@ def test_fused_score_topk_matches_dense_and_cpu(ops, Q, I, K, k):
 	assert all(s or c for s, c in zip(same, close.tolist()))
 
 
+@pytest.mark.parametrize("Q,I,K,k", [(300, 40000, 64, 10), (257, 65536, 128, 100), (1000, 50007, 256, 100), (64, 70000, 256, 1), (50, 131072, 200, 500)])
+def test_fused_mfma16_sweep_gives_the_same_topk(ops, Q, I, K, k):
+	"""The 16x16x32 sweep (ANNCUR_TOPK_MFMA16, score16.hpp): other lane <-> (query, item) map, four segments per query and split,
+	one shared ring per lane.  Same products, same fp32 sums per output element -> values bit for bit, sets identical."""
+	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	(v16, i16), nfb16 = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma16=True)
+	torch.cuda.synchronize()
+	assert nfb.item() == 0 and nfb16.item() == 0
+	torch.testing.assert_close(v16, v, rtol=1e-6, atol=1e-6)     # (the MFMA shapes may associate the k-sum differently)
+	assert (torch.sort(i16, 1).values == torch.sort(i, 1).values).float().mean() > 0.9995
+
+
+def test_fused_mfma16_overflow_and_ring_wrap_are_repaired_exactly(ops):
+	# a contiguous block of items far above the rest: segments overflow, the lane's shared ring wraps -> exact repair
+	Q, I, K, k = 300, 80000, 128, 100
+	g = _g(4242)
+	X = torch.randn(Q, K, generator=g).abs().bfloat16()
+	E = (0.01 * torch.randn(K, I, generator=g))
+	E[:, 30000:36000] += 1.0
+	E = E.bfloat16()
+	Xp = ops.pack_bf16(X.cuda(), 128); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 128, row_multiple=32)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma16=True)
+	torch.cuda.synchronize()
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
+	assert nfb.item() > 0
+	torch.testing.assert_close(torch.gather(S, 1, i.cpu().long()), v.cpu().double(), rtol=1e-4, atol=1e-4)
+
+
 def test_fused_overflow_fallback_is_exact(ops):
 	# ascending scores along the item axis: every element beats the sampled threshold -> segments overflow
 	Q, I, K, k = 40, 60000, 64, 50

@@ -262,9 +262,39 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		const bool in = lane < head;
 		wsel_offer_inorder(w, in, in ? load_as_f32<T>(row + lane) : 0.f, (uint32_t)lane);
 	}
-	// ---- stream, element 0 onwards, blocks of WS_PF vectors per lane
+	// ---- stream, element 0 onwards, blocks of WS_PF vectors per lane.
+	// Candidate path in two phases (round 2: the per-element work used to run for every step in which ANY lane passed -- ~60 % of
+	// the steps, ~70 wave instructions each, one or two useful lanes).  Phase A, in the stream: a lane whose vector passes the
+	// prefilter RECORDS it (16 bytes + element index of its first element) in a 64-entry staging area, ~10 instructions per
+	// passing step.  Phase B, when the next step's vectors would not fit (and at the end): every lane takes ONE recorded vector
+	// and the elements are tested lane-locally, 64 vectors at a time with all lanes busy.  Exactness: batches are processed in
+	// stream order and the threshold only changes at a compaction, which runs between batches -- every element of a batch has a
+	// larger index than everything that was in the buffer at the last compaction, so the strict compare against that threshold
+	// stays exact whatever the order inside the batch.
+	// Staging = the layout's sort scratch (64 x 16 B) + the first 64 histogram words (the histogram is only live inside a
+	// compaction, which finds the staging area empty).
 	ScanPre<T> sp;
 	const uint32_t tie_limit = k + (trig - k) / 2;  // ties at the k-th score are kept while they fit below
+	u32x4 *stage_vec = reinterpret_cast<u32x4 *>(w.sort_buf);
+	uint32_t *stage_idx = w.hist;
+	uint32_t scnt = 0;  // staged vectors (wave-uniform)
+#define SCAN_DRAIN()                                                                                                            \
+	{                                                                                                                           \
+		__builtin_amdgcn_wave_barrier();                                                                                        \
+		const bool have = (uint32_t)lane < scnt;                                                                                \
+		const T *sv = reinterpret_cast<const T *>(stage_vec + lane);                                                            \
+		const uint32_t i0 = have ? stage_idx[lane] : 0u;                                                                        \
+		const bool nothr = !(w.tau > -INFINITY);  /* no threshold yet: every real number is a candidate, -inf included */        \
+		_Pragma("unroll 1") for (int e = 0; e < VEC; ++e) {                                                                     \
+			const float v = have ? load_as_f32<T>(sv + e) : 0.f;                                                                \
+			const bool hit = have && v == v && (v > w.tau || nothr);                                                            \
+			const unsigned long long hm = __ballot(hit);                                                                        \
+			if (hm != 0ull) wsel_push_mask(w, hm, hit, f32_sortable(v), 0xffffffffu - (i0 + (uint32_t)e));                      \
+		}                                                                                                                       \
+		scnt = 0;                                                                                                               \
+		__builtin_amdgcn_wave_barrier();                                                                                        \
+		if (w.cnt > trig) wsel_compact_call<WS_CAP, HP, true>(w, k, tie_limit);                                                 \
+	}
 #define SCAN_STEP(d)                                                                                                            \
 	{                                                                                                                           \
 		const u32x4 cur = pf[d];                                                                                                \
@@ -278,20 +308,16 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 			pf[d] = vp[ivn < nvec ? ivn : vlast];                                                                               \
 			pass = pass && iv < nvec;                                                                                           \
 		}                                                                                                                       \
-		if (__ballot(pass) != 0ull) {                                                                                           \
-			const uint32_t i0 = (uint32_t)(head + iv * VEC);                                                                    \
-			_Pragma("unroll") for (int j = 0; j < 4; ++j) {  /* word by word: most words of a passing vector hold no candidate */ \
-				const uint32_t hw = pass ? sp.word_hits(y[j]) : 0u;                                                             \
-				if (__ballot(hw != 0u) != 0ull) {                                                                               \
-					_Pragma("unroll") for (int e = j * VEC / 4; e < (j + 1) * VEC / 4; ++e) {                                   \
-						const float v = vec_elem<T>(cur, e);                                                                    \
-						const bool hit = sp.elem_hit(hw, e) && v == v;  /* NaN patterns can pass the integer tests */            \
-						const unsigned long long hm = __ballot(hit);                                                            \
-						if (hm != 0ull) wsel_push_mask(w, hm, hit, f32_sortable(v), 0xffffffffu - (i0 + (uint32_t)e));          \
-					}                                                                                                           \
-				}                                                                                                               \
+		const unsigned long long pm = __ballot(pass);                                                                           \
+		if (pm != 0ull) {                                                                                                       \
+			const uint32_t np = (uint32_t)__popcll(pm);                                                                         \
+			if (scnt + np > (uint32_t)WAVE) SCAN_DRAIN()                                                                        \
+			if (pass) {                                                                                                         \
+				const uint32_t pos = scnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u)); \
+				stage_vec[pos] = cur;                                                                                           \
+				stage_idx[pos] = (uint32_t)(head + iv * VEC);                                                                   \
 			}                                                                                                                   \
-			if (w.cnt > trig) wsel_compact_call<WS_CAP, HP, true>(w, k, tie_limit);                                             \
+			scnt += np;                                                                                                         \
 		}                                                                                                                       \
 	}
 	static_assert(WS_PF == 8, "the block spells out eight steps");
@@ -300,7 +326,9 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		const bool full = (s0 + 2 * WS_PF) * WAVE <= nvec;  // (wave-uniform) the block and its prefetch lie inside the row
 		SCAN_STEP(0) SCAN_STEP(1) SCAN_STEP(2) SCAN_STEP(3) SCAN_STEP(4) SCAN_STEP(5) SCAN_STEP(6) SCAN_STEP(7)
 	}
+	if (scnt > 0u) SCAN_DRAIN()
 #undef SCAN_STEP
+#undef SCAN_DRAIN
 	{  // the tail (fewer than VEC elements), still in index order
 		const bool in = lane < I - tail0;
 		wsel_offer_inorder(w, in, in ? load_as_f32<T>(row + tail0 + lane) : 0.f, (uint32_t)(tail0 + lane));

@@ -39,7 +39,7 @@ def _pinv_host(M):
 	return torch.from_numpy(np.linalg.pinv(M.detach().float().cpu().numpy()))
 
 
-AUTO_COND_LIMIT = 1e3   # pinv_backend "auto": the device result is taken while cond_F(W) stays below this
+AUTO_COND_LIMIT = 1e3   # pinv_backend "auto": the device result is taken while cond_2(W) stays below this (numpy's fp32 SVD is then good to ~1e-4)
 
 
 def _pinv(M, device, backend):
@@ -48,7 +48,7 @@ def _pinv(M, device, backend):
 	  fp32 matrix; differs from numpy's fp32 LAPACK SVD by numpy's own round-off, ~cond(W) * 6e-8 (measured 1e-6..1e-5 on the
 	  golden cases).  A block that is singular to fp32 precision (no convergence within the iteration budget) goes to the host
 	  call: what numpy returns there is an inverse of round-off noise that no other algorithm reproduces.
-	backend "auto": the device route, kept only where it is as good as pinned -- cond_F(W) = ||W||_F ||W^+||_F <= 1e3, where
+	backend "auto": the device route, kept only where it is as good as pinned -- cond_2(W) = ||W||_2 ||W^+||_2 <= 1e3 (power iteration), where
 	  the two agree far inside the 1e-4 score tolerance; an ill-conditioned block (e.g. as many anchor rows as anchor columns:
 	  numpy inverts singular values that are fp32 noise, and the reference's numbers are made of that noise) goes to the host call.
 	backend "device32": the fp32 iteration of round 1 (fast, ~1e-3)."""
@@ -59,9 +59,9 @@ def _pinv(M, device, backend):
 		if min(M.shape) == 0:
 			return torch.zeros((M.shape[1], M.shape[0]), dtype=torch.float32, device=device)
 		X, info = pinv_newton_schulz_f64(M.to(device), return_info=True)
-		if info["converged"] and (backend == "device" or info["cond_F"] <= AUTO_COND_LIMIT):
+		if info["converged"] and (backend == "device" or info["cond_2"] <= AUTO_COND_LIMIT):
 			return X
-		LOGGER.info("pinv %s: cond_F = %.3g after %d iterations (converged: %s) -> host numpy.linalg.pinv", backend, info["cond_F"], info["iterations"], info["converged"])
+		LOGGER.info("pinv %s: cond_2 = %.3g after %d iterations (converged: %s) -> host numpy.linalg.pinv", backend, info["cond_2"], info["iterations"], info["converged"])
 		return _pinv_host(M).to(device)
 	if backend == "device32":
 		from .pinv import pinv_newton_schulz

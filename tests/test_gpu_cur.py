@@ -189,6 +189,11 @@ def test_device_pinv_f64_meets_the_score_tolerance_on_the_goldens(CUR, golden_di
 		g = np.load(os.path.join(golden_dir, "protoB_2000x20000.npz"))
 		anc = g["anc"].tolist()
 		ref = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(500), col_idxs=anc, approx_preference="rows", pinv_backend="numpy")
+		from anncur_amd.pinv import pinv_newton_schulz_f64
+		_, info = pinv_newton_schulz_f64(A_train[:, anc].cuda(), return_info=True)
+		assert info["converged"] and info["cond_2"] < 1e3 and info["iterations"] <= 30, info     # "auto" keeps the device result here
+		auto = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(500), col_idxs=anc, approx_preference="rows", pinv_backend="auto")
+		assert not torch.equal(auto.U, ref.U)                                                      # (... i.e. it is not numpy's)
 		for backend in ("device", "auto"):
 			cur = CUR(rows=A_train, cols=A_train[:, anc], row_idxs=np.arange(500), col_idxs=anc, approx_preference="rows", pinv_backend=backend)
 			assert ((cur.U - ref.U).norm() / ref.U.norm()).item() <= 1e-5

@@ -145,7 +145,7 @@ __device__ __forceinline__ void lds_store_2x32(uint32_t addr, uint32_t lo, uint3
 // Measured on cfg2 (MI355X): branch version 0.58 ms per sweep, predicated version 0.655 ms independent of the hit rate (its
 // compare -> exec -> store chain sits in front of the wave's next MFMA) -> the branch version is the one in use.
 // (plan_stages picks the variant per sweep stage from the expected hit rate: predicated above ~0.5 taken branches per compare)
-template <int D, bool FILTER_PREDICATED = false>
+template <int D, bool FILTER_PREDICATED = false, bool INLINE_HIT = false>
 __device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t item0, uint32_t lq, uint32_t &qcnt) {
 	static_assert((D & (D - 1)) == 0, "queue depth must be a power of two");
 	// qcnt is kept pre-shifted (slot stride 2048 B); lq has bits 11..13 clear (16 KiB-aligned ring), so OR == ADD
@@ -171,6 +171,15 @@ __device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t i
 			  [c] "n"((e & 3) + 8 * (e >> 2))
 			: "vcc", "memory");
 #endif
+	} else if (INLINE_HIT) {
+		// the push block stays IN LINE behind a short forward skip (taken when no lane hits) instead of out of line behind a far
+		// branch out and back (taken when one does)
+		if (__builtin_expect(__ballot(v >= tau) != 0ull, 1)) {
+			if (v >= tau) {
+				lds_store_2x32((qcnt & (uint32_t)((D - 1) << 11)) | lq, __float_as_uint(v), item0 + (uint32_t)((e & 3) + 8 * (e >> 2)));
+				qcnt += 2048u;
+			}
+		}
 	} else if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
 		if (v >= tau) {
 			lds_store_2x32((qcnt & (uint32_t)((D - 1) << 11)) | lq, __float_as_uint(v), item0 + (uint32_t)((e & 3) + 8 * (e >> 2)));
@@ -233,7 +242,7 @@ __device__ __forceinline__ void lds_wait_frag(u32x4 &frag, int pending) {  // `p
 //   steps K..2K-1  : acc1 (sub-tile 1 of this tile)  ||  filter of accA
 // The A fragments (same K fragments for both halves) stream through one ring of AR registers, AR-1 steps ahead, without a
 // break between the halves.  CUR = tile buffer parity (compile-time: an immediate offset of the LDS reads).
-template <int KP, int CUR, bool PRED>
+template <int KP, int CUR, bool PRED, bool INL = false>
 __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>::KSTEPS], const bf16x8 (&xb)[2][FusedCfg<KP>::KSTEPS],
 											  f32x16 &acc1, float tau0, float tau1_prev, uint32_t item0, uint32_t item0_prev,
 											  uint32_t lq0, uint32_t lq1, uint32_t &q0, uint32_t &q1) {
@@ -262,14 +271,14 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 			accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[0][g], accA, 0, 0, 0);
 #pragma unroll
 			for (int e = (g == 1 ? 0 : g) * EPS; e < (g == 0 ? 0 : g + 1) * EPS; ++e)
-				filter_one<Cfg::QDEPTH, PRED>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
+				filter_one<Cfg::QDEPTH, PRED, INL>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
 		} else {
 			// no filter in the first step of the half: accA's last MFMA is still in the pipe (and the predicated filter is
 			// inline asm, invisible to the compiler's MFMA -> VALU hazard handling); step 1 takes two groups instead
 			accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[1][g - K], accB, 0, 0, 0);
 #pragma unroll
 			for (int e = (g - K == 1 ? 0 : g - K) * EPS; e < (g == K ? 0 : g - K + 1) * EPS; ++e)
-				filter_one<Cfg::QDEPTH, PRED>(accA[e], e, tau0, item0, lq0, q0);
+				filter_one<Cfg::QDEPTH, PRED, INL>(accA[e], e, tau0, item0, lq0, q0);
 		}
 	}
 	acc1 = accB;
@@ -277,7 +286,7 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 
 // MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep (PRED: branch-free filter, for stages in
 // which most compares find a survivor in some lane -- large k).
-template <int KP, int MODE, int GROUP, bool PRED = false>
+template <int KP, int MODE, int GROUP, bool PRED = false, bool INL = false>
 __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 	using Cfg = FusedCfg<KP>;
 	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I);               \
 			}                                                                                                                   \
 			const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * h;                                                              \
-			stagger_tile<KP, CUR, PRED>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1]);            \
+			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1]);            \
 			tau1_prev = tau[1]; item0_prev = item0;                                                                             \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
@@ -1110,6 +1119,13 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			}
 		}
 #ifdef ANNCUR_TIMING_EXPERIMENTS
+		if constexpr (Cfg::QT == 2) {
+			if (!launched && getenv("ANNCUR_DEBUG_INLINE_HIT")) {
+				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, true>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+				launched = true;
+			}
+		}
 		if (!launched && getenv("ANNCUR_DEBUG_ONE_WG")) {  // padded LDS request: a second workgroup does not fit on the CU
 			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16>, 84 * 1024)) != ANNCUR_OK) return rc;
 			hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), 84 * 1024, st, p);

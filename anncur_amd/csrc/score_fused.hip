@@ -226,6 +226,11 @@ __device__ __forceinline__ void lds_read_frag(u32x4 &dst, uint32_t addr) {
 	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 #endif
 }
+__device__ __forceinline__ void lds_read_frag_at(u32x4 &dst, uint32_t addr, int off) {  // `off` folds to an immediate after unrolling
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+#endif
+}
 __device__ __forceinline__ void lds_wait_frag(u32x4 &frag, int pending) {  // `pending` folds to a constant after unrolling
 #if defined(__HIP_DEVICE_COMPILE__)
 	if (pending >= 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(frag));
@@ -282,6 +287,37 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 		}
 	}
 	acc1 = accB;
+}
+
+// Kp = 512 (one 32-query sub-tile per wave: the query operand alone takes 128 VGPRs): the same idea across TILES -- while the
+// 32-MFMA chain of tile j executes, the filter of tile j-1's accumulator is issued in its shadow, one element every second
+// k-step; A fragments through the counted-wait register ring as in stagger_tile.  Fragment address of k-step s:
+// row * CPR * 16 + ((2 s + h) ^ (r & 15)) * 16 = aoff8[s & 7] + (s >> 3) * 256 (the XOR only touches the chunk's low four bits),
+// so eight address registers serve the 32 k-steps.
+template <int KP, int CUR>
+__device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const bf16x8 (&xb)[FusedCfg<KP>::KSTEPS], f32x16 &accP, float tau,
+											   uint32_t item0_prev, uint32_t lq, uint32_t &qcnt) {
+	using Cfg = FusedCfg<KP>;
+	constexpr int K = Cfg::KSTEPS, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;
+	static_assert(K == 32 && Cfg::CPR >= 16, "written for Kp = 512");
+	u32x4 ring[AR];
+#define S1_READ(slot, s) lds_read_frag_at(ring[slot], aoff8[(s) & 7], OFF + ((s) >> 3) * 256)
+	S1_READ(0, 0); S1_READ(1, 1); S1_READ(2, 2);
+	f32x16 acc = {0};
+#pragma unroll
+	for (int g = 0; g < K; ++g) {
+		const int nxt = g + DIST;
+		if (nxt < K) S1_READ(nxt % AR, nxt);
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (g >= 1) asm volatile("" ::"v"(ring[(g - 1) % AR]));
+#endif
+		const int after = K - 1 - g;
+		lds_wait_frag(ring[g % AR], after < DIST ? after : DIST);
+		acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % AR]), xb[g], acc, 0, 0, 0);
+		if (g & 1) filter_one<Cfg::QDEPTH>(accP[g >> 1], g >> 1, tau, item0_prev, lq, qcnt);
+	}
+#undef S1_READ
+	accP = acc;
 }
 
 // MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep (PRED: branch-free filter, for stages in
@@ -386,6 +422,40 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
+	} else if constexpr (MODE == 1 && QT == 1 && KP == 512 && !INL) {  // (INL = the plain loop, kept for A/B in the experiments build)
+		// ---- software-pipelined sweep for Kp = 512 (stagger1_tile): tile loop unrolled by two (buffer parity = immediate offset)
+		f32x16 accP;
+#pragma unroll
+		for (int e = 0; e < 16; ++e) accP[e] = 0.f;
+		float tau_prev = INFINITY;   // no previous tile yet
+		uint32_t item0_prev = 0;
+		uint32_t aoff8[8];
+#pragma unroll
+		for (int s = 0; s < 8; ++s) aoff8[s] = lds_addr(smem) + (uint32_t)(r * CPR + ((2 * s + h) ^ (r & 15))) * 16u;
+		const int flush_period = (p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;
+		int flush_in2 = flush_period;
+		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger1_tile() counts LDS reads
+#define STAGGER1_STEP(CUR, J)                                                                                                   \
+		do {                                                                                                                    \
+			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
+			if (--flush_in2 == 0) {                                                                                             \
+				flush_in2 = flush_period;                                                                                       \
+				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);                        \
+			}                                                                                                                   \
+			stagger1_tile<KP, CUR>(aoff8, xb[0], accP, tau_prev, item0_prev, lq0, qcnt[0]);                                     \
+			tau_prev = tau[0]; item0_prev = (uint32_t)(J) * TILE_I + 4 * h;                                                     \
+			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
+			__syncthreads();                                                                                                    \
+		} while (0)
+		for (int j = j_begin; j < j_end; j += 2) {
+			STAGGER1_STEP(0, j);
+			if (j + 1 < j_end) STAGGER1_STEP(1, j + 1);
+		}
+#undef STAGGER1_STEP
+		flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);
+#pragma unroll
+		for (int e = 0; e < 16; ++e)  // drain: the last tile
+			filter_one<Cfg::QDEPTH>(accP[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
 	} else {
 	const int flush_period_p = (MODE == 1 && p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;  // (see the staggered path)
 	int flush_in = flush_period_p;
@@ -1119,6 +1189,13 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			}
 		}
 #ifdef ANNCUR_TIMING_EXPERIMENTS
+		if constexpr (KP == 512) {
+			if (!launched && getenv("ANNCUR_DEBUG_PLAIN512")) {  // the sweep without the cross-tile software pipeline
+				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, true>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+				launched = true;
+			}
+		}
 		if constexpr (Cfg::QT == 2) {
 			if (!launched && getenv("ANNCUR_DEBUG_INLINE_HIT")) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("ANNCUR_LIB") or os.path.join(_HERE, "lib", "libanncur
 F32, BF16, F64 = 0, 1, 2
 TOPK_LEADING_SAMPLE = 1
 TOPK_MFMA16 = 2
+TOPK_QT1 = 4
 MAX_TOPK = 2048
 
 _p32 = POINTER(c_int32)

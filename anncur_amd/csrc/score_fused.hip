@@ -40,10 +40,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vecto
 
 constexpr int TILE_I = 32;
 
-template <int KP>
+template <int KP, int QTV = ((KP <= 256) ? 2 : 1)>
 struct FusedCfg {
 	static constexpr int KSTEPS = KP / 16;
-	static constexpr int QT = (KP <= 256) ? 2 : 1;  // 32-query sub-tiles per wave
+	static constexpr int QT = QTV;                  // 32-query sub-tiles per wave (default: 2 up to Kp = 256, 1 for Kp = 512)
 	static constexpr int BQ = 4 * 32 * QT;          // queries per workgroup (4 waves)
 	static constexpr int CPR = KP / 8;              // 16-byte chunks per Et row
 	static constexpr int TILE_BYTES = TILE_I * KP * 2;
@@ -295,11 +295,11 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 // row * CPR * 16 + ((2 s + h) ^ (r & 15)) * 16 = aoff8[s & 7] + (s >> 3) * 256 (the XOR only touches the chunk's low four bits),
 // so eight address registers serve the 32 k-steps.
 template <int KP, int CUR>
-__device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const bf16x8 (&xb)[FusedCfg<KP>::KSTEPS], f32x16 &accP, float tau,
+__device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const bf16x8 (&xb)[FusedCfg<KP, 1>::KSTEPS], f32x16 &accP, float tau,
 											   uint32_t item0_prev, uint32_t lq, uint32_t &qcnt) {
-	using Cfg = FusedCfg<KP>;
+	using Cfg = FusedCfg<KP, 1>;
 	constexpr int K = Cfg::KSTEPS, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;
-	static_assert(K == 32 && Cfg::CPR >= 16, "written for Kp = 512");
+	static_assert((K == 32 || K == 16 || K == 8) && Cfg::CPR >= 16, "Kp = 128, 256 or 512");
 	u32x4 ring[AR];
 #define S1_READ(slot, s) lds_read_frag_at(ring[slot], aoff8[(s) & 7], OFF + ((s) >> 3) * 256)
 	S1_READ(0, 0); S1_READ(1, 1); S1_READ(2, 2);
@@ -314,7 +314,12 @@ __device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const 
 		const int after = K - 1 - g;
 		lds_wait_frag(ring[g % AR], after < DIST ? after : DIST);
 		acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % AR]), xb[g], acc, 0, 0, 0);
-		if (g & 1) filter_one<Cfg::QDEPTH>(accP[g >> 1], g >> 1, tau, item0_prev, lq, qcnt);
+		if constexpr (K == 32) {  // one element every second k-step
+			if (g & 1) filter_one<Cfg::QDEPTH>(accP[g >> 1], g >> 1, tau, item0_prev, lq, qcnt);
+		} else {                  // 16 / K elements per k-step
+#pragma unroll
+			for (int e = g * (16 / K); e < (g + 1) * (16 / K); ++e) filter_one<Cfg::QDEPTH>(accP[e], e, tau, item0_prev, lq, qcnt);
+		}
 	}
 #undef S1_READ
 	accP = acc;
@@ -322,9 +327,9 @@ __device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const 
 
 // MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep (PRED: branch-free filter, for stages in
 // which most compares find a survivor in some lane -- large k).
-template <int KP, int MODE, int GROUP, bool PRED = false, bool INL = false>
-__global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
-	using Cfg = FusedCfg<KP>;
+template <int KP, int MODE, int GROUP, bool PRED = false, bool INL = false, int QTV = FusedCfg<KP>::QT>
+__global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_kernel(const FusedParams p) {
+	using Cfg = FusedCfg<KP, QTV>;
 	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void score_kernel(const FusedParams p) {
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
-	} else if constexpr (MODE == 1 && QT == 1 && KP == 512 && !INL) {  // (INL = the plain loop, kept for A/B in the experiments build)
+	} else if constexpr (MODE == 1 && QT == 1 && KP >= 128 && !INL) {  // (INL = the plain loop, kept for A/B in the experiments build)
 		// ---- software-pipelined sweep for Kp = 512 (stagger1_tile): tile loop unrolled by two (buffer parity = immediate offset)
 		f32x16 accP;
 #pragma unroll
@@ -971,13 +976,15 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	}
 }
 
-FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false) {
+FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false) {
 	FusedPlan P{};
 	P.ok = false;
 	P.leading = leading ? 1 : 0;
 	if (!(KP == 64 || KP == 128 || KP == 256 || KP == 512)) return P;
 	if (k < 1 || k > ANNCUR_MAX_TOPK || Q < 1 || I < 1 || I >= (int64_t)0x7fffffff - 64 || k > I) return P;
-	P.QT = (KP <= 256) ? 2 : 1;
+	// qt1 (ANNCUR_TOPK_QT1, Kp = 128 / 256): one 32-query sub-tile per wave with the cross-tile pipeline of the Kp = 512 sweep,
+	// 3 workgroups per CU (<= 168 VGPRs) instead of two sub-tiles staggered inside a wave at 2 workgroups per CU
+	P.QT = (KP <= 256 && !(qt1 && KP >= 128)) ? 2 : 1;
 	P.BQ = 128 * P.QT;
 	P.n_rb = (int)ceil_div64(Q, P.BQ);
 	P.n_tiles = (int)ceil_div64(I, TILE_I);
@@ -990,7 +997,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	if ((int64_t)P.n_st * 4 > P.n_full) return P;  // problem too small for the fused path: use dense GEMM + scan
 	P.n_groups = P.n_st * (P.group == 16 ? 2 : 8);
 	if (P.n_groups < k) return P;
-	int slots = 2 * num_cu();
+	int slots = ((P.QT == 1 && KP <= 256) ? 3 : 2) * num_cu();
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_ONE_WG")) slots = num_cu();  // one sweep workgroup per CU (co-residence experiment)
 #endif
@@ -1123,10 +1130,10 @@ int launch_threshold(const FusedPlan &P, const float *gmax, int64_t Q, int k, un
 	return anncur_rowwise_topk(gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, (int32_t *)(ws + P.off_tidx), st);
 }
 
-template <int KP>
+template <int KP, int QTV = FusedCfg<KP>::QT>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
 				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev) {
-	using Cfg = FusedCfg<KP>;
+	using Cfg = FusedCfg<KP, QTV>;
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
 	p.n_tiles = P.n_tiles; p.n_full_tiles = P.n_full; p.S = P.S; p.tiles_per_split = P.tiles_per_split;
@@ -1145,9 +1152,9 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	// 1. prepass
 	p.n_wg = P.n_rb * P.S0;
 	if (P.group == 16)
-		hipLaunchKernelGGL((score_kernel<KP, 0, 16>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
+		hipLaunchKernelGGL((score_kernel<KP, 0, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
 	else
-		hipLaunchKernelGGL((score_kernel<KP, 0, 4>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
+		hipLaunchKernelGGL((score_kernel<KP, 0, 4, false, false, QTV>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
 	ANNCUR_LAUNCH_OK();
 	EV(1);
 	// 2. tau = k-th largest group maximum
@@ -1156,7 +1163,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	EV(2);
 	// 3. sweep, in stages; between stages the thresholds are raised from the candidates collected so far
 	p.n_wg = P.n_rb * P.S;
-	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
 		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
@@ -1165,16 +1172,16 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
 		if (getenv("ANNCUR_DEBUG_GEMM_NOSYNC")) {  // MFMA + LDS fragment reads, no staging, no barriers
-			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 3, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
-			hipLaunchKernelGGL((score_kernel<KP, 3, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 3, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+			hipLaunchKernelGGL((score_kernel<KP, 3, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 			launched = true;
 		} else if (getenv("ANNCUR_DEBUG_GEMM_ONLY")) {  // no candidates are produced
-			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 2, 16>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
-			hipLaunchKernelGGL((score_kernel<KP, 2, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 2, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+			hipLaunchKernelGGL((score_kernel<KP, 2, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 			launched = true;
 		}
 #endif
-		if constexpr (KP <= 256) {  // 16x16x32 sweep (score16.hpp): four lane groups -> 4 S segments per query
+		if constexpr (KP <= 256 && QTV == 2) {  // 16x16x32 sweep (score16.hpp): four lane groups -> 4 S segments per query
 			if (!launched && P.lg == 4) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score16_kernel<KP>, Fused16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((score16_kernel<KP>), dim3(p.n_wg), dim3(256), Fused16Cfg<KP>::LDS_BYTES, st, p);
@@ -1183,33 +1190,33 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		}
 		if constexpr (Cfg::QT == 2) {  // (the predicated filter lives in the staggered path)
 			if (!launched && P.stage_pred[stg]) {
-				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
-				hipLaunchKernelGGL((score_kernel<KP, 1, 16, true>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, true, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score_kernel<KP, 1, 16, true, false, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 				launched = true;
 			}
 		}
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		if constexpr (KP == 512) {
 			if (!launched && getenv("ANNCUR_DEBUG_PLAIN512")) {  // the sweep without the cross-tile software pipeline
-				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
-				hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, true>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, true, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 				launched = true;
 			}
 		}
 		if constexpr (Cfg::QT == 2) {
 			if (!launched && getenv("ANNCUR_DEBUG_INLINE_HIT")) {
-				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
-				hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, true>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, true, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 				launched = true;
 			}
 		}
 		if (!launched && getenv("ANNCUR_DEBUG_ONE_WG")) {  // padded LDS request: a second workgroup does not fit on the CU
-			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16>, 84 * 1024)) != ANNCUR_OK) return rc;
-			hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), 84 * 1024, st, p);
+			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, 84 * 1024)) != ANNCUR_OK) return rc;
+			hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), 84 * 1024, st, p);
 			launched = true;
 		}
 #endif
-		if (!launched) hipLaunchKernelGGL((score_kernel<KP, 1, 16>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
+		if (!launched) hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
 		if (stg + 1 < P.n_stages &&
@@ -1345,16 +1352,19 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 }
 #undef EV
 
-FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false) {
-	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16);
+FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false) {
+	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1);
 }
 
 }  // namespace
 
 extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
-	const FusedPlan P = plan_any(Q, I, Kp, k), P16 = plan_any(Q, I, Kp, k, false, true);  // (whatever flags the call will carry)
+	const FusedPlan P = plan_any(Q, I, Kp, k), P16 = plan_any(Q, I, Kp, k, false, true), P1 = plan_any(Q, I, Kp, k, false, false, true);  // (whatever flags the call will carry)
 	if (!P.ok) return 0;
-	return P16.ok && P16.total > P.total ? P16.total : P.total;
+	size_t t = P.total;
+	if (P16.ok && P16.total > t) t = P16.total;
+	if (P1.ok && P1.total > t) t = P1.total;
+	return t;
 }
 
 extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
@@ -1373,8 +1383,8 @@ __global__ __launch_bounds__(256) void remap_ids_kernel(int32_t *__restrict__ id
 static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr) {
-	ANNCUR_REQUIRE((flags & ~(ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16)) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
-	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0);
+	ANNCUR_REQUIRE((flags & ~(ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1)) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
+	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0, (flags & ANNCUR_TOPK_QT1) != 0);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
 				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512} or a multiple of 128 up to %d, "
 				   "1<=k<=%d, I large enough for a sampled threshold); use anncur_gemm + anncur_rowwise_topk",
@@ -1390,8 +1400,10 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 	int rc;
 	switch (Kp) {
 		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
-		case 128: rc = launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
-		case 256: rc = launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
+		case 128: rc = P.QT == 1 ? launch_fused<128, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev)
+								  : launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
+		case 256: rc = P.QT == 1 ? launch_fused<256, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev)
+								  : launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
 		case 512: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
 		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev); break;
 	}
@@ -1422,7 +1434,7 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 	constexpr int NEV = 11;  // 0..4 stage boundaries, 5..10 begin/end of up to three sweep launches
 	hipEvent_t ev[NEV];
 	for (int i = 0; i < NEV; ++i) ANNCUR_HIP_OK(hipEventCreate(&ev[i]));
-	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0);
+	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0, (flags & ANNCUR_TOPK_QT1) != 0);
 	int rc = score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, ev, flags, item_ids);
 	if (rc == ANNCUR_OK) {
 		hipError_t e = hipEventSynchronize(ev[4]);

@@ -359,7 +359,7 @@ def _item_ids_arg(item_ids, I, device):
 
 
 @_on_device
-def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False):
+def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False):
 	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16).
 	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time).
 	leading_sample / item_ids: the index builder's hints of anncur_score_topk_ex (rows of Etp ordered by descending norm, and the
@@ -403,7 +403,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 
 
 @_on_device
-def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False):
+def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False):
 	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches]) in ms,
 	from HIP events on the launch stream."""
 	_dev(Xp, Etp)

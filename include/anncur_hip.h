@@ -163,6 +163,9 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
  *    the order of exact score ties; the chip holds a higher clock on that shape: +6 % on the bare GEMM loop, level with the
  *    default once survivors are collected -- kept selectable for A/B measurements on other devices). */
 #define ANNCUR_TOPK_MFMA16 2
+/*  ANNCUR_TOPK_QT1 (Kp = 128 / 256): one 32-query sub-tile per wave and three workgroups per CU, with the cross-tile software
+ *    pipeline of the Kp = 512 sweep, instead of two sub-tiles staggered inside a wave at two workgroups per CU (A/B variant). */
+#define ANNCUR_TOPK_QT1 4
 int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde,
                          int64_t Q, int64_t I, int32_t Kp, int32_t k,
                          float *out_val, int32_t *out_idx,

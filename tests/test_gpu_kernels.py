@@ -186,6 +186,11 @@ def test_fused_mfma16_sweep_gives_the_same_topk(ops, Q, I, K, k):
 	assert nfb.item() == 0 and nfb16.item() == 0
 	torch.testing.assert_close(v16, v, rtol=1e-6, atol=1e-6)     # (the MFMA shapes may associate the k-sum differently)
 	assert (torch.sort(i16, 1).values == torch.sort(i, 1).values).float().mean() > 0.9995
+	# ANNCUR_TOPK_QT1 (Kp = 128 / 256): one sub-tile per wave, cross-tile pipeline, three workgroups per CU -- same MFMA, same sums
+	(v1, i1), nfb1 = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, qt1=True)
+	torch.cuda.synchronize()
+	assert nfb1.item() == 0 and torch.equal(v1, v)
+	assert (torch.sort(i1, 1).values == torch.sort(i, 1).values).float().mean() > 0.9995
 
 
 def test_fused_mfma16_overflow_and_ring_wrap_are_repaired_exactly(ops):

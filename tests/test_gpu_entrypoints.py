@@ -113,7 +113,8 @@ def test_default_grids_match_reference(gpu):
 	assert gA["top_k_vals"] == [10] and gA["top_k_retr_vals"] == [500] and gA["eval_methods"] == ["cur", "cur_oracle"]
 
 
-@pytest.mark.parametrize("n,d,nq,k,dtype", [(3000, 96, 37, 10, "fp32"), (12000, 768, 20, 64, "fp32"), (70000, 128, 50, 100, "bf16"), (50, 16, 5, 64, "fp32")])
+@pytest.mark.parametrize("n,d,nq,k,dtype", [(3000, 96, 37, 10, "fp32"), (12000, 768, 20, 64, "fp32"), (70000, 128, 50, 100, "bf16"), (50, 16, 5, 64, "fp32"),
+											   (30000, 768, 300, 64, "bf16")])   # d = 768 bi-encoder embeddings in bf16: the K-general fused kernel
 def test_flat_ip_index_matches_exact_search(gpu, n, d, nq, k, dtype):
 	from models.nearest_nbr import build_flat_or_ivff_index
 	from oracle import cur_oracle as O

@@ -82,6 +82,7 @@ def main():
 	ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg2 on one GPU, cfg4_per_gpu on several")
 	ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-rank path with ranks sharing GPUs")
 	ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses GPU r %% device_count (RCCL cannot; use --backend gloo)")
+	ap.add_argument("--no-k500", action="store_true", help="skip the retrieve_only_k500 side-line (profiling runs: its launches share the sweep kernel's name)")
 	ap.add_argument("--sustained-seconds", type=float, default=2.0, help="also loop the same step for this long and report it (DVFS-settled rate); 0 = skip")
 	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
 	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
@@ -322,7 +323,7 @@ def main():
 	# retrieve-only at k_retvr = 500, the reference's default for entry A (crossenc.py:238): more survivors, wave-level select with
 	# 8 keys per lane, predicated sweep stages
 	retrieve500_ms = None
-	if ops.fused_supported(Q, I, Kp, 500):
+	if not args.no_k500 and ops.fused_supported(Q, I, Kp, 500):
 		for _ in range(2):
 			ops.score_topk_fused(Xr, cur._Etp_sorted, I, 500, leading_sample=True, item_ids=cur._item_ids)
 		ev[0].record()

@@ -12,7 +12,8 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 SHAPES = {"cfg2": dict(Q=10000, I=100000, Kp=256, k=100), "cfg4_per_gpu": dict(Q=6250, I=1000000, Kp=512, k=100)}
 shape = SHAPES[cfg]
 kp = shape["Kp"]
-sweep, prepass = f"score_kernel<{kp}, 1, 16", f"score_kernel<{kp}, 0, 16"   # (prefixes: further template arguments follow)
+qt = 2 if kp <= 256 else 1
+sweep, prepass = f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 0, 16, false, false, {qt}>"   # the default variants
 names = [sweep, prepass, "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false>", "select_wave_kernel<true>",
 		 "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel", "gemm_f64_kernel"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

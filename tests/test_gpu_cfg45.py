@@ -120,7 +120,8 @@ def test_cfg5_domain_shape_matches_oracle(cfg5_data, dtype, tol):
 		assert g == pytest.approx(w, abs=tol), (dtype, k, g, w)
 
 
-@pytest.mark.parametrize("Q,I,K,k", [(1200, 15603, 1024, 100), (333, 40000, 768, 64), (2100, 9000, 2048, 10), (64, 70000, 640, 500)])
+@pytest.mark.parametrize("Q,I,K,k", [(1200, 15603, 1024, 100), (333, 40000, 768, 64), (2100, 9000, 2048, 10), (64, 70000, 640, 500), (100, 50000, 1024, 1000),
+									  (700, 20000, 4096, 100)])
 def test_wide_inner_dimension_route_values_and_sets(Q, I, K, k):
 	"""Whatever serves K > 512 (cfg5's 1 024 anchors, d = 768 bi-encoder embeddings): values and index sets against fp64 on the
 	same bf16 operands.  S_hat must not be materialised by the library GEMM: the route is the K-general fused kernel."""

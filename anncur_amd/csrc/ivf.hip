@@ -175,3 +175,49 @@ extern "C" int anncur_ivf_scan(const float *Xs, int64_t ldx, int32_t dp, const i
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }
+
+// ------------------------------------------------------------------ descending-norm buckets (index-build hint of the fused top-k)
+// bucket[i] of row i by its squared norm, largest norms first: 0 .. n_buckets-1, linear between the largest and the smallest norm
+// of the matrix.  Followed by anncur_ivf_build_lists (a stable counting sort) this yields the coarse descending-norm row order the
+// index builder passes to anncur_score_topk_ex -- an ordering that only moves speed, so a coarse one does.
+namespace {
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float *__restrict__ A, int64_t n_rows, int64_t n_cols, int64_t lda, float *__restrict__ out,
+														 uint32_t *__restrict__ minmax) {
+	const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= n_rows) return;
+	const float *row = A + r * lda;
+	float s = 0.f;
+	for (int64_t c = threadIdx.x & 63; c < n_cols; c += 64) { const float v = row[c]; s = fmaf(v, v, s); }
+	for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+	if ((threadIdx.x & 63) == 0) {
+		out[r] = s;
+		const uint32_t key = f32_sortable(s == s ? s : 0.f);
+		atomicMin(&minmax[0], key);
+		atomicMax(&minmax[1], key);
+	}
+}
+__global__ __launch_bounds__(256) void norm_bucket_kernel(const float *__restrict__ nrm, int64_t n, const uint32_t *__restrict__ minmax, int32_t n_buckets,
+														   int32_t *__restrict__ bucket) {
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const float lo = f32_unsortable(minmax[0]), hi = f32_unsortable(minmax[1]);
+	const float v = nrm[i] == nrm[i] ? nrm[i] : lo;
+	const float span = hi - lo;
+	int32_t b = span > 0.f ? (int32_t)((hi - v) / span * (float)n_buckets) : 0;
+	bucket[i] = b < 0 ? 0 : (b >= n_buckets ? n_buckets - 1 : b);
+}
+}  // namespace
+
+extern "C" int anncur_norm_buckets(const float *A, int64_t n_rows, int64_t n_cols, int64_t lda, int32_t n_buckets, float *norms, uint32_t *minmax2,
+								   int32_t *bucket, void *stream) {
+	ANNCUR_REQUIRE(n_rows >= 0 && n_cols >= 0 && lda >= n_cols && n_buckets >= 1, ANNCUR_E_INVALID, "norm_buckets: bad sizes");
+	if (n_rows == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(A && norms && minmax2 && bucket, ANNCUR_E_INVALID, "norm_buckets: null pointer");
+	hipStream_t st = (hipStream_t)stream;
+	ANNCUR_HIP_OK(hipMemsetAsync(minmax2, 0xff, 4, st));      // running minimum of the sortable keys
+	ANNCUR_HIP_OK(hipMemsetAsync(minmax2 + 1, 0, 4, st));     // running maximum
+	hipLaunchKernelGGL(row_sumsq_kernel, dim3((unsigned)ceil_div64(n_rows, 4)), dim3(256), 0, st, A, n_rows, n_cols, lda, norms, minmax2);
+	hipLaunchKernelGGL(norm_bucket_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, st, norms, n_rows, minmax2, n_buckets, bucket);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}

@@ -501,6 +501,22 @@ def ivf_build_lists(assign, nlist):
 
 
 @_on_device
+def descending_norm_order(M, n_buckets=4096):
+	"""Row ids of the fp32 matrix M in coarse descending-norm order (int32 device tensor): norm buckets + the stable counting sort
+	of the inverted-file builder.  The index builder's ordering hint; no torch arithmetic involved."""
+	_dev(M)
+	M = _rowmajor(M)
+	if M.dtype != torch.float32:
+		raise TypeError("descending_norm_order takes fp32")
+	n = M.shape[0]
+	norms = torch.empty(n, dtype=torch.float32, device=M.device)
+	mm = torch.empty(2, dtype=torch.int32, device=M.device)
+	bucket = torch.empty(n, dtype=torch.int32, device=M.device)
+	check(_lib.load().anncur_norm_buckets(_p(M), n, M.shape[1], _ld(M), n_buckets, _p(norms), _p(mm), _p(bucket), _stream()), "norm_buckets")
+	return ivf_build_lists(bucket, n_buckets)[2]
+
+
+@_on_device
 def ivf_list_means(Xs, offsets, centroids):
 	"""centroids[l] <- mean of the rows of list l of Xs (list-ordered fp32 vectors); empty lists keep theirs.  In place."""
 	_dev(Xs, offsets, centroids)

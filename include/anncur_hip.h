@@ -218,6 +218,14 @@ int anncur_ivf_list_means(const float *Xs, int64_t ldx, int32_t d, const int32_t
 int anncur_ivf_scan(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, const float *Q, int64_t ldq, int64_t nq,
                     const int32_t *probe, int32_t nprobe, int32_t k, float *out_val, int32_t *out_idx, void *stream);
 
+/* Index-build hint of anncur_score_topk_ex: bucket[i] in 0..n_buckets-1 by the squared norm of row i of the fp32 matrix A, largest
+ * norms first (linear between the matrix' largest and smallest row norm); norms float[n_rows] and minmax2 uint32[2] are scratch
+ * outputs.  anncur_ivf_build_lists(bucket, n_rows, n_buckets, ...) then returns the rows in coarse descending-norm order (a stable
+ * counting sort): the order in which CURApprox stores the hint copy of E^T (matrix_approx_zeshel.py:65 builds latent_cols; the
+ * ordering is this build's own and only moves speed). */
+int anncur_norm_buckets(const float *A, int64_t n_rows, int64_t n_cols, int64_t lda, int32_t n_buckets, float *norms, uint32_t *minmax2,
+                        int32_t *bucket, void *stream);
+
 /* dtype plumbing: fp32 <-> bf16 (round-to-nearest-even), strided 2-D ------------------ */
 int anncur_convert(const void *src, int src_dtype, int64_t lds_, void *dst, int dst_dtype, int64_t ldd,
                    int64_t n_rows, int64_t n_cols, void *stream);

@@ -964,7 +964,9 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		if (end <= prev) end = prev + 1 < P.n_tiles ? prev + 1 : P.n_tiles;
 		P.stage_end[i] = end;
 		P.stage_tps[i] = (end - prev + P.S - 1) / P.S;
-		int ft = (int)(0.5 / (rate > 1e-9 ? rate : 1e-9));
+		// ring window: expected hits per (lane, sub-tile) ring and window <= 0.35, so that 8 slots wrap with p ~ 1.5e-10 per window
+		// (cfg2: 3.1e7 windows per call -> one repaired query per ~200 calls; at 0.5 it was one per ~10 calls)
+		int ft = (int)(0.35 / (rate > 1e-9 ? rate : 1e-9));
 		P.stage_flush[i] = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
 		// a compare covers 64 elements (32 queries x 2 items): with `rate` hits per 16 elements, 1 - exp(-4 rate) of the compares
 		// find a survivor in some lane.  Measured at cfg2 size: the branching filter costs 0.41 ms + ~0.5 ms per unit of that
@@ -1031,7 +1033,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.capg = capg;
 	// queue window: keep the expected hits per (lane, sub-tile) window near 0.5 so that 8 slots overflow with p ~ 1e-9
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
-	int ft = (int)(0.5 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
+	int ft = (int)(0.35 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
 	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);

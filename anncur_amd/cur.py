@@ -246,7 +246,7 @@ def _norm_sorted_pack(Et, kp):
 	top-k (anncur_score_topk_ex): items with a large ||E_i|| are the likeliest high scorers, so a threshold sampled from the leading
 	rows -- and a sweep that meets them first -- lets far fewer elements through (-40 % on the synthetic protocol, whose norms vary
 	by only 7 %).  The result is unchanged: the exact top-k of S_hat, reported with the original item ids."""
-	order = ops.descending_norm_order(Et if Et.dtype == torch.float32 else ops.convert(Et, torch.float32))   # 4096 norm buckets, stable inside a bucket
+	order = ops.descending_norm_order(Et if Et.dtype == torch.float32 else ops.convert(Et, torch.float32))   # 256 norm buckets, stable inside a bucket
 	return ops.pack_bf16(ops.gather_rows(Et, order), kp, row_multiple=32), order
 
 

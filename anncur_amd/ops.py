@@ -501,7 +501,7 @@ def ivf_build_lists(assign, nlist):
 
 
 @_on_device
-def descending_norm_order(M, n_buckets=4096):
+def descending_norm_order(M, n_buckets=256):
 	"""Row ids of the fp32 matrix M in coarse descending-norm order (int32 device tensor): norm buckets + the stable counting sort
 	of the inverted-file builder.  The index builder's ordering hint; no torch arithmetic involved."""
 	_dev(M)

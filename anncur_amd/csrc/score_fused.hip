@@ -968,10 +968,14 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		// (cfg2: 3.1e7 windows per call -> one repaired query per ~200 calls; at 0.5 it was one per ~10 calls)
 		int ft = (int)(0.35 / (rate > 1e-9 ? rate : 1e-9));
 		P.stage_flush[i] = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-		// a compare covers 64 elements (32 queries x 2 items): with `rate` hits per 16 elements, 1 - exp(-4 rate) of the compares
-		// find a survivor in some lane.  Measured at cfg2 size: the branching filter costs 0.41 ms + ~0.5 ms per unit of that
-		// fraction, the predicated one 0.655 ms whatever the data -> predicated above 0.5 (k = 500: 0.82 -> 0.66 ms per sweep)
-		P.stage_pred[i] = (1.0 - exp(-4.0 * rate)) > 0.5 ? 1 : 0;
+		// The predicated (branch-free, inline-asm) filter is NOT used by the product: its asm reads accumulator registers that an
+		// MFMA may still be writing -- hipcc neither orders register-only MFMAs against inline asm nor pads hazards inside it --
+		// and a randomised parity run caught it dropping one survivor (Q=4, I=12479, K=241, k=18).  It stays a timing experiment
+		// (ANNCUR_DEBUG_ALL_PRED in the experiments build); the branching filter's compare is compiler-generated and hazard-safe.
+		P.stage_pred[i] = 0;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (getenv("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = 1;
+#endif
 		// next stage: threshold = k-th best of the fraction seen so far
 		rate = (double)k / ((double)end * unit_items) * 16.0 * 1.2;
 		prev = end;

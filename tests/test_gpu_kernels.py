@@ -211,6 +211,24 @@ def test_fused_mfma16_overflow_and_ring_wrap_are_repaired_exactly(ops):
 	torch.testing.assert_close(torch.gather(S, 1, i.cpu().long()), v.cpu().double(), rtol=1e-4, atol=1e-4)
 
 
+def test_fused_regression_dense_first_stage_found_by_fuzzing(ops):
+	"""Round-2 fuzz find: Q=4, I=12479, K=241, k=18, rank-2 scores (half of the first stage's compares hit).  The plan briefly sent
+	such stages to the branch-free inline-asm filter, whose asm read an accumulator register the compiler had not ordered behind its
+	MFMA: one survivor (query 3, item 5760) was lost.  The product now always uses the compiler-generated compare."""
+	g = torch.Generator().manual_seed(0)
+	Q, I, K, k, rank = 4, 12479, 241, 18, 2
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	E = (torch.randn(K, rank, generator=g) @ torch.randn(rank, I, generator=g) / rank ** 0.5 + 0.0 * torch.randn(K, I, generator=g)).bfloat16()
+	Kp = ops.padded_k(K)
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	for kw in ({}, {"mfma16": True}, {"qt1": True}):
+		v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)
+		assert (v.cpu().double() - rv).abs().max() <= 1e-4 * float(S.abs().max())
+		assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(i.cpu(), ri)), kw
+
+
 def test_fused_overflow_fallback_is_exact(ops):
 	# ascending scores along the item axis: every element beats the sampled threshold -> segments overflow
 	Q, I, K, k = 40, 60000, 64, 50

@@ -73,12 +73,38 @@ def test_rowwise_topk_random(ops, Q, I, kfrac, bf16, kind, off, seed):
 
 @settings(max_examples=(_N // 4) or 25, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(Q=st.integers(1, 300), I=st.integers(2500, 90000), K=st.integers(8, 512), k=st.integers(1, 200), rank=st.integers(2, 48),
-	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6))
-def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed):
+	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), variant=st.sampled_from(["", "", "mfma16", "qt1"]))
+def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	g = torch.Generator().manual_seed(seed)
 	X = torch.randn(Q, K, generator=g).bfloat16()
 	E = (torch.randn(K, rank, generator=g) @ torch.randn(rank, I, generator=g) / rank ** 0.5 + noise * torch.randn(K, I, generator=g)).bfloat16()
 	Kp = ops.padded_k(K)
+	if not ops.fused_supported(Q, I, Kp, k):
+		return
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	v, i = ops.score_topk_fused(Xp, Etp, I, k, mfma16=variant == "mfma16", qt1=variant == "qt1")   # (sweep variants: same answer)
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	scale = float(S.abs().max()) + 1e-30
+	got = i.cpu().long()
+	assert (got >= 0).all() and (got < I).all() and all(len(set(r.tolist())) == k for r in got)
+	assert (v.cpu().double() - rv).abs().max() <= 1e-4 * scale
+	assert (torch.gather(S, 1, got) - v.cpu().double()).abs().max() <= 1e-4 * scale
+	assert ((v[:, :-1] >= v[:, 1:]).all())                       # sorted descending
+	# every selected item beats (up to fp32 round-off) the true k-th score
+	assert (torch.gather(S, 1, got).min(dim=1).values >= rv[:, -1] - 1e-4 * scale).all()
+
+
+@settings(max_examples=(_N // 8) or 12, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 600), I=st.integers(600, 60000), K=st.integers(513, 2300), k=st.integers(1, 300), rank=st.integers(2, 48),
+	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6))
+def test_wide_score_topk_random(ops, Q, I, K, k, rank, noise, seed):
+	"""The K-general kernel (Kp > 512: LDS-tiled GEMM with the filter as epilogue) on random shapes, against fp64."""
+	g = torch.Generator().manual_seed(seed)
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	E = (torch.randn(K, rank, generator=g) @ torch.randn(rank, I, generator=g) / rank ** 0.5 + noise * torch.randn(K, I, generator=g)).bfloat16()
+	Kp = ops.padded_k(K)
+	assert Kp > 512 and Kp % 128 == 0
 	if not ops.fused_supported(Q, I, Kp, k):
 		return
 	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
@@ -90,9 +116,33 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed):
 	assert (got >= 0).all() and (got < I).all() and all(len(set(r.tolist())) == k for r in got)
 	assert (v.cpu().double() - rv).abs().max() <= 1e-4 * scale
 	assert (torch.gather(S, 1, got) - v.cpu().double()).abs().max() <= 1e-4 * scale
-	assert ((v[:, :-1] >= v[:, 1:]).all())                       # sorted descending
-	# every selected item beats (up to fp32 round-off) the true k-th score
+	assert ((v[:, :-1] >= v[:, 1:]).all())
 	assert (torch.gather(S, 1, got).min(dim=1).values >= rv[:, -1] - 1e-4 * scale).all()
+
+
+@settings(max_examples=(_N // 10) or 8, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 400), I=st.integers(600, 40000), K=st.integers(513, 1100), k=st.integers(1, 300), levels=st.integers(1, 3),
+	   kind=st.sampled_from(["ties", "const", "hot"]), seed=st.integers(0, 10 ** 6))
+def test_wide_score_topk_random_ties_and_overflow(ops, Q, I, K, k, levels, kind, seed):
+	"""Small-integer operands through the K-general kernel: exact integer scores, ties everywhere, whole item ranges above the
+	sampled threshold (segment overflow -> the in-call repair).  The result must be THE top-k under the defined order."""
+	g = torch.Generator().manual_seed(seed)
+	X = torch.randint(0, levels + 1, (Q, K), generator=g).float()
+	if kind == "const":
+		E = torch.ones(K, I)
+	else:
+		E = torch.randint(-levels, levels + 1, (K, I), generator=g).float()
+		if kind == "hot":
+			width = min(3000, I // 3); lo = int(torch.randint(0, I - width, (1,), generator=g)); E[:, lo:lo + width] += levels + 1
+	Kp = ops.padded_k(K)
+	if not ops.fused_supported(Q, I, Kp, k):
+		return
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	v, i = ops.score_topk_fused(Xp, Etp, I, k)
+	S = X.double() @ E.double()
+	order = torch.argsort(S, dim=1, descending=True, stable=True)[:, :k]
+	assert torch.equal(v.cpu().double(), torch.gather(S, 1, order))
+	assert torch.equal(i.cpu().long(), order)
 
 
 @settings(max_examples=_N or 40, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
@@ -245,6 +295,11 @@ def test_entry_point_sweeps_random_vs_oracle(ops, n_train, n_test, n_ent, rank, 
 	got = harness.run_eval_method_cur(dev(A_test), dev(A_train), seed, grids)
 	want = O.run_eval_method_cur(A_test, A_train, seed, [1, 10], [k_retvr], anc_vals)
 	tol = 0.06 if bf16 else 0.02      # per-query boundary near-ties (and bf16 item embeddings) move single elements in and out
+	if bf16:
+		# bf16 exact scores tie often; the reference-faithful oracle inherits torch.topk's arbitrary tie order (its exact top-1 and
+		# its re-ranked top-1 can be two items of equal score, DESIGN.md section 2 "Ties"), this build orders ties by index: with
+		# few queries allow two queries' worth (found by a fresh-draw run: n_test = 22, recall@1 1.0 vs 0.909)
+		tol = max(tol, 2.01 / n_test)
 	for k in (1, 10):
 		for n_anc in anc_vals:
 			cell = f"anc_n_m={n_train}_anc_n_e={n_anc}"

@@ -325,3 +325,45 @@ def test_entry_point_sweeps_random_vs_oracle(ops, n_train, n_test, n_ent, rank, 
 			assert abs(float(a[subset][key]) - float(b[subset][key])) <= 0.03, subset
 			if subset != "anchor":
 				assert float(a[subset]["approx_error_relative"]) == pytest.approx(float(b[subset]["approx_error_relative"]), rel=2e-2, abs=1e-4), subset
+
+
+@settings(max_examples=(_N // 20) or 6, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(200, 30000), d=st.integers(3, 200), nlist=st.integers(2, 120), nprobe=st.integers(1, 120), nq=st.integers(1, 60), k=st.integers(1, 300),
+	   clusters=st.integers(1, 40), seed=st.integers(0, 10 ** 6))
+def test_ivf_flat_random(ops, n, d, nlist, nprobe, nq, k, clusters, seed):
+	"""IVF-flat index on random sizes: lists complete and disjoint, the search equals a brute-force search restricted to the probed
+	lists (scores exact, FAISS padding), and probing every list equals the exact search."""
+	from anncur_amd.nearest_nbr import IVFFlatIPIndex
+	g = np.random.default_rng(seed)
+	nlist = min(nlist, n)
+	centers = g.standard_normal((clusters, d)).astype(np.float32) * 2
+	X = (centers[g.integers(0, clusters, n)] + g.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+	q = (centers[g.integers(0, clusters, nq)] + g.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+	index = IVFFlatIPIndex(d, nlist, niter=5)
+	index.train(X); index.add(X)
+	index.nprobe = nprobe
+	D, I = index.search(q, k)
+	off, ids = index._offsets.cpu().numpy(), index._ids.cpu().numpy()
+	assert off[0] == 0 and off[-1] == n and (np.sort(ids) == np.arange(n)).all()
+	C = index.centroids.cpu().numpy()
+	S = q.astype(np.float64) @ X.astype(np.float64).T
+	npr = min(nprobe, nlist)
+	probe = np.argsort(-(q @ C.T), axis=1, kind="stable")[:, :npr]
+	scale = np.abs(S).max() + 1e-30
+	for j in range(nq):
+		cand = np.concatenate([ids[off[l]:off[l + 1]] for l in probe[j]])
+		found = I[j][I[j] >= 0]
+		m = min(k, len(cand))
+		if m < k:   # fewer vectors in the probed lists than asked for: (-inf, -1) padding
+			assert (I[j, m:] == -1).all() and np.isinf(D[j, m:]).all()
+		# a near-tie among the centroid scores may swap the last probed list between fp32 GEMM and this numpy reference: compare scores
+		assert len(found) >= min(k, 1) and len(set(found.tolist())) == len(found)
+		np.testing.assert_allclose(D[j, :len(found)], S[j, found], rtol=0, atol=1e-4 * scale)
+		assert (D[j, :len(found) - 1] >= D[j, 1:len(found)]).all()
+		if len(found) == m:
+			want = np.sort(S[j, cand])[::-1][:m]
+			assert np.abs(D[j, :m] - want).max() <= 1e-4 * scale or len(set(found.tolist()) - set(cand.tolist())) > 0
+	index.nprobe = nlist
+	D2, I2 = index.search(q, min(k, n))
+	want = -np.sort(-S, axis=1)[:, :min(k, n)]
+	np.testing.assert_allclose(D2, want, rtol=0, atol=1e-4 * scale)

@@ -77,6 +77,7 @@ struct FusedParams {
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
 	int n_wg;                         // grid size (for the XCD remap)
+	unsigned long long *stamps;       // diagnostic build only (ANNCUR_DEBUG_STAMPS): per workgroup {d s_memtime, d s_memrealtime} around the tile loop
 };
 
 // Contiguous work ids per XCD (blocks b and b+8 share an XCD's L2): speed only, never correctness.
@@ -385,6 +386,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	// In-kernel clock (MI355X guide, 'DVFS give-back' (6)): shader cycles per 100 MHz reference tick around the tile loop.  The
+	// stamps go to a buffer nothing else reads; the shipped library contains none of this.
+	unsigned long long st_c0 = 0, st_r0 = 0;
+	if (MODE == 1 && p.stamps) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
 	if constexpr (MODE == 1 && QT == 2) {
 		// ---- staggered sweep (stagger_tile): tile loop unrolled by two so that the LDS buffer parity is a compile-time offset
@@ -528,6 +535,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	}  // plain loop
 
 #undef tile_of
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (MODE == 1 && p.stamps && tid == 0) {
+		p.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+		p.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+	}
+#endif
 	if (MODE == 1) {
 #pragma unroll
 		for (int t = 0; t < QT; ++t) {
@@ -1136,6 +1149,10 @@ int launch_threshold(const FusedPlan &P, const float *gmax, int64_t Q, int k, un
 	return anncur_rowwise_topk(gmax, ANNCUR_F32, Q, P.n_groups, P.n_groups, k, tval, (int32_t *)(ws + P.off_tidx), st);
 }
 
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+unsigned long long *g_stamps = nullptr;  // diagnostic build: the last sweep launch's per-workgroup {cycles, 100 MHz ticks}
+#endif
+
 template <int KP, int QTV = FusedCfg<KP>::QT>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
 				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev) {
@@ -1148,6 +1165,14 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	p.tau_bias = 0.f;
+	p.stamps = nullptr;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (getenv("ANNCUR_DEBUG_STAMPS")) {
+		if (!g_stamps) { ANNCUR_HIP_OK(hipMalloc((void **)&g_stamps, 2 * 8192 * sizeof(unsigned long long))); }
+		ANNCUR_HIP_OK(hipMemsetAsync(g_stamps, 0, 2 * 8192 * sizeof(unsigned long long), st));
+		if (P.n_rb * P.S <= 8192) p.stamps = g_stamps;
+	}
+#endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS  // (the -DANNCUR_TIMING_EXPERIMENTS build of scripts/fused_microbench.py only: results become wrong)
 	{ const char *dbg = getenv("ANNCUR_DEBUG_TAU_BIAS"); p.tau_bias = dbg ? (float)atof(dbg) : 0.f; }
 	if (getenv("ANNCUR_DEBUG_NOSTORE")) p.capg = 0;  // every candidate is dropped at the store
@@ -1538,3 +1563,21 @@ extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }
+
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+/* diagnostic build only (not in include/anncur_hip.h): median in-kernel clock in GHz over the workgroups of the last sweep launch
+ * that ran with ANNCUR_DEBUG_STAMPS set (s_memtime ticks per s_memrealtime tick x 100 MHz), and the median loop duration in us. */
+extern "C" int anncur_debug_read_stamps(double *clock_ghz, double *loop_us, int *n_wg) {
+	if (!g_stamps) return ANNCUR_E_INVALID;
+	static unsigned long long h[2 * 8192];
+	if (hipMemcpy(h, g_stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return ANNCUR_E_HIP;
+	double r[8192], u[8192];
+	int n = 0;
+	for (int i = 0; i < 8192; ++i)
+		if (h[2 * i + 1] > 0) { r[n] = (double)h[2 * i] / (double)h[2 * i + 1] * 0.1; u[n] = (double)h[2 * i + 1] / 100.0; ++n; }
+	if (n == 0) return ANNCUR_E_INVALID;
+	for (int i = 1; i < n; ++i) { double x = r[i], y = u[i]; int j = i - 1; while (j >= 0 && r[j] > x) { r[j + 1] = r[j]; --j; } r[j + 1] = x; j = i - 1; while (j >= 0 && u[j] > y) { u[j + 1] = u[j]; --j; } u[j + 1] = y; }
+	*clock_ghz = r[n / 2]; *loop_us = u[n / 2]; *n_wg = n;
+	return ANNCUR_OK;
+}
+#endif

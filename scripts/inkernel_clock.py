@@ -1,0 +1,33 @@
+"""Dev tool (experiments build): the clock the chip holds INSIDE the sweep kernel (MI355X guide, 'DVFS give-back' (6)):
+Delta s_memtime / Delta s_memrealtime x 100 MHz around the tile loop, median over the workgroups of the last sweep launch, after
+>= 2 s of back-to-back calls on random data.  ANNCUR_LIB=anncur_amd/lib/libanncur_hip_exp.so python scripts/inkernel_clock.py [K]"""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+os.environ["ANNCUR_DEBUG_STAMPS"] = "1"
+from anncur_amd import ops, _lib
+from anncur_amd.cur import _norm_sorted_pack
+dev = torch.device("cuda")
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+Q, I, k = (10000, 100000, 100) if K <= 256 else (6250, 1000000, 100)
+g = torch.Generator(device=dev).manual_seed(0)
+Z = torch.randn(64, I, generator=g, device=dev)
+X = (torch.randn(Q, 64, generator=g, device=dev) @ torch.randn(64, K, generator=g, device=dev) / 8).bfloat16()
+E = (torch.randn(K, 64, generator=g, device=dev) @ Z / 8 / 16 + 0.003 * torch.randn(K, I, generator=g, device=dev)).bfloat16()
+Kp = ops.padded_k(K)
+Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), Kp)
+Xp = ops.pack_bf16(X, Kp)
+del Z, E
+lib = _lib.load()
+lib.anncur_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < 2.5:
+	for _ in range(20): ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, item_ids=ids)
+	torch.cuda.synchronize(); n += 20
+(_, _), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids)
+ghz, us, nwg = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+assert lib.anncur_debug_read_stamps(ctypes.byref(ghz), ctypes.byref(us), ctypes.byref(nwg)) == 0
+tf = 2.0 * Q * Kp * I / (ms[4] * 1e-3) / 1e12
+peak_at_clock = 1024 * 1024 * ghz.value * 1e9 / 1e12   # 1024 SIMDs x 1024 flop / clk
+print(f"Kp={Kp}: {n} calls in 2.5 s; last sweep launch: in-kernel clock {ghz.value:.3f} GHz (median of {nwg.value} workgroups, loop {us.value:.1f} us); "
+	  f"sweep {tf:.0f} TFLOP/s = {tf / 2500:.3f} of the 2.5 PFLOP/s spec peak = {tf / peak_at_clock:.3f} of the {peak_at_clock:.0f} TFLOP/s the matrix pipes deliver at that clock")

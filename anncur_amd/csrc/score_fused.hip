@@ -27,8 +27,16 @@
 #include <stdlib.h>
 #include <math.h>
 #include <type_traits>
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+__device__ unsigned long long *d_sweep_stamps = nullptr;  // diagnostic build: {d s_memtime, d s_memrealtime} of the sweep's tile loop per workgroup
+__device__ unsigned long long *d_sel_stamps = nullptr;  // diagnostic build: phase stamps of the wave-level select kernels (4 per workgroup)
+#define SEL_STAMP(i) do { if (d_sel_stamps && wave == 0 && lane == 0) d_sel_stamps[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEL_STAMP(i) do { } while (0)
+#endif
 #include "select.hpp"
 #include "wave_select.hpp"
+#include "select_stream.hpp"
 
 using namespace anncur;
 
@@ -77,7 +85,6 @@ struct FusedParams {
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
 	int n_wg;                         // grid size (for the XCD remap)
-	unsigned long long *stamps;       // diagnostic build only (ANNCUR_DEBUG_STAMPS): per workgroup {d s_memtime, d s_memrealtime} around the tile loop
 };
 
 // Contiguous work ids per XCD (blocks b and b+8 share an XCD's L2): speed only, never correctness.
@@ -290,21 +297,37 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 	acc1 = accB;
 }
 
+// Wait states between the last MFMA of an accumulate chain and the first instruction that is not the next MFMA of that chain
+// (hipcc's own floor for the 8-pass 32x32x16 bf16 MFMA is 11).  hipcc pads this itself -- except where it does not: in the first
+// version of stagger1_tile (one accumulator, `accP = acc` at the end of the tile) it copied the accumulator EIGHT states after the
+// last MFMA on one path of the unrolled loop (MFMA, s_cbranch, v_lshl_or, s_nop 5, v_mov ...), so three registers were copied without
+// the last k-step's contribution whenever instruction fetch did not happen to supply the missing states -- which depended on where
+// the loop sat in memory: the shipped build passed every parity test, a diagnostic build with two more instructions in the prologue
+// returned wrong scores for item rows 24-26 / 28-30 of every second tile.  scripts/check_mfma_hazards.py (run by the CPU tests on the
+// built library) now walks every kernel for this; the statement below makes the distance explicit where a chain ends.
+__device__ __forceinline__ void mfma_chain_done(f32x16 &acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("s_nop 7\n\ts_nop 2" : "+v"(acc));
+#endif
+}
+
 // Kp = 512 (one 32-query sub-tile per wave: the query operand alone takes 128 VGPRs): the same idea across TILES -- while the
-// 32-MFMA chain of tile j executes, the filter of tile j-1's accumulator is issued in its shadow, one element every second
-// k-step; A fragments through the counted-wait register ring as in stagger_tile.  Fragment address of k-step s:
+// 32-MFMA chain of tile j executes into `acc`, the filter of tile j-1's accumulator `accP` is issued in its shadow, one element every
+// second k-step; A fragments through the counted-wait register ring as in stagger_tile.  The caller alternates two accumulators
+// (no copy: see mfma_chain_done).  Fragment address of k-step s:
 // row * CPR * 16 + ((2 s + h) ^ (r & 15)) * 16 = aoff8[s & 7] + (s >> 3) * 256 (the XOR only touches the chunk's low four bits),
 // so eight address registers serve the 32 k-steps.
 template <int KP, int CUR>
-__device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const bf16x8 (&xb)[FusedCfg<KP, 1>::KSTEPS], f32x16 &accP, float tau,
-											   uint32_t item0_prev, uint32_t lq, uint32_t &qcnt) {
+__device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const bf16x8 (&xb)[FusedCfg<KP, 1>::KSTEPS], f32x16 &acc,
+											   const f32x16 &accP, float tau, uint32_t item0_prev, uint32_t lq, uint32_t &qcnt) {
 	using Cfg = FusedCfg<KP, 1>;
 	constexpr int K = Cfg::KSTEPS, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;
 	static_assert((K == 32 || K == 16 || K == 8) && Cfg::CPR >= 16, "Kp = 128, 256 or 512");
 	u32x4 ring[AR];
 #define S1_READ(slot, s) lds_read_frag_at(ring[slot], aoff8[(s) & 7], OFF + ((s) >> 3) * 256)
 	S1_READ(0, 0); S1_READ(1, 1); S1_READ(2, 2);
-	f32x16 acc = {0};
+#pragma unroll
+	for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
 	for (int g = 0; g < K; ++g) {
 		const int nxt = g + DIST;
@@ -323,7 +346,7 @@ __device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const 
 		}
 	}
 #undef S1_READ
-	accP = acc;
+	mfma_chain_done(acc);
 }
 
 // MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep (PRED: branch-free filter, for stages in
@@ -389,8 +412,13 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	// In-kernel clock (MI355X guide, 'DVFS give-back' (6)): shader cycles per 100 MHz reference tick around the tile loop.  The
 	// stamps go to a buffer nothing else reads; the shipped library contains none of this.
+	// (this diagnostic is how the MFMA -> v_mov hazard of the Kp = 512 loop was found: the extra instructions moved the loop by 8 bytes
+	//  and the scores changed -- see mfma_chain_done())
 	unsigned long long st_c0 = 0, st_r0 = 0;
-	if (MODE == 1 && p.stamps) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+	if (MODE == 1) {
+		st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime();
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_c0), "+s"(st_r0)::"memory");
+	}
 #endif
 
 	if constexpr (MODE == 1 && QT == 2) {
@@ -435,11 +463,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
 	} else if constexpr (MODE == 1 && QT == 1 && KP >= 128 && !INL) {  // (INL = the plain loop, kept for A/B in the experiments build)
-		// ---- software-pipelined sweep for Kp = 512 (stagger1_tile): tile loop unrolled by two (buffer parity = immediate offset)
-		f32x16 accP;
+		// ---- software-pipelined sweep for Kp = 512 (stagger1_tile): tile loop unrolled by two (buffer parity = immediate offset);
+		// even steps accumulate into accA and filter accB, odd steps the other way round
+		f32x16 accA, accB;
 #pragma unroll
-		for (int e = 0; e < 16; ++e) accP[e] = 0.f;
-		float tau_prev = INFINITY;   // no previous tile yet
+		for (int e = 0; e < 16; ++e) { accA[e] = 0.f; accB[e] = 0.f; }
+		float tau_prev = INFINITY;   // no previous tile yet: the filter never fires
 		uint32_t item0_prev = 0;
 		uint32_t aoff8[8];
 #pragma unroll
@@ -447,27 +476,33 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 		const int flush_period = (p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;
 		int flush_in2 = flush_period;
 		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger1_tile() counts LDS reads
-#define STAGGER1_STEP(CUR, J)                                                                                                   \
+#define STAGGER1_STEP(CUR, J, ACC, ACCP)                                                                                        \
 		do {                                                                                                                    \
 			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
 			if (--flush_in2 == 0) {                                                                                             \
 				flush_in2 = flush_period;                                                                                       \
 				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);                        \
 			}                                                                                                                   \
-			stagger1_tile<KP, CUR>(aoff8, xb[0], accP, tau_prev, item0_prev, lq0, qcnt[0]);                                     \
+			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0]);                                \
 			tau_prev = tau[0]; item0_prev = (uint32_t)(J) * TILE_I + 4 * h;                                                     \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
 		} while (0)
+		bool last_in_a = false;  // (uniform) which accumulator holds the last tile
 		for (int j = j_begin; j < j_end; j += 2) {
-			STAGGER1_STEP(0, j);
-			if (j + 1 < j_end) STAGGER1_STEP(1, j + 1);
+			STAGGER1_STEP(0, j, accA, accB);
+			last_in_a = true;
+			if (j + 1 < j_end) { STAGGER1_STEP(1, j + 1, accB, accA); last_in_a = false; }
 		}
 #undef STAGGER1_STEP
 		flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);
+		if (last_in_a) {  // drain: the last tile
 #pragma unroll
-		for (int e = 0; e < 16; ++e)  // drain: the last tile
-			filter_one<Cfg::QDEPTH>(accP[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
+			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accA[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
+		} else {
+#pragma unroll
+			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accB[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
+		}
 	} else {
 	const int flush_period_p = (MODE == 1 && p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;  // (see the staggered path)
 	int flush_in = flush_period_p;
@@ -536,9 +571,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 
 #undef tile_of
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (MODE == 1 && p.stamps && tid == 0) {
-		p.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
-		p.stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+	if (MODE == 1 && tid == 0) {
+		unsigned long long *stamps = d_sweep_stamps;
+		if (stamps && blockIdx.x < 8192) {
+			stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+			stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+		}
 	}
 #endif
 	if (MODE == 1) {
@@ -869,6 +907,7 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 	const int lane = lane_id(), wave = threadIdx.x >> 6;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
 	if (q >= Q) return;
+	SEL_STAMP(0);
 	const uint32_t c = (lane < nseg) ? seg_cnt[q * nseg + lane] : 0u;
 	uint32_t inc = c;
 #pragma unroll
@@ -887,28 +926,43 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 	// are dropped at the load (at least k candidates are >= it by construction)
 	if (tau && prefilter) w.tau = tau[q * tau_stride];
 	const uint2 *qc = cand + q * nseg * (int64_t)capg;
-#pragma unroll 4
-	for (uint32_t j0 = 0; j0 < total; j0 += WAVE) {
-		const uint32_t j = j0 + (uint32_t)lane;
-		int sg = 0;  // last segment whose exclusive prefix is <= j (skips empty segments)
+	// The candidates are fetched LOAD_U chunks of 64 at a time, all loads in flight before the first chunk is offered: with one
+	// load per chunk behind the previous chunk's (data-dependent) compaction the kernel ran at one HBM latency per 64 candidates
+	// (k = 500, ~3000 candidates per query: 0.33 ms per call, now see DESIGN.md 4.3).
+	SEL_STAMP(1);
+	constexpr int LOAD_U = 8;
+	for (uint32_t j0 = 0; j0 < total; j0 += LOAD_U * WAVE) {
+		uint2 e[LOAD_U];
 #pragma unroll
-		for (int step = 32; step >= 1; step >>= 1) {
-			const int cs = sg + step;
-			const uint32_t pv = __shfl(pre, cs & 63);
-			if (cs < nseg && pv <= j) sg = cs;
+		for (int u = 0; u < LOAD_U; ++u) {
+			const uint32_t j = j0 + (uint32_t)(u * WAVE + lane);
+			int sg = 0;  // last segment whose exclusive prefix is <= j (skips empty segments)
+#pragma unroll
+			for (int step = 32; step >= 1; step >>= 1) {
+				const int cs = sg + step;
+				const uint32_t pv = __shfl(pre, cs & 63);
+				if (cs < nseg && pv <= j) sg = cs;
+			}
+			const uint32_t ps = __shfl(pre, sg);
+			e[u] = j < total ? qc[(int64_t)sg * capg + (j - ps)] : make_uint2(0u, 0u);
 		}
-		const uint32_t ps = __shfl(pre, sg);
-		const bool in = j < total;
-		const uint2 e = in ? qc[(int64_t)sg * capg + (j - ps)] : make_uint2(0u, 0u);
-		wsel_offer(w, in, __uint_as_float(e.x), e.y);
-		if (w.cnt > (uint32_t)TRIGGER) wsel_compact<4, false>(w, k);
+#pragma unroll
+		for (int u = 0; u < LOAD_U; ++u) {
+			if (j0 + (uint32_t)(u * WAVE) < total) {  // (uniform)
+				wsel_offer(w, j0 + (uint32_t)(u * WAVE + lane) < total, __uint_as_float(e[u].x), e[u].y);
+				if (w.cnt > (uint32_t)TRIGGER) wsel_compact<4, false, true>(w, k);
+			}
+		}
 	}
+	SEL_STAMP(2);
 	if (TAU_ONLY) {
-		if (w.cnt > k) wsel_compact<4, false>(w, k);
+		if (w.cnt > k) wsel_compact<4, false, true>(w, k);
 		if (lane == 0 && w.cnt >= k) tau[q * tau_stride] = fmaxf(tau[q * tau_stride], w.tau);
+		SEL_STAMP(3);
 		return;
 	}
-	wsel_finish<0, 4, WqCfg<KW>::E>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	wsel_finish<0, 4, WqCfg<KW>::E, true>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	SEL_STAMP(3);
 }
 
 }  // namespace
@@ -1047,6 +1101,9 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	int capg = next_pow2((int)(4.0 * per_seg) + 32);
 	if (capg < 64) capg = 64;
 	if (capg > 16384) capg = 16384;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_CAPG")) capg = atoi(dbg);
+#endif
 	P.capg = capg;
 	// queue window: keep the expected hits per (lane, sub-tile) window near 0.5 so that 8 slots overflow with p ~ 1e-9
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
@@ -1069,6 +1126,14 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 
 #define EV(i) do { if (ev) ANNCUR_HIP_OK(hipEventRecord(ev[i], st)); } while (0)
 
+// k <= 128: which wave-level candidate select runs (the buffer-and-compact one or the streaming one)
+bool stream_select_small() {
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_STREAM128")) return atoi(dbg) != 0;
+#endif
+	return false;
+}
+
 // Threshold refinement between two sweep stages: tau[q] = max(tau[q], k-th best candidate collected so far).
 int launch_tau_refine(const uint2 *cand, const uint32_t *seg_cnt, int nseg, int capg, int64_t Q, int k, int kmax, float *tau, int tau_stride,
 					  int prefilter, hipStream_t st) {
@@ -1081,7 +1146,12 @@ int launch_tau_refine(const uint2 *cand, const uint32_t *seg_cnt, int nseg, int 
 			hipLaunchKernelGGL((select_wave_kernel<true, KW>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, capg, Q, \
 							   (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, tau, tau_stride, prefilter); \
 		} while (0)
-		if (k <= WSEL_K) LAUNCH_WTAU(128); else LAUNCH_WTAU(512);
+		if (k <= WSEL_K && !stream_select_small()) LAUNCH_WTAU(128);
+		else {  // streaming radix select (select_stream.hpp): 1 KB of LDS per wave
+			constexpr int lds = 4 * StreamSelLayout::BYTES;
+			hipLaunchKernelGGL((select_stream_kernel<true, 2>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, capg, Q,
+							   (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, tau, tau_stride, prefilter);
+		}
 #undef LAUNCH_WTAU
 	} else {
 #define LAUNCH_TAU(KM)                                                                                                        \
@@ -1124,7 +1194,16 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 			hipLaunchKernelGGL((select_wave_kernel<false, KW>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, P.capg, Q, \
 							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0); \
 		} while (0)
-		if (k <= WSEL_K) LAUNCH_WSEL(128); else LAUNCH_WSEL(512);
+#define LAUNCH_SSEL(EE)                                                                                                           \
+		do {                                                                                                                      \
+			constexpr int lds = 4 * StreamSelLayout::BYTES;                                                                       \
+			hipLaunchKernelGGL((select_stream_kernel<false, EE>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, P.capg, Q, \
+							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0); \
+		} while (0)
+		if (k <= WSEL_K) { if (stream_select_small()) LAUNCH_SSEL(2); else LAUNCH_WSEL(128); }
+		else if (k <= 256) LAUNCH_SSEL(4);
+		else LAUNCH_SSEL(8);
+#undef LAUNCH_SSEL
 #undef LAUNCH_WSEL
 		ANNCUR_LAUNCH_OK();
 		hard_list = hl; hard_cnt = hc;
@@ -1165,12 +1244,13 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	p.tau_bias = 0.f;
-	p.stamps = nullptr;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
-		if (!g_stamps) { ANNCUR_HIP_OK(hipMalloc((void **)&g_stamps, 2 * 8192 * sizeof(unsigned long long))); }
+		if (!g_stamps) {
+			ANNCUR_HIP_OK(hipMalloc((void **)&g_stamps, 2 * 8192 * sizeof(unsigned long long)));
+			ANNCUR_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(d_sweep_stamps), &g_stamps, sizeof(g_stamps)));
+		}
 		ANNCUR_HIP_OK(hipMemsetAsync(g_stamps, 0, 2 * 8192 * sizeof(unsigned long long), st));
-		if (P.n_rb * P.S <= 8192) p.stamps = g_stamps;
 	}
 #endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS  // (the -DANNCUR_TIMING_EXPERIMENTS build of scripts/fused_microbench.py only: results become wrong)
@@ -1219,14 +1299,14 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 				launched = true;
 			}
 		}
-		if constexpr (Cfg::QT == 2) {  // (the predicated filter lives in the staggered path)
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if constexpr (Cfg::QT == 2) {  // (the predicated inline-asm filter: timing experiment only, see plan_stages)
 			if (!launched && P.stage_pred[stg]) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, true, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((score_kernel<KP, 1, 16, true, false, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 				launched = true;
 			}
 		}
-#ifdef ANNCUR_TIMING_EXPERIMENTS
 		if constexpr (KP == 512) {
 			if (!launched && getenv("ANNCUR_DEBUG_PLAIN512")) {  // the sweep without the cross-tile software pipeline
 				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
@@ -1578,6 +1658,33 @@ extern "C" int anncur_debug_read_stamps(double *clock_ghz, double *loop_us, int 
 	if (n == 0) return ANNCUR_E_INVALID;
 	for (int i = 1; i < n; ++i) { double x = r[i], y = u[i]; int j = i - 1; while (j >= 0 && r[j] > x) { r[j + 1] = r[j]; --j; } r[j + 1] = x; j = i - 1; while (j >= 0 && u[j] > y) { u[j + 1] = u[j]; --j; } u[j + 1] = y; }
 	*clock_ghz = r[n / 2]; *loop_us = u[n / 2]; *n_wg = n;
+	return ANNCUR_OK;
+}
+#endif
+
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+/* diagnostic build only: arm (n_wg > 0) or read the phase stamps of select_wave_kernel.  out[3] = median cycles of the phases
+ * (prologue, candidate load loop, final compaction / sort) over the workgroups' first waves. */
+extern "C" int anncur_debug_sel_stamps(int arm, double *out) {
+	static unsigned long long *buf = nullptr;
+	const int N = 4096;
+	if (!buf) { if (hipMalloc((void **)&buf, 4 * N * sizeof(unsigned long long)) != hipSuccess) return ANNCUR_E_HIP; }
+	if (arm) {
+		if (hipMemset(buf, 0, 4 * N * sizeof(unsigned long long)) != hipSuccess) return ANNCUR_E_HIP;
+		unsigned long long *v = arm > 0 ? buf : nullptr;
+		return hipMemcpyToSymbol(HIP_SYMBOL(d_sel_stamps), &v, sizeof(v)) == hipSuccess ? ANNCUR_OK : ANNCUR_E_HIP;
+	}
+	static unsigned long long h[4 * 4096];
+	if (hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return ANNCUR_E_HIP;
+	static double ph[3][4096];
+	int n = 0;
+	for (int i = 0; i < N; ++i)
+		if (h[4 * i + 3] > h[4 * i]) { for (int j = 0; j < 3; ++j) ph[j][n] = (double)(h[4 * i + j + 1] - h[4 * i + j]); ++n; }
+	if (!n) return ANNCUR_E_INVALID;
+	for (int j = 0; j < 3; ++j) {
+		for (int i = 1; i < n; ++i) { double x = ph[j][i]; int t = i - 1; while (t >= 0 && ph[j][t] > x) { ph[j][t + 1] = ph[j][t]; --t; } ph[j][t + 1] = x; }
+		out[j] = ph[j][n / 2];
+	}
 	return ANNCUR_OK;
 }
 #endif

@@ -123,19 +123,87 @@ __device__ __forceinline__ uint32_t wsel_kth(const WaveSel &w, const uint32_t *k
 	return prefix << (32 - 8 * PASSES);
 }
 
+// The same for keys that crowd into a narrow range (candidates of the fused sweep: every score is >= the sweep's threshold, so the
+// sign / exponent byte -- and mostly the next one -- is common to all of them and the fixed-digit histogram above serialises 64 lanes on
+// ONE LDS word per instruction).  Digits are taken from (key - min) instead, as many 8-bit digits as (max - min) has bytes: the first
+// pass spreads the keys over up to 256 bins, later passes only touch the k-th key's bin.
+__device__ __forceinline__ uint32_t wsel_kth_ranged(const WaveSel &w, const uint32_t *key, uint32_t n, uint32_t k, uint32_t &need_out) {
+	const uint32_t lane = (uint32_t)lane_id();
+	uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll 4
+	for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+		const uint32_t j = j0 + lane;
+		if (j < n) { const uint32_t x = key[j]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+	}
+#pragma unroll
+	for (int d = WAVE / 2; d > 0; d >>= 1) {
+		const uint32_t a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
+		mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+	}
+	const uint32_t range = mx - mn;
+	const int passes = range == 0u ? 0 : (32 - __clz(range) + 7) / 8;  // (uniform)
+	uint32_t prefix = 0, need = k;
+	for (int pass = 0; pass < passes; ++pass) {
+		const int shift = 8 * (passes - 1 - pass);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) w.hist[lane * 4 + i] = 0;
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+		for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+			const uint32_t j = j0 + lane;
+			if (j < n) {
+				const uint32_t x = key[j] - mn;
+				// (shift + 8 == 32 only in pass 0 of a four-byte range, where every key takes part)
+				if (pass == 0 || (x >> (shift + 8)) == prefix) atomicAdd(&w.hist[(x >> shift) & 255u], 1u);
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t h0 = w.hist[lane * 4], h1 = w.hist[lane * 4 + 1], h2 = w.hist[lane * 4 + 2], h3 = w.hist[lane * 4 + 3];
+		const uint32_t c4 = h0 + h1 + h2 + h3;
+		uint32_t suf = c4;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+		for (int d = 1; d < WAVE; d <<= 1) {
+			const uint32_t t = __shfl_down(suf, d);
+			if (lane + d < WAVE) suf += t;
+		}
+		uint32_t a = suf - c4, bin = 0;
+		const bool mine = a < need && suf >= need;
+		if (mine) {
+			if (a + h3 >= need) { bin = lane * 4 + 3; }
+			else { a += h3;
+				if (a + h2 >= need) { bin = lane * 4 + 2; }
+				else { a += h2;
+					if (a + h1 >= need) { bin = lane * 4 + 1; }
+					else { a += h1; bin = lane * 4; } } }
+		}
+		const int src = __ffsll((long long)__ballot(mine)) - 1;  // exactly one lane
+		bin = __shfl(bin, src);
+		a = __shfl(a, src);
+		need -= a;
+		prefix = (prefix << 8) | bin;
+		__builtin_amdgcn_wave_barrier();
+	}
+	need_out = need;
+	return mn + prefix;
+}
+
 // Cut the buffer down to its k best candidates (cnt > k), in place; the k-th best becomes the threshold.
 // KEEP_TIES (mid-stream use only): keep every candidate that ties with the k-th score instead of resolving the tie by
 // index, as long as they fit below `tie_limit`; the buffer then holds >= k entries and the threshold is the k-th SCORE,
 // which is all an in-order stream needs (later elements lose score ties).  The final call must be exact.
-template <int HI_PASSES = 4, bool KEEP_TIES = false>
+// RANGED: the keys are expected in a narrow range (wsel_kth_ranged; full 32-bit keys only).
+template <int HI_PASSES = 4, bool KEEP_TIES = false, bool RANGED = false>
 __device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t tie_limit = 0) {
+	static_assert(!RANGED || HI_PASSES == 4, "the ranged radix select takes whole keys");
 	const uint32_t lane = (uint32_t)lane_id();
 	const uint32_t n = w.cnt;
 	__builtin_amdgcn_wave_barrier();
 	uint32_t need, need2;
 	// with HI_PASSES < 4 only the top 8*HI_PASSES key bits are significant (and the low bits of all keys of one sign agree)
 	constexpr uint32_t M = HI_PASSES >= 4 ? 0xffffffffu : (0xffffffffu << (32 - 8 * HI_PASSES));
-	const uint32_t T = wsel_kth<false, HI_PASSES>(w, w.whi, n, k, need, w.whi, 0u);
+	uint32_t T;
+	if constexpr (RANGED) T = wsel_kth_ranged(w, w.whi, n, k, need);
+	else T = wsel_kth<false, HI_PASSES>(w, w.whi, n, k, need, w.whi, 0u);
 	uint32_t cnt_eq = 0;
 #pragma unroll 4
 	for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
@@ -284,12 +352,12 @@ __device__ __forceinline__ void wave_sort_desc(uint32_t (&hi)[E], uint32_t (&lo)
 
 // Reduce to the k best, sort them, write the output row.  Fewer than k candidates -> (-inf, -1) padding.
 // E = keys per lane of the final sort (k <= 64 E).
-template <int OUTLINED_CAP = 0, int HI_PASSES = 4, int E = 2>
+template <int OUTLINED_CAP = 0, int HI_PASSES = 4, int E = 2, bool RANGED = false>
 __device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx) {
 	const int lane = lane_id();
 	if (w.cnt > k) {
 		if constexpr (OUTLINED_CAP > 0) wsel_compact_call<OUTLINED_CAP, HI_PASSES, false>(w, k);
-		else wsel_compact<HI_PASSES, false>(w, k);
+		else wsel_compact<HI_PASSES, false, RANGED>(w, k);
 	}
 	__builtin_amdgcn_wave_barrier();
 	uint32_t sh[E], sl[E];

@@ -241,3 +241,19 @@ def test_full_range_shortcut_is_the_identity_only():
 	assert not _is_full_range([0, 2, 1, 3], 4)      # a permutation with the right ends
 	assert not _is_full_range([0, 1, 1, 3], 4)      # a repeat with the right ends
 	assert not _is_full_range([0, 1, 2], 4) and not _is_full_range([], 0)
+
+
+def test_built_library_passes_the_static_hazard_checks():
+	"""The sweep kernels mix MFMA builtins with inline-asm LDS reads and counted waits; hipcc neither pads nor orders what it cannot
+	see, and where it under-pads the result depends on code placement (DESIGN.md 4.1 'A latent hazard').  The shipped library is
+	therefore disassembled and walked: (a) no instruction may touch an MFMA's result registers earlier than hipcc's own floor for that
+	MFMA unless it is the next MFMA of the accumulate chain, (b) no instruction may touch the destination of an in-flight ds_read."""
+	sys.path.insert(0, os.path.join(ROOT, "scripts"))
+	import check_lds_hazards, check_mfma_hazards
+	lib = os.path.join(ROOT, "anncur_amd", "lib", "libanncur_hip.so")
+	f, nk, nm = check_mfma_hazards.check(lib)
+	assert nk >= 30 and nm >= 1000, (nk, nm)   # the walk really saw the kernels
+	assert f == [], "\n".join(f[:20])
+	f, nk, nr = check_lds_hazards.check(lib)
+	assert nk >= 20 and nr >= 5000, (nk, nr)
+	assert f == [], "\n".join(f[:20])

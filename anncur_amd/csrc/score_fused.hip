@@ -202,14 +202,55 @@ __device__ __forceinline__ void filter_queue(const f32x16 &acc, float tau, uint3
 	for (int e = 0; e < 16; ++e) filter_one<D>(acc[e], e, tau, item0, lq, qcnt);
 }
 
+// Dense splits (norm-ordered rows: the leading splits of the first stage; their rings are drained every tile): a lane that finds
+// more than D survivors in ONE tile has wrapped its ring.  At k = 500 the prepass threshold lets about half of the leading tiles'
+// elements through and a handful of queries did this in every call -- each one a whole-split repair by the workgroup-level kernel
+// (0.26 ms per call for five queries).  The tile's accumulator is still in registers when its filter ends, and the lane's ring is
+// 8 slots x 8 bytes = 16 floats: the lane overwrites its ring with the RAW accumulator (mark_wrapped_raw) and flags its count; the
+// next flush filters those 16 scores itself.  Exact, no repair, and nothing but the accumulator, the ring address and the count is
+// live where it happens (a direct store to the segment from inside the tile function cost the headline kernel its registers: the
+// query operand went to scratch).  The ring must hold nothing but that tile's survivors, i.e. the split drains every tile.
+constexpr uint32_t RING_RAW = 0x80000000u;
+template <int D>
+__device__ __forceinline__ void mark_wrapped_raw(const f32x16 &acc, uint32_t lq, uint32_t &qcnt) {
+	static_assert(D == 8, "the raw tile (16 floats) fills the ring exactly");
+	const bool wrapped = (qcnt >> 11) > (uint32_t)D && qcnt < RING_RAW;
+	if (__builtin_expect(__ballot(wrapped) != 0ull, 0)) {
+		if (wrapped) {
+#pragma unroll
+			for (int i = 0; i < D; ++i) lds_store_2x32(lq + (uint32_t)i * 2048u, __float_as_uint(acc[2 * i]), __float_as_uint(acc[2 * i + 1]));
+			qcnt = RING_RAW;
+		}
+	}
+}
+
 // Drain the lane's ring to its HBM candidate segment: one store instruction per queue slot for the whole wave.
+// raw_item0: first item (+ 4 h) of the tile a RING_RAW ring holds (dense splits only).
 template <int D>
 __device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *__restrict__ seg, uint32_t &ncand, uint32_t capg,
-											 uint32_t n_items) {
+											 uint32_t n_items, float tau, uint32_t raw_item0) {
+	if (__builtin_expect(__ballot(qcnt >= RING_RAW) != 0ull, 0)) {
+		if (qcnt >= RING_RAW) {
+			for (int i = 0; i < D; ++i) {
+				const uint2 w = lds_load_u64(lq + (uint32_t)i * 2048u);
+#pragma unroll
+				for (int half = 0; half < 2; ++half) {
+					const int e = 2 * i + half;
+					const float v = __uint_as_float(half ? w.y : w.x);
+					const uint32_t item = raw_item0 + (uint32_t)((e & 3) + 8 * (e >> 2));
+					if (v >= tau && item < n_items) {
+						if (ncand < capg) seg[ncand] = make_uint2(__float_as_uint(v), item);
+						ncand++;
+					}
+				}
+			}
+			qcnt = 0;
+		}
+	}
 	uint32_t n = qcnt >> 11;  // (the filter keeps the count pre-shifted by the slot stride)
 	if (__builtin_expect(__ballot(n > (uint32_t)D) != 0ull, 0)) {
-		// ring wrapped between two flushes (p ~ 1e-9 per window): poison the segment count -> the select kernel recomputes
-		// this query exactly
+		// ring wrapped between two flushes of a multi-tile window (p ~ 1e-9 per window): poison the segment count -> the select
+		// kernel recomputes this query exactly
 		if (n > (uint32_t)D) { ncand = 0x80000000u; n = D; }
 	}
 	for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
@@ -258,7 +299,7 @@ __device__ __forceinline__ void lds_wait_frag(u32x4 &frag, int pending) {  // `p
 template <int KP, int CUR, bool PRED, bool INL = false>
 __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>::KSTEPS], const bf16x8 (&xb)[2][FusedCfg<KP>::KSTEPS],
 											  f32x16 &acc1, float tau0, float tau1_prev, uint32_t item0, uint32_t item0_prev,
-											  uint32_t lq0, uint32_t lq1, uint32_t &q0, uint32_t &q1) {
+											  uint32_t lq0, uint32_t lq1, uint32_t &q0, uint32_t &q1, bool dense) {
 	using Cfg = FusedCfg<KP>;
 	constexpr int K = Cfg::KSTEPS, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;  // ring slots / prefetch distance in k-steps
 	constexpr int EPS = 16 / K > 0 ? 16 / K : 1;  // filter elements per k-step (Kp = 64: 4, 128: 2, 256: 1)
@@ -285,6 +326,7 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 #pragma unroll
 			for (int e = (g == 1 ? 0 : g) * EPS; e < (g == 0 ? 0 : g + 1) * EPS; ++e)
 				filter_one<Cfg::QDEPTH, PRED, INL>(acc1[e], e, tau1_prev, item0_prev, lq1, q1);
+			if (g == K - 1 && dense) mark_wrapped_raw<Cfg::QDEPTH>(acc1, lq1, q1);  // (uniform) the previous tile's sub-tile 1 is filtered
 		} else {
 			// no filter in the first step of the half: accA's last MFMA is still in the pipe (and the predicated filter is
 			// inline asm, invisible to the compiler's MFMA -> VALU hazard handling); step 1 takes two groups instead
@@ -294,6 +336,7 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 				filter_one<Cfg::QDEPTH, PRED, INL>(accA[e], e, tau0, item0, lq0, q0);
 		}
 	}
+	if (dense) mark_wrapped_raw<Cfg::QDEPTH>(accA, lq0, q0);  // (uniform) this tile's sub-tile 0 is filtered
 	acc1 = accB;
 }
 
@@ -319,7 +362,7 @@ __device__ __forceinline__ void mfma_chain_done(f32x16 &acc) {
 // so eight address registers serve the 32 k-steps.
 template <int KP, int CUR>
 __device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const bf16x8 (&xb)[FusedCfg<KP, 1>::KSTEPS], f32x16 &acc,
-											   const f32x16 &accP, float tau, uint32_t item0_prev, uint32_t lq, uint32_t &qcnt) {
+											   const f32x16 &accP, float tau, uint32_t item0_prev, uint32_t lq, uint32_t &qcnt, bool dense) {
 	using Cfg = FusedCfg<KP, 1>;
 	constexpr int K = Cfg::KSTEPS, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;
 	static_assert((K == 32 || K == 16 || K == 8) && Cfg::CPR >= 16, "Kp = 128, 256 or 512");
@@ -347,6 +390,7 @@ __device__ __forceinline__ void stagger1_tile(const uint32_t (&aoff8)[8], const 
 	}
 #undef S1_READ
 	mfma_chain_done(acc);
+	if (dense) mark_wrapped_raw<Cfg::QDEPTH>(accP, lq, qcnt);  // (uniform) the previous tile is filtered
 }
 
 // MODE 0: prepass (GROUP = 16 or 4 items per group maximum).  MODE 1: filter sweep (PRED: branch-free filter, for stages in
@@ -406,6 +450,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	static_assert(Cfg::QUEUE_OFF % (Cfg::QDEPTH * 2048) == 0 && Cfg::QDEPTH * 2048 == 16384, "ring must be 16 KiB aligned");
 	if (MODE == 1 && (lds_addr(smem) & 0x3fffu) != 0u) __builtin_trap();  // filter_one() ORs the slot offset into the address
 
+	uint32_t last_item0 = 0;  // first item (+ 4 h) of the last tile filtered: what a raw ring holds at the final flush
 	if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
@@ -444,11 +489,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
 			if (--flush_in2 == 0) {                                                                                             \
 				flush_in2 = flush_period;                                                                                       \
-				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);                        \
-				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I);               \
+				/* (a raw ring holds one tile: sub-tile 0 of tile J-1, sub-tile 1 of tile J-2) */                               \
+				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev);    \
+				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - TILE_I); \
 			}                                                                                                                   \
 			const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * h;                                                              \
-			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1]);            \
+			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], flush_period == 1); \
 			tau1_prev = tau[1]; item0_prev = item0;                                                                             \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
@@ -458,10 +504,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if (j + 1 < j_end) STAGGER_STEP(1, j + 1);
 		}
 #undef STAGGER_STEP
-		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I);  // keep one tile's hits per queue window
+		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - TILE_I);  // keep one tile's hits per queue window
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
+		mark_wrapped_raw<Cfg::QDEPTH>(acc1, lq1, qcnt[1]);  // (its ring was just drained: exact in every split)
+		last_item0 = item0_prev;
 	} else if constexpr (MODE == 1 && QT == 1 && KP >= 128 && !INL) {  // (INL = the plain loop, kept for A/B in the experiments build)
 		// ---- software-pipelined sweep for Kp = 512 (stagger1_tile): tile loop unrolled by two (buffer parity = immediate offset);
 		// even steps accumulate into accA and filter accB, odd steps the other way round
@@ -481,9 +529,10 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
 			if (--flush_in2 == 0) {                                                                                             \
 				flush_in2 = flush_period;                                                                                       \
-				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);                        \
+				/* (a raw ring holds tile J-2, filtered during step J-1) */                                                     \
+				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - TILE_I); \
 			}                                                                                                                   \
-			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0]);                                \
+			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0], flush_period == 1);             \
 			tau_prev = tau[0]; item0_prev = (uint32_t)(J) * TILE_I + 4 * h;                                                     \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
@@ -495,14 +544,17 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if (j + 1 < j_end) { STAGGER1_STEP(1, j + 1, accB, accA); last_in_a = false; }
 		}
 #undef STAGGER1_STEP
-		flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I);
-		if (last_in_a) {  // drain: the last tile
+		flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - TILE_I);
+		if (last_in_a) {  // drain: the last tile (its ring was just drained: the raw path is exact in every split)
 #pragma unroll
 			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accA[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
+			mark_wrapped_raw<Cfg::QDEPTH>(accA, lq0, qcnt[0]);
 		} else {
 #pragma unroll
 			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accB[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
+			mark_wrapped_raw<Cfg::QDEPTH>(accB, lq0, qcnt[0]);
 		}
+		last_item0 = item0_prev;
 	} else {
 	const int flush_period_p = (MODE == 1 && p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;  // (see the staggered path)
 	int flush_in = flush_period_p;
@@ -516,7 +568,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if (--flush_in == 0) {
 				flush_in = flush_period_p;
 #pragma unroll
-				for (int t = 0; t < QT; ++t) flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I);
+				for (int t = 0; t < QT; ++t) flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I, tau[t], last_item0);
 			}
 		}
 
@@ -560,7 +612,11 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 		} else {
 			const uint32_t item0 = (uint32_t)tile * TILE_I + 4 * h;
 #pragma unroll
-			for (int t = 0; t < QT; ++t) filter_queue<Cfg::QDEPTH>(acc[t], tau[t], item0, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
+			for (int t = 0; t < QT; ++t) {
+				filter_queue<Cfg::QDEPTH>(acc[t], tau[t], item0, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
+				if (flush_period_p == 1 || !more) mark_wrapped_raw<Cfg::QDEPTH>(acc[t], lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);  // (uniform)
+			}
+			last_item0 = item0;
 		}
 		if (MODE != 3) {
 			__builtin_amdgcn_s_waitcnt(0x0F70);  // the DMA of tile j+1 (and the queue stores issued with it) have landed
@@ -582,7 +638,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	if (MODE == 1) {
 #pragma unroll
 		for (int t = 0; t < QT; ++t) {
-			flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I);
+			flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I, tau[t], last_item0);
 			if (qv[t] < p.Q) p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] = ncand[t];
 		}
 	}

@@ -429,6 +429,40 @@ def test_fused_index_hints_leave_the_result_unchanged(ops):
 	assert torch.equal(ids.long()[i2.long()].cpu(), i1.cpu().long())
 
 
+@pytest.mark.parametrize("K,k", [(256, 500), (512, 300), (64, 400)])
+def test_fused_dense_leading_tiles_need_no_repair(ops, K, k):
+	"""Norm-ordered rows, large k: the prepass threshold lets about half of the leading tiles' elements through, so single lanes find
+	more than 8 survivors in one tile -- more than their LDS ring holds.  Those lanes hand the tile's raw accumulator to the next
+	flush (mark_wrapped_raw / RING_RAW): exact results, and NO query goes to the repair kernel (round 1..2a: five repairs per call on
+	this kind of input, 0.26 ms of the k = 500 call).  All three loop shapes: staggered (Kp = 256), cross-tile (512), plain (64)."""
+	from anncur_amd.cur import _norm_sorted_pack
+	Q, I = 640, 60000
+	g = _g(1234 + K)
+	Z = torch.randn(8, I, generator=g)
+	X = (torch.randn(Q, 8, generator=g) @ torch.randn(8, K, generator=g) / 8).bfloat16()
+	E = ((torch.randn(K, 8, generator=g) @ Z / 8 / 12 + 0.002 * torch.randn(K, I, generator=g)) * (0.4 + 1.6 * torch.rand(1, I, generator=g) ** 6)).bfloat16()
+	Kp = ops.padded_k(K)
+	Xp = ops.pack_bf16(X.cuda(), Kp); Et = E.t().contiguous().cuda()
+	Es, ids = _norm_sorted_pack(Et.float(), Kp)
+	(v, i), nfb = ops.score_topk_fused(Xp, Es, I, k, leading_sample=True, item_ids=ids, return_fallbacks=True)
+	assert nfb.item() == 0
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
+	torch.testing.assert_close(torch.gather(S, 1, i.cpu().long()), v.cpu().double(), rtol=1e-4, atol=1e-4)
+	assert all(len(set(r.tolist())) == k for r in i.cpu())
+	# the case must really be dense: restate the prepass threshold (k-th largest maximum over the lanes' accumulator groups in the
+	# leading sample tiles) and count, per (query, tile, lane half), the survivors among the lane's 16 rows of a leading tile
+	plan = ops.fused_plan(Q, I, Kp, k)
+	n_st, grp = plan["n_sample_tiles"], plan["group"]
+	Ss = S[:, ids.long().cpu()]                                          # scores in the kernel's row order
+	lead = Ss[:, : 32 * n_st].reshape(Q, n_st, 4, 2, 4)                  # [query, tile, row octet, lane half, row]: row = 8 b + 4 h + j
+	gmax = lead.amax(dim=4) if grp == 4 else lead.amax(dim=(2, 4))       # group = 4 rows of one (octet, half), or the lane's 16 rows
+	tau0 = torch.topk(gmax.reshape(Q, -1), k, dim=1).values[:, -1]
+	per_lane = (lead >= tau0[:, None, None, None, None]).sum(dim=(2, 4))
+	assert int((per_lane > 8).sum()) >= 1, int(per_lane.max())            # (lanes that wrap their 8-slot ring exist on this input)
+
+
 def test_fused_wrong_index_hint_is_still_exact(ops):
 	"""ANNCUR_TOPK_LEADING_SAMPLE on rows ordered the WRONG way (ascending norm, strongly skewed norms): the threshold sampled from the
 	leading tiles is far too low, segments overflow, the in-call repair keeps the result exact."""

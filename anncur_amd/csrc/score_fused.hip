@@ -158,27 +158,16 @@ __device__ __forceinline__ void filter_one(float v, int e, float tau, uint32_t i
 	static_assert((D & (D - 1)) == 0, "queue depth must be a power of two");
 	// qcnt is kept pre-shifted (slot stride 2048 B); lq has bits 11..13 clear (16 KiB-aligned ring), so OR == ADD
 	if (FILTER_PREDICATED) {
-		// Branch-free: the push is executed under the compare's lane mask.  With lane = query a wave-level "any hit" branch is
-		// taken by ~30 % of the compares, and each taken branch (out and back) cost more than these five always-issued
-		// instructions, which fit in the MFMA shadow (4 VALU issue slots per MFMA and wave).
-		// CAUTION: the asm is opaque to hipcc's hazard recognizer: the caller must make sure that `v` is not the result of an
-		// MFMA issued within the last ~48 clocks (stagger_tile: no filter in the first step of a half).
-#if defined(__HIP_DEVICE_COMPILE__)
-		uint32_t addr, item;
-		uint64_t sv;
-		asm volatile(
-			"v_cmp_ge_f32 vcc, %[v], %[tau]\n\t"
-			"s_and_saveexec_b64 %[sv], vcc\n\t"
-			"v_and_or_b32 %[a], %[q], %[m], %[lq]\n\t"
-			"v_add_u32 %[it], %[c], %[i0]\n\t"
-			"ds_write2_b32 %[a], %[v], %[it] offset1:1\n\t"
-			"v_add_u32 %[q], 0x800, %[q]\n\t"
-			"s_mov_b64 exec, %[sv]"
-			: [q] "+v"(qcnt), [a] "=&v"(addr), [it] "=&v"(item), [sv] "=&s"(sv)
-			: [v] "v"(v), [tau] "v"(tau), [m] "s"((uint32_t)((D - 1) << 11)), [lq] "v"(lq), [i0] "v"(item0),
-			  [c] "n"((e & 3) + 8 * (e >> 2))
-			: "vcc", "memory");
-#endif
+		// Branch-free: no wave-level "any hit" test, the push runs under the compare's lane mask (a block this short gets no
+		// s_cbranch_execz from hipcc).  With lane = query the wave-level branch is taken by ~35 % of the compares at k = 100 and by nearly
+		// all of them at k >= 500, and a taken branch (out and back) costs more than these always-issued instructions.
+		// The compare is compiler-generated, so hipcc keeps its own MFMA -> VALU distance; the first version of this variant did the
+		// compare INSIDE an inline-asm string, 0-6 wait states behind the MFMA whose result it read, and lost a survivor now and then
+		// (found by the randomised parity run; scripts/check_mfma_hazards.py flags exactly that string).
+		if (v >= tau) {
+			lds_store_2x32((qcnt & (uint32_t)((D - 1) << 11)) | lq, __float_as_uint(v), item0 + (uint32_t)((e & 3) + 8 * (e >> 2)));
+			qcnt += 2048u;
+		}
 	} else if (INLINE_HIT) {
 		// the push block stays IN LINE behind a short forward skip (taken when no lane hits) instead of out of line behind a far
 		// branch out and back (taken when one does)
@@ -1091,13 +1080,15 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		// (cfg2: 3.1e7 windows per call -> one repaired query per ~200 calls; at 0.5 it was one per ~10 calls)
 		int ft = (int)(0.35 / (rate > 1e-9 ? rate : 1e-9));
 		P.stage_flush[i] = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-		// The predicated (branch-free, inline-asm) filter is NOT used by the product: its asm reads accumulator registers that an
-		// MFMA may still be writing -- hipcc neither orders register-only MFMAs against inline asm nor pads hazards inside it --
-		// and a randomised parity run caught it dropping one survivor (Q=4, I=12479, K=241, k=18).  It stays a timing experiment
-		// (ANNCUR_DEBUG_ALL_PRED in the experiments build); the branching filter's compare is compiler-generated and hazard-safe.
-		P.stage_pred[i] = 0;
+		// Filter variant of the stage: `rate` survivors per (lane, sub-tile, tile) = rate / 16 per element, so a compare finds a survivor
+		// in one of its 64 lanes with P = 1 - exp(-4 rate).  The ballot variant pays for that with a wave-level branch out and back, the
+		// exec variant (filter_one<.., true>) with two more scalar instructions on EVERY compare and a shorter survivor block.  Measured
+		// (MI355X, one process, alternating): cfg2 k = 100 (P ~ 0.3-0.5) exec 0.535 vs ballot 0.551 ms per sweep; k = 500 (P ~ 0.9)
+		// 0.84 vs 0.88; I = 10^6, Kp = 256 (P ~ 0.2 over most of the sweep) 2.80 vs 2.76 -> exec above P = 0.25.
+		// (staggered Kp <= 256 loop only: launch_fused ignores it elsewhere)
+		P.stage_pred[i] = (1.0 - exp(-4.0 * rate)) > 0.25 ? 1 : 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-		if (getenv("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = 1;
+		if (const char *dbg = getenv("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = atoi(dbg) != 0;
 #endif
 		// next stage: threshold = k-th best of the fraction seen so far
 		rate = (double)k / ((double)end * unit_items) * 16.0 * 1.2;
@@ -1355,14 +1346,14 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 				launched = true;
 			}
 		}
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-		if constexpr (Cfg::QT == 2) {  // (the predicated inline-asm filter: timing experiment only, see plan_stages)
+		if constexpr (Cfg::QT == 2) {  // (the branch-free filter lives in the staggered path)
 			if (!launched && P.stage_pred[stg]) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, true, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((score_kernel<KP, 1, 16, true, false, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 				launched = true;
 			}
 		}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
 		if constexpr (KP == 512) {
 			if (!launched && getenv("ANNCUR_DEBUG_PLAIN512")) {  // the sweep without the cross-tile software pipeline
 				if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, true, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;

@@ -6,7 +6,8 @@ asm's output register is still in flight after the statement, so nothing but the
 copying, spilling or consuming such a register early (the hardware has no interlock: the instruction reads stale data).  LDS
 instructions of one wave return in order, so the check is a FIFO walk over the disassembly: every DS instruction enters the queue,
 `s_waitcnt lgkmcnt(n)` retires all but the youngest n, and any instruction that names a register of a queued ds_read's destination
-is a finding.  Loop bodies are walked twice so that reads in flight across the back edge are seen.
+is a finding.  The walk follows the kernel's control-flow graph with the queue as its state (every basic block is visited once per
+distinct queue at its entry), so out-of-line blocks are judged on the paths that really reach them.
 
 usage: python scripts/check_lds_hazards.py [lib.so]
 """
@@ -25,57 +26,59 @@ def regs(text):
 	return out
 
 
-def check(lib):
+def _is_ds_load(op):
+	return op.startswith("ds_read") or op.startswith("ds_bpermute") or op.startswith("ds_permute") or op.startswith("ds_swizzle") or "_rtn" in op
+
+
+def check(lib, only=None):
+	"""Path-sensitive walk: the state is the FIFO of LDS instructions in flight (destination registers of the loads, empty sets for
+	stores / atomics); every (basic block, state at its entry) pair is visited once."""
+	from check_mfma_hazards import basic_blocks
 	findings, n_kernels, n_reads = [], 0, 0
 	for dis in disassemble(lib):
 		for name, body in functions(dis):
 			if not KERNELS.search(name) or not body: continue
+			if only and not re.search(only, name): continue
 			n_kernels += 1
-			base = body[0][0]
-			addr_index = {a: i for i, (a, _, _) in enumerate(body)}
-			seen, replayed = set(), set()
-
-			def walk(lo, hi, queue):
-				nonlocal n_reads
-				i = lo
-				while i <= hi:
-					a, ins, tail = body[i]
+			n_reads += sum(1 for _, ins, _ in body if _is_ds_load(ins.split()[0]))
+			blocks, succ = basic_blocks(body)
+			seen_states, reported = set(), set()
+			work = [(0, ())]
+			visits = 0
+			while work and visits < 400000:
+				k, state = work.pop()
+				if (k, state) in seen_states: continue
+				seen_states.add((k, state)); visits += 1
+				queue = list(state)
+				st, en = blocks[k]
+				for i in range(st, en + 1):
+					a, ins, _ = body[i]
 					op = ins.split()[0]
 					w = _lgkm(ins)
 					if w is not None:
 						while len(queue) > w: queue.pop(0)
-					elif op.startswith("ds_") or SMEM.match(ins):
-						used = regs(ins)
+						continue
+					used = regs(ins) if queue else set()
+					if used:
 						for (qa, qins, dst) in queue:
-							if dst & used and (qa, a) not in seen:
-								seen.add((qa, a)); findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches the destination of in-flight '{qins}' @ {qa:x}")
-						dst = set()
-						if op.startswith("ds_read") or op.startswith("ds_bpermute") or op.startswith("ds_permute") or op.startswith("ds_swizzle") or "_rtn" in op:
-							first = ins[len(op):].split(",")[0]
-							dst = regs(first); n_reads += 1
-						queue.append((a, ins, dst))
-					else:
-						used = regs(ins)
-						if used:
-							for (qa, qins, dst) in queue:
-								if dst & used and (qa, a) not in seen:
-									seen.add((qa, a)); findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches the destination of in-flight '{qins}' @ {qa:x}")
-						if op.startswith("s_cbranch") or op.startswith("s_branch"):
-							m = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>", tail)
-							tgt = base + int(m.group(1), 16) if m else None
-							if tgt is not None and tgt <= a and tgt in addr_index and i not in replayed:
-								replayed.add(i)
-								walk(addr_index[tgt], i - 1, list(queue))  # once more around the loop with what is in flight now
-					i += 1
-				return queue
-
-			walk(0, len(body) - 1, [])
+							if dst & used and (qa, a) not in reported:
+								reported.add((qa, a))
+								findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches the destination of in-flight '{qins}' @ {qa:x}")
+					# (LDS stores / atomics are left out of the queue: most of them sit in conditional blocks, a queue that tracked them
+					#  would differ on every path, and without them a counted wait retires FEWER loads here than in the hardware -- the
+					#  conservative direction)
+					if _is_ds_load(op):
+						queue.append((a, ins, frozenset(regs(ins[len(op):].split(",")[0]))))
+						if len(queue) > 16: queue.pop(0)  # (the hardware counter saturates; nothing here keeps that many in flight)
+				out = tuple(queue)
+				for t in succ[k]: work.append((t, out))
+			if visits >= 400000: findings.append(f"{name[:70]}: state space not exhausted (walk capped)")
 	return findings, n_kernels, n_reads
 
 
 if __name__ == "__main__":
 	lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anncur_amd", "lib", "libanncur_hip.so")
-	f, nk, nr = check(lib)
+	f, nk, nr = check(lib, sys.argv[2] if len(sys.argv) > 2 else None)
 	print(f"{lib}: {nk} sweep kernels, {nr} LDS reads followed to their wait, {len(f)} findings")
 	for x in f[:40]: print("  " + x)
 	sys.exit(1 if f else 0)

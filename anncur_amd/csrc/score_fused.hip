@@ -938,7 +938,7 @@ __global__ __launch_bounds__(SEL_THREADS) void tau_block_kernel(const uint2 *__r
 // No workgroup barrier.  Queries whose segments overflowed or that collected fewer than k candidates are appended to
 // hard_list for the workgroup-level kernel (which recomputes them exactly).
 constexpr int WQ_CAP = 1024;
-constexpr int WQ_K2 = 512;  // largest k of the wave-level candidate select (8 keys per lane in the final sort, 2048-entry buffer)
+constexpr int WQ_K2 = 1024;  // largest k of the wave-level candidate select (select_stream.hpp: 16 keys per lane in the final sort)
 template <int KW> struct WqCfg { static constexpr int CAP = KW <= 128 ? WQ_CAP : 2048, TRIGGER = CAP - WAVE, E = KW / 64; };
 
 // TAU_ONLY (between sweep stages): no output, the query's threshold is raised to the k-th best candidate collected so far.
@@ -1249,7 +1249,8 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 		} while (0)
 		if (k <= WSEL_K) { if (stream_select_small()) LAUNCH_SSEL(2); else LAUNCH_WSEL(128); }
 		else if (k <= 256) LAUNCH_SSEL(4);
-		else LAUNCH_SSEL(8);
+		else if (k <= 512) LAUNCH_SSEL(8);
+		else LAUNCH_SSEL(16);
 #undef LAUNCH_SSEL
 #undef LAUNCH_WSEL
 		ANNCUR_LAUNCH_OK();
@@ -1264,7 +1265,7 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 
 // tau = k-th largest group maximum of the prepass (a valid lower bound on the query's k-th best score)
 int launch_threshold(const FusedPlan &P, const float *gmax, int64_t Q, int k, unsigned char *ws, const float *&tau, int &tau_stride, hipStream_t st) {
-	if (P.n_groups <= 2048) {  // one wave per query, keys in registers
+	if (P.n_groups <= 4096) {  // one wave per query, keys in LDS (kth_value_wave_kernel)
 		float *t = (float *)(ws + P.off_tau);
 		const int rc = anncur_internal_kth_value(gmax, Q, P.n_groups, P.n_groups, k, t, 1, st);
 		tau = t; tau_stride = 1;

@@ -340,25 +340,30 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 // (the fused path's threshold step: rows of a few hundred group maxima).  The row's sortable keys go to a wave-private LDS
 // array; MSB-first radix select with 8-bit digits (wsel_kth: four histogram passes instead of 32 bit-by-bit ballot rounds).
 // No workgroup barrier.  NaN is never selected.
-constexpr int KTH_MAX_N = 2048;
+// Round 2: the key array is dynamic LDS sized to n (it was a static 4 x 2048 array: 36 KB per workgroup whatever n) and n may be
+// 4096: the threshold of k = 1000 (4000 group maxima per query) no longer goes through the workgroup-level top-k (0.74 -> 0.21 ms).
+constexpr int KTH_MAX_N = 4096;
 __global__ __launch_bounds__(256) void kth_value_wave_kernel(const float *__restrict__ G, int64_t Q, int n, int64_t ldg, uint32_t k,
-															  float *__restrict__ out, int64_t out_stride) {
-	__shared__ uint32_t keys[4][KTH_MAX_N];
-	__shared__ uint32_t hist[4][256];
+															  float *__restrict__ out, int64_t out_stride, int n_pad) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char kth_smem[];
 	const uint32_t lane = (uint32_t)lane_id();
 	const int wave = threadIdx.x >> 6;
+	uint32_t *hist = reinterpret_cast<uint32_t *>(kth_smem) + wave * (256 + n_pad);
+	uint32_t *keys = hist + 256;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
 	if (q >= Q) return;
 	const float *g = G + q * ldg;
 	for (uint32_t j = lane; j < (uint32_t)n; j += WAVE) {
 		const float v = g[j];
-		keys[wave][j] = (v == v) ? f32_sortable(v) : 0u;
+		keys[j] = (v == v) ? f32_sortable(v) : 0u;
 	}
 	__builtin_amdgcn_wave_barrier();
 	WaveSel w;
-	w.whi = keys[wave]; w.wlo = nullptr; w.sort_buf = nullptr; w.hist = hist[wave];
+	w.whi = keys; w.wlo = nullptr; w.sort_buf = nullptr; w.hist = hist;
 	w.cnt = (uint32_t)n; w.tau_hi = 0; w.tau_lo = 0; w.tau = 0.f;
 	uint32_t need;
+	// (fixed sign/exponent digits: the range-adaptive digits of wsel_kth_ranged cost more here -- min / max pass and two reductions
+	//  per row -- than the histogram conflicts they avoid: 0.034 vs 0.030 ms at n = 512, 0.23 vs 0.21 ms at n = 4000, measured)
 	const uint32_t kk = wsel_kth<false, 4>(w, w.whi, (uint32_t)n, k, need, w.whi, 0u);
 	if (lane == 0) out[q * out_stride] = f32_unsortable(kk);
 }
@@ -527,9 +532,13 @@ int kmax_class(int k) { return k <= 128 ? 128 : (k <= 512 ? 512 : 2048); }
 
 // internal (not part of the C ABI): tau[q] = k-th largest of G[q, :n], n <= 2048
 int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st) {
-	ANNCUR_REQUIRE(n >= 1 && n <= 2048 && k >= 1 && k <= n, ANNCUR_E_INVALID, "kth_value: need 1 <= k <= n <= 2048");
+	ANNCUR_REQUIRE(n >= 1 && n <= KTH_MAX_N && k >= 1 && k <= n, ANNCUR_E_INVALID, "kth_value: need 1 <= k <= n <= 4096");
 	const unsigned grid = (unsigned)ceil_div64(Q, 4);
-	hipLaunchKernelGGL(kth_value_wave_kernel, dim3(grid), dim3(256), 0, st, G, Q, n, ldg, (uint32_t)k, out, out_stride);
+	const int n_pad = (n + 63) & ~63;
+	const int lds = 4 * (256 + n_pad) * 4;  // (<= 68 KB: above the 64 KB default only for n > 3840)
+	int rc;
+	if (lds > 64 * 1024 && (rc = anncur_ensure_dyn_lds((const void *)kth_value_wave_kernel, lds)) != ANNCUR_OK) return rc;
+	hipLaunchKernelGGL(kth_value_wave_kernel, dim3(grid), dim3(256), lds, st, G, Q, n, ldg, (uint32_t)k, out, out_stride, n_pad);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -971,25 +971,34 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 	// are dropped at the load (at least k candidates are >= it by construction)
 	if (tau && prefilter) w.tau = tau[q * tau_stride];
 	const uint2 *qc = cand + q * nseg * (int64_t)capg;
-	// The candidates are fetched LOAD_U chunks of 64 at a time, all loads in flight before the first chunk is offered: with one
-	// load per chunk behind the previous chunk's (data-dependent) compaction the kernel ran at one HBM latency per 64 candidates
-	// (k = 500, ~3000 candidates per query: 0.33 ms per call, now see DESIGN.md 4.3).
+	// The candidates are fetched LOAD_U chunks of 64 at a time: the batch's flat-index -> (segment, entry) searches advance in
+	// LOCKSTEP (one round = LOAD_U independent ds_bpermute, one wait), the loads are unconditional (clamped address) and issued back
+	// to back.  Written chunk by chunk hipcc emitted LOAD_U serial chains of seven LDS round trips and one exposed HBM latency per chunk.
 	SEL_STAMP(1);
 	constexpr int LOAD_U = 8;
 	for (uint32_t j0 = 0; j0 < total; j0 += LOAD_U * WAVE) {
+		int sg[LOAD_U];  // last segment whose exclusive prefix is <= j (skips empty segments)
+#pragma unroll
+		for (int u = 0; u < LOAD_U; ++u) sg[u] = 0;
+#pragma unroll
+		for (int step = 32; step >= 1; step >>= 1) {
+			if (step < nseg) {  // (uniform: segments >= nseg do not exist)
+				uint32_t pv[LOAD_U];
+#pragma unroll
+				for (int u = 0; u < LOAD_U; ++u) pv[u] = __shfl(pre, (sg[u] + step) & 63);
+#pragma unroll
+				for (int u = 0; u < LOAD_U; ++u)
+					if (sg[u] + step < nseg && pv[u] <= j0 + (uint32_t)(u * WAVE + lane)) sg[u] += step;
+			}
+		}
+		uint32_t ps[LOAD_U];
+#pragma unroll
+		for (int u = 0; u < LOAD_U; ++u) ps[u] = __shfl(pre, sg[u]);
 		uint2 e[LOAD_U];
 #pragma unroll
 		for (int u = 0; u < LOAD_U; ++u) {
 			const uint32_t j = j0 + (uint32_t)(u * WAVE + lane);
-			int sg = 0;  // last segment whose exclusive prefix is <= j (skips empty segments)
-#pragma unroll
-			for (int step = 32; step >= 1; step >>= 1) {
-				const int cs = sg + step;
-				const uint32_t pv = __shfl(pre, cs & 63);
-				if (cs < nseg && pv <= j) sg = cs;
-			}
-			const uint32_t ps = __shfl(pre, sg);
-			e[u] = j < total ? qc[(int64_t)sg * capg + (j - ps)] : make_uint2(0u, 0u);
+			e[u] = qc[j < total ? (int64_t)sg[u] * capg + (j - ps[u]) : 0];
 		}
 #pragma unroll
 		for (int u = 0; u < LOAD_U; ++u) {

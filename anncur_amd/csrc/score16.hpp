@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                     \
 		__syncthreads();                                                                                                        \
 	} while (0)
+	ANNCUR_PAD_HERE();
 	for (int j = j_begin; j < j_end; j += 2) {
 		STAGGER16_STEP(0, j);
 		if (j + 1 < j_end) STAGGER16_STEP(1, j + 1);

@@ -27,6 +27,14 @@
 #include <stdlib.h>
 #include <math.h>
 #include <type_traits>
+// scripts/placement_sweep.sh builds the library with ANNCUR_PLACEMENT_PAD = 1..n: that many extra instructions in front of every
+// sweep loop move the loops through all alignments relative to the instruction-fetch lines.  A result that changes with the pad is a
+// missing wait state somewhere (DESIGN.md 4.1 'A latent hazard'); the shipped build has no pad.
+#ifdef ANNCUR_PLACEMENT_PAD
+#define ANNCUR_PAD_HERE() asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(ANNCUR_PLACEMENT_PAD) : "memory")
+#else
+#define ANNCUR_PAD_HERE() do { } while (0)
+#endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 __device__ unsigned long long *d_sweep_stamps = nullptr;  // diagnostic build: {d s_memtime, d s_memrealtime} of the sweep's tile loop per workgroup
 __device__ unsigned long long *d_sel_stamps = nullptr;  // diagnostic build: phase stamps of the wave-level select kernels (4 per workgroup)
@@ -443,6 +451,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
+	ANNCUR_PAD_HERE();
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	// In-kernel clock (MI355X guide, 'DVFS give-back' (6)): shader cycles per 100 MHz reference tick around the tile loop.  The
 	// stamps go to a buffer nothing else reads; the shipped library contains none of this.

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 			WIDE_DMA2(3); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f1); WIDE_PRIO(0);           \
 		} while (0)
 
+		ANNCUR_PAD_HERE();
 		for (int kt = 0; kt < nk; kt += 2) {
 			// stage 0 holds k-tile kt: fetch kt + 1 into stage 1 while it is consumed
 			const unsigned char *da = abase + (kt + 1) * 128, *db = xbase + (kt + 1) * 128;

@@ -77,6 +77,46 @@ __device__ __forceinline__ uint32_t key_idx(uint64_t k) { return 0xffffffffu - (
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// ---- cross-lane scans / reductions on the VALU (DPP).  A `__shfl*` is a ds_bpermute: an LDS round trip (~100+ cycles exposed in a
+// dependent chain), and the LDS pipe turned out to be the limit of the candidate-select kernels (a seven-round segment search cost
+// 5 k cycles per wave with 16 waves per CU competing for it).  These are the classic gfx9 wave64 sequences: row_shr 1/2/3 of the
+// input, row_shr 4 and 8 of the running value under bank masks, then row_bcast 15 and 31 under row masks; a lane whose source is
+// masked off or out of range keeps `identity`.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t identity, uint32_t x) {
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+struct DppAdd { static constexpr uint32_t ID = 0u; __device__ static uint32_t op(uint32_t a, uint32_t b) { return a + b; } };
+struct DppMin { static constexpr uint32_t ID = 0xffffffffu; __device__ static uint32_t op(uint32_t a, uint32_t b) { return a < b ? a : b; } };
+struct DppMax { static constexpr uint32_t ID = 0u; __device__ static uint32_t op(uint32_t a, uint32_t b) { return a > b ? a : b; } };
+// inclusive scan over the lanes 0..lane (lane 63 holds the wave's total)
+template <typename OP>
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+	uint32_t t = x;
+	t = OP::op(t, dpp_mov<0x111>(OP::ID, x));              // row_shr:1
+	t = OP::op(t, dpp_mov<0x112>(OP::ID, x));              // row_shr:2
+	t = OP::op(t, dpp_mov<0x113>(OP::ID, x));              // row_shr:3
+	t = OP::op(t, dpp_mov<0x114, 0xf, 0xe>(OP::ID, t));    // row_shr:4  bank_mask:0xe
+	t = OP::op(t, dpp_mov<0x118, 0xf, 0xc>(OP::ID, t));    // row_shr:8  bank_mask:0xc
+	t = OP::op(t, dpp_mov<0x142, 0xa, 0xf>(OP::ID, t));    // row_bcast:15 row_mask:0xa
+	t = OP::op(t, dpp_mov<0x143, 0xc, 0xf>(OP::ID, t));    // row_bcast:31 row_mask:0xc
+	return t;
+}
+template <typename OP>
+__device__ __forceinline__ uint32_t wave_reduce(uint32_t x) {  // the same value in every lane (wave-uniform)
+	return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl<OP>(x), WAVE - 1);
+}
+
+// value of lane (lane ^ stride): strides 1, 2 are one quad_perm, 4 = row_half_mirror (^7) then a quad reversal (^3), 8 = row_mirror
+// (^15) then row_half_mirror (^7) -- VALU only; 16 and 32 go through ds_bpermute (`stride` must fold to a constant)
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int stride) {
+	if (stride == 1) return dpp_mov<0xB1>(x, x);                       // quad_perm:[1,0,3,2]
+	if (stride == 2) return dpp_mov<0x4E>(x, x);                       // quad_perm:[2,3,0,1]
+	if (stride == 4) return dpp_mov<0x1B>(x, dpp_mov<0x141>(x, x));    // row_half_mirror, quad_perm:[3,2,1,0]
+	if (stride == 8) return dpp_mov<0x141>(x, dpp_mov<0x140>(x, x));   // row_mirror, row_half_mirror
+	return (uint32_t)__shfl_xor((int)x, stride);
+}
+
 template <typename T>
 __device__ __forceinline__ float load_as_f32(const T *p);
 template <>

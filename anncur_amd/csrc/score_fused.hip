@@ -38,7 +38,7 @@
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 __device__ unsigned long long *d_sweep_stamps = nullptr;  // diagnostic build: {d s_memtime, d s_memrealtime} of the sweep's tile loop per workgroup
 __device__ unsigned long long *d_sel_stamps = nullptr;  // diagnostic build: phase stamps of the wave-level select kernels (4 per workgroup)
-#define SEL_STAMP(i) do { if (d_sel_stamps && wave == 0 && lane == 0) d_sel_stamps[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SEL_STAMP(i) do { if (d_sel_stamps && wave == 0 && lane == 0) d_sel_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SEL_STAMP(i) do { } while (0)
 #endif
@@ -963,13 +963,8 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 	if (q >= Q) return;
 	SEL_STAMP(0);
 	const uint32_t c = (lane < nseg) ? seg_cnt[q * nseg + lane] : 0u;
-	uint32_t inc = c;
-#pragma unroll
-	for (int d = 1; d < WAVE; d <<= 1) {
-		const uint32_t t = __shfl_up(inc, d);
-		if (lane >= d) inc += t;
-	}
-	const uint32_t total = __shfl(inc, WAVE - 1), pre = inc - c;
+	const uint32_t inc = wave_scan_incl<DppAdd>(c);
+	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1), pre = inc - c;
 	if (__ballot(c > (uint32_t)capg) != 0ull || total < k) {
 		if (!TAU_ONLY && lane == 0) hard_list[atomicAdd(hard_cnt, 1u)] = (int32_t)q;
 		return;  // TAU_ONLY: keep the old (still valid) threshold
@@ -983,6 +978,8 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 	// The candidates are fetched LOAD_U chunks of 64 at a time: the batch's flat-index -> (segment, entry) searches advance in
 	// LOCKSTEP (one round = LOAD_U independent ds_bpermute, one wait), the loads are unconditional (clamped address) and issued back
 	// to back.  Written chunk by chunk hipcc emitted LOAD_U serial chains of seven LDS round trips and one exposed HBM latency per chunk.
+	// (A search without LDS -- the segment ends read into scalars with v_readlane, every lane counting the ends at or below its index --
+	//  was slower: 9.5 k instead of 5 k cycles per wave for the 23 ends x 8 chunks.)
 	SEL_STAMP(1);
 	constexpr int LOAD_U = 8;
 	for (uint32_t j0 = 0; j0 < total; j0 += LOAD_U * WAVE) {
@@ -1004,11 +1001,15 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 #pragma unroll
 		for (int u = 0; u < LOAD_U; ++u) ps[u] = __shfl(pre, sg[u]);
 		uint2 e[LOAD_U];
+		if (j0 == 0) SEL_STAMP(4);
 #pragma unroll
 		for (int u = 0; u < LOAD_U; ++u) {
 			const uint32_t j = j0 + (uint32_t)(u * WAVE + lane);
 			e[u] = qc[j < total ? (int64_t)sg[u] * capg + (j - ps[u]) : 0];
 		}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (j0 == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SEL_STAMP(5); }
+#endif
 #pragma unroll
 		for (int u = 0; u < LOAD_U; ++u) {
 			if (j0 + (uint32_t)(u * WAVE) < total) {  // (uniform)
@@ -1734,22 +1735,23 @@ extern "C" int anncur_debug_read_stamps(double *clock_ghz, double *loop_us, int 
 extern "C" int anncur_debug_sel_stamps(int arm, double *out) {
 	static unsigned long long *buf = nullptr;
 	const int N = 4096;
-	if (!buf) { if (hipMalloc((void **)&buf, 4 * N * sizeof(unsigned long long)) != hipSuccess) return ANNCUR_E_HIP; }
+	if (!buf) { if (hipMalloc((void **)&buf, 8 * N * sizeof(unsigned long long)) != hipSuccess) return ANNCUR_E_HIP; }
 	if (arm) {
-		if (hipMemset(buf, 0, 4 * N * sizeof(unsigned long long)) != hipSuccess) return ANNCUR_E_HIP;
+		if (hipMemset(buf, 0, 8 * N * sizeof(unsigned long long)) != hipSuccess) return ANNCUR_E_HIP;
 		unsigned long long *v = arm > 0 ? buf : nullptr;
 		return hipMemcpyToSymbol(HIP_SYMBOL(d_sel_stamps), &v, sizeof(v)) == hipSuccess ? ANNCUR_OK : ANNCUR_E_HIP;
 	}
-	static unsigned long long h[4 * 4096];
+	static unsigned long long h[8 * 4096];
 	if (hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return ANNCUR_E_HIP;
-	static double ph[3][4096];
-	int n = 0;
-	for (int i = 0; i < N; ++i)
-		if (h[4 * i + 3] > h[4 * i]) { for (int j = 0; j < 3; ++j) ph[j][n] = (double)(h[4 * i + j + 1] - h[4 * i + j]); ++n; }
-	if (!n) return ANNCUR_E_INVALID;
-	for (int j = 0; j < 3; ++j) {
-		for (int i = 1; i < n; ++i) { double x = ph[j][i]; int t = i - 1; while (t >= 0 && ph[j][t] > x) { ph[j][t + 1] = ph[j][t]; --t; } ph[j][t + 1] = x; }
-		out[j] = ph[j][n / 2];
+	// out[0..2]: prologue, load loop, finish; out[3..4] (select_wave_kernel only): first batch's segment search, its loads' latency
+	static const int from[5] = {0, 1, 2, 1, 4}, to[5] = {1, 2, 3, 4, 5};
+	static double ph[4096];
+	for (int j = 0; j < 5; ++j) {
+		int n = 0;
+		for (int i = 0; i < N; ++i)
+			if (h[8 * i + 3] > h[8 * i] && h[8 * i + to[j]] > h[8 * i + from[j]]) ph[n++] = (double)(h[8 * i + to[j]] - h[8 * i + from[j]]);
+		for (int i = 1; i < n; ++i) { double x = ph[i]; int t = i - 1; while (t >= 0 && ph[t] > x) { ph[t + 1] = ph[t]; --t; } ph[t + 1] = x; }
+		out[j] = n ? ph[n / 2] : 0.0;
 	}
 	return ANNCUR_OK;
 }

@@ -24,31 +24,11 @@
 
 namespace anncur {
 
-// Suffix-scan the 256-bin histogram (4 bins per lane) for the bin that holds the need-th largest key.
-// Returns the bin; `above` = keys in higher bins, `in_bin` = keys in it.
+// (the bin search of a digit histogram is wsel_find_bin of wave_select.hpp)
 __device__ __forceinline__ uint32_t hist_find_bin(const uint32_t *hist, uint32_t lane, uint32_t need, uint32_t &above, uint32_t &in_bin) {
-	const uint32_t h0 = hist[lane * 4], h1 = hist[lane * 4 + 1], h2 = hist[lane * 4 + 2], h3 = hist[lane * 4 + 3];
-	const uint32_t c4 = h0 + h1 + h2 + h3;
-	uint32_t suf = c4;  // inclusive suffix sum over lanes >= lane
-#pragma unroll
-	for (int d = 1; d < WAVE; d <<= 1) {
-		const uint32_t t = __shfl_down(suf, d);
-		if (lane + d < WAVE) suf += t;
-	}
-	uint32_t a = suf - c4, bin = 0, hb = 0;
-	const bool mine = a < need && suf >= need;
-	if (mine) {
-		if (a + h3 >= need) { bin = lane * 4 + 3; hb = h3; }
-		else { a += h3;
-			if (a + h2 >= need) { bin = lane * 4 + 2; hb = h2; }
-			else { a += h2;
-				if (a + h1 >= need) { bin = lane * 4 + 1; hb = h1; }
-				else { a += h1; bin = lane * 4; hb = h0; } } }
-	}
-	const int src = __ffsll((long long)__ballot(mine)) - 1;  // exactly one lane
-	above = __shfl(a, src);
-	in_bin = __shfl(hb, src);
-	return __shfl(bin, src);
+	uint32_t bin;
+	wsel_find_bin(hist, lane, need, bin, above, in_bin);
+	return bin;
 }
 
 // Visit the query's candidates segment by segment, 64 entries of ONE segment per visit (the last visit of a segment is partial),
@@ -126,9 +106,7 @@ __global__ __launch_bounds__(256) void select_stream_kernel(const uint2 *__restr
 	uint32_t *hist = reinterpret_cast<uint32_t *>(smem + wave * StreamSelLayout::BYTES);
 	uint32_t *keys = hist + 256;
 	const uint32_t c = (lane < nseg) ? seg_cnt[q * nseg + lane] : 0u;
-	uint32_t total = c;
-#pragma unroll
-	for (int d = WAVE / 2; d > 0; d >>= 1) total += __shfl_xor(total, d);
+	const uint32_t total = wave_reduce<DppAdd>(c);
 	auto defer = [&]() {  // the workgroup-level kernel recomputes this query exactly
 		if (!TAU_ONLY && lane == 0) hard_list[atomicAdd(hard_cnt, 1u)] = (int32_t)q;
 	};
@@ -152,11 +130,7 @@ __global__ __launch_bounds__(256) void select_stream_kernel(const uint2 *__restr
 		}
 		n_in += (uint32_t)__popcll(m);
 	});
-#pragma unroll
-	for (int d = WAVE / 2; d > 0; d >>= 1) {
-		const uint32_t a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
-		mn = a < mn ? a : mn; mx = b > mx ? b : mx;
-	}
+	mn = wave_reduce<DppMin>(mn); mx = wave_reduce<DppMax>(mx);
 	__builtin_amdgcn_wave_barrier();
 	SEL_STAMP(1);
 	if (n_in < k) { defer(); return; }

@@ -70,6 +70,30 @@ __device__ __forceinline__ void wsel_offer_inorder(WaveSel &w, bool valid, float
 	wsel_push(w, hit, f32_sortable(v), 0xffffffffu - idx);
 }
 
+// The bin of a 256-bin digit histogram that holds the need-th LARGEST key; `above` = keys in higher bins, `in_bin` = keys in it.
+// Lane L owns the four bins 252 - 4 L .. 255 - 4 L, so that an inclusive prefix sum over the lanes (DPP, no LDS round trip) counts
+// the keys from the top bin down.
+__device__ __forceinline__ void wsel_find_bin(const uint32_t *hist, uint32_t lane, uint32_t need, uint32_t &bin_out, uint32_t &above, uint32_t &in_bin) {
+	const uint32_t b0 = (WAVE - 1 - lane) * 4;
+	const uint32_t h0 = hist[b0], h1 = hist[b0 + 1], h2 = hist[b0 + 2], h3 = hist[b0 + 3];
+	const uint32_t c4 = h0 + h1 + h2 + h3;
+	const uint32_t pre = wave_scan_incl<DppAdd>(c4);  // keys in this lane's bins and above
+	uint32_t a = pre - c4, bin = 0, hb = 0;
+	const bool mine = a < need && pre >= need;
+	if (mine) {
+		if (a + h3 >= need) { bin = b0 + 3; hb = h3; }
+		else { a += h3;
+			if (a + h2 >= need) { bin = b0 + 2; hb = h2; }
+			else { a += h2;
+				if (a + h1 >= need) { bin = b0 + 1; hb = h1; }
+				else { a += h1; bin = b0; hb = h0; } } }
+	}
+	const int src = __ffsll((long long)__ballot(mine)) - 1;  // exactly one lane (wave-uniform index: v_readlane, not a shuffle)
+	bin_out = (uint32_t)__builtin_amdgcn_readlane((int)bin, src);
+	above = (uint32_t)__builtin_amdgcn_readlane((int)a, src);
+	in_bin = (uint32_t)__builtin_amdgcn_readlane((int)hb, src);
+}
+
 // k-th largest among key[0..n) (optionally only where gate[j] == gate_val): MSB-first radix select, 8-bit digits,
 // histogram filled with non-returning LDS atomics.  Returns the key; need_out = copies of it that belong to the top-k.
 // PASSES < 4: the keys are known to be zero below bit 32 - 8*PASSES (bf16 scores: 2 passes).
@@ -94,27 +118,8 @@ __device__ __forceinline__ uint32_t wsel_kth(const WaveSel &w, const uint32_t *k
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
-		const uint32_t h0 = w.hist[lane * 4], h1 = w.hist[lane * 4 + 1], h2 = w.hist[lane * 4 + 2], h3 = w.hist[lane * 4 + 3];
-		const uint32_t c4 = h0 + h1 + h2 + h3;
-		uint32_t suf = c4;  // inclusive suffix sum over lanes >= lane
-#pragma unroll
-		for (int d = 1; d < WAVE; d <<= 1) {
-			const uint32_t t = __shfl_down(suf, d);
-			if (lane + d < WAVE) suf += t;
-		}
-		uint32_t a = suf - c4, bin = 0;
-		const bool mine = a < need && suf >= need;
-		if (mine) {
-			if (a + h3 >= need) { bin = lane * 4 + 3; }
-			else { a += h3;
-				if (a + h2 >= need) { bin = lane * 4 + 2; }
-				else { a += h2;
-					if (a + h1 >= need) { bin = lane * 4 + 1; }
-					else { a += h1; bin = lane * 4; } } }
-		}
-		const int src = __ffsll((long long)__ballot(mine)) - 1;  // exactly one lane
-		bin = __shfl(bin, src);
-		a = __shfl(a, src);
+		uint32_t bin, a, hb;
+		wsel_find_bin(w.hist, lane, need, bin, a, hb);
 		need -= a;
 		prefix = (prefix << 8) | bin;
 		__builtin_amdgcn_wave_barrier();
@@ -135,11 +140,7 @@ __device__ __forceinline__ uint32_t wsel_kth_ranged(const WaveSel &w, const uint
 		const uint32_t j = j0 + lane;
 		if (j < n) { const uint32_t x = key[j]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
 	}
-#pragma unroll
-	for (int d = WAVE / 2; d > 0; d >>= 1) {
-		const uint32_t a = __shfl_xor(mn, d), b = __shfl_xor(mx, d);
-		mn = a < mn ? a : mn; mx = b > mx ? b : mx;
-	}
+	mn = wave_reduce<DppMin>(mn); mx = wave_reduce<DppMax>(mx);
 	const uint32_t range = mx - mn;
 	const int passes = range == 0u ? 0 : (32 - __clz(range) + 7) / 8;  // (uniform)
 	uint32_t prefix = 0, need = k;
@@ -158,27 +159,8 @@ __device__ __forceinline__ uint32_t wsel_kth_ranged(const WaveSel &w, const uint
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
-		const uint32_t h0 = w.hist[lane * 4], h1 = w.hist[lane * 4 + 1], h2 = w.hist[lane * 4 + 2], h3 = w.hist[lane * 4 + 3];
-		const uint32_t c4 = h0 + h1 + h2 + h3;
-		uint32_t suf = c4;  // inclusive suffix sum over lanes >= lane
-#pragma unroll
-		for (int d = 1; d < WAVE; d <<= 1) {
-			const uint32_t t = __shfl_down(suf, d);
-			if (lane + d < WAVE) suf += t;
-		}
-		uint32_t a = suf - c4, bin = 0;
-		const bool mine = a < need && suf >= need;
-		if (mine) {
-			if (a + h3 >= need) { bin = lane * 4 + 3; }
-			else { a += h3;
-				if (a + h2 >= need) { bin = lane * 4 + 2; }
-				else { a += h2;
-					if (a + h1 >= need) { bin = lane * 4 + 1; }
-					else { a += h1; bin = lane * 4; } } }
-		}
-		const int src = __ffsll((long long)__ballot(mine)) - 1;  // exactly one lane
-		bin = __shfl(bin, src);
-		a = __shfl(a, src);
+		uint32_t bin, a, hb;
+		wsel_find_bin(w.hist, lane, need, bin, a, hb);
 		need -= a;
 		prefix = (prefix << 8) | bin;
 		__builtin_amdgcn_wave_barrier();
@@ -241,14 +223,12 @@ __device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t ti
 		}
 		base += (uint32_t)__popcll(m);
 	}
-#pragma unroll
-	for (int d = WAVE / 2; d > 0; d >>= 1) {
-		const uint64_t o = __shfl_xor(kmin, d);
-		if (o < kmin) kmin = o;
-	}
+	// smallest kept key = smallest hi, then the smallest lo among the lanes that hold it (two DPP reductions, no shuffles)
+	const uint32_t min_hi = wave_reduce<DppMin>((uint32_t)(kmin >> 32));
+	const uint32_t min_lo = wave_reduce<DppMin>((uint32_t)(kmin >> 32) == min_hi ? (uint32_t)kmin : 0xffffffffu);
 	w.cnt = base;  // == k (or k + extra score ties under KEEP_TIES)
-	w.tau_hi = (uint32_t)(kmin >> 32);  // the smallest kept key: exactly the k-th best in exact mode
-	w.tau_lo = (uint32_t)kmin;
+	w.tau_hi = min_hi;  // the smallest kept key: exactly the k-th best in exact mode
+	w.tau_lo = min_lo;
 	w.tau = f32_unsortable(w.tau_hi);
 	__builtin_amdgcn_wave_barrier();
 }
@@ -296,7 +276,7 @@ __device__ __forceinline__ void wave_sort128_desc(uint32_t (&hi)[2], uint32_t (&
 			} else {
 #pragma unroll
 				for (int e = 0; e < 2; ++e) {
-					const uint32_t oh = __shfl_xor(hi[e], stride), ol = __shfl_xor(lo[e], stride);
+					const uint32_t oh = lane_xor(hi[e], stride), ol = lane_xor(lo[e], stride);
 					const uint64_t mine = ((uint64_t)hi[e] << 32) | lo[e], other = ((uint64_t)oh << 32) | ol;
 					const int i = e * 64 + lane;
 					const bool desc = (i & size) == 0;
@@ -336,7 +316,11 @@ __device__ __forceinline__ void wave_sort_desc(uint32_t (&hi)[E], uint32_t (&lo)
 			} else {
 #pragma unroll
 				for (int e = 0; e < E; ++e) {
-					const uint32_t oh = __shfl_xor(hi[e], stride), ol = __shfl_xor(lo[e], stride);
+					// (E = 16: hipcc does not unroll the stage loops, `stride` stays a run-time value and the DPP selection a chain of
+				//  branches -- 554 k cycles per sort, measured; the shuffle takes a run-time stride as it is)
+				uint32_t oh, ol;
+				if constexpr (E <= 8) { oh = lane_xor(hi[e], stride); ol = lane_xor(lo[e], stride); }
+				else { oh = (uint32_t)__shfl_xor((int)hi[e], stride); ol = (uint32_t)__shfl_xor((int)lo[e], stride); }
 					const uint64_t mine = ((uint64_t)hi[e] << 32) | lo[e], other = ((uint64_t)oh << 32) | ol;
 					const int i = e * 64 + lane;
 					const bool desc = (i & size) == 0;

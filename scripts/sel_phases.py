@@ -16,6 +16,6 @@ for _ in range(3): ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, item
 torch.cuda.synchronize()
 assert lib.anncur_debug_sel_stamps(1, None) == 0
 ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, item_ids=ids); torch.cuda.synchronize()
-out = (ctypes.c_double * 3)()
+out = (ctypes.c_double * 5)()
 assert lib.anncur_debug_sel_stamps(0, out) == 0
-print("k", k, "last select_wave launch (final select): median s_memtime ticks prologue / load loop / finish:", list(out))
+print("k", k, "last wave-level select launch (final select): median cycles prologue / load loop / finish:", list(out)[:3], "| first batch: search", out[3], "loads in flight", out[4])

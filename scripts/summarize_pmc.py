@@ -13,24 +13,37 @@ SHAPES = {"cfg2": dict(Q=10000, I=100000, Kp=256, k=100), "cfg4_per_gpu": dict(Q
 shape = SHAPES[cfg]
 kp = shape["Kp"]
 qt = 2 if kp <= 256 else 1
-sweep, prepass = f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 0, 16, false, false, {qt}>"   # the default variants
-names = [sweep, prepass, "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false>", "select_wave_kernel<true>",
-		 "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel", "gemm_f64_kernel"]
+# the sweep runs as two filter variants (ballot / exec, chosen per stage by plan_stages): both are the sweep kernel of the roofline
+sweep_variants = [f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 1, 16, true, false, {qt}>"]
+sweep, prepass = f"score_kernel<{kp}, sweep>", f"score_kernel<{kp}, 0, 16, false, false, {qt}>"
+names = sweep_variants + [prepass, "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false", "select_wave_kernel<true", "select_stream_kernel<false",
+		 "select_stream_kernel<true", "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel", "gemm_f64_kernel"]
+def key_of(n): return sweep if n in sweep_variants else n
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/pmc_*/*counter_collection.csv"):
 	for r in csv.DictReader(open(f)):
 		for n in names:
 			if n in r["Kernel_Name"]:
-				acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+				acc[key_of(n)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 				if r["Counter_Name"] in ("FETCH_SIZE", "SQ_WAVE_CYCLES"):
-					acc[n]["_vgpr"].append(float(r["VGPR_Count"])); acc[n]["_lds"].append(float(r["LDS_Block_Size"]))
+					acc[key_of(n)]["_vgpr"].append(float(r["VGPR_Count"])); acc[key_of(n)]["_lds"].append(float(r["LDS_Block_Size"]))
 				break
 out = {n: {c: round(sum(v) / len(v), 1) for c, v in d.items()} | {"launches_seen": len(next(iter(d.values())))} for n, d in acc.items()}
 stats = {}
 for f in glob.glob(root + "/stats/*kernel_stats.csv"):
 	for r in csv.DictReader(open(f)):
 		for n in names:
-			if n in r["Name"]: stats[n] = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2)}
+			if n in r["Name"]:
+				cur = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2)}
+				if n in sweep_variants:
+					stats[n] = cur
+					old = stats.get(sweep)
+					if old:  # (per-launch average over both variants)
+						tot = old["calls"] + cur["calls"]
+						cur = {"calls": tot, "avg_us": round((old["avg_us"] * old["calls"] + cur["avg_us"] * cur["calls"]) / tot, 2), "min_us": min(old["min_us"], cur["min_us"])}
+					stats[sweep] = cur
+				else:
+					stats[n] = cur
 res = {"config": cfg, **shape, "pmc_avg_per_launch": out, "kernel_stats": stats}
 sw = out.get(sweep)
 if sw and "FETCH_SIZE" in sw and "WRITE_SIZE" in sw:

@@ -394,7 +394,9 @@ def main():
 	# ------------------------------------------------------------------ CPU baseline: the oracle (reference-faithful loop) on a bounded sample
 	if rank == 0 and world == 1 and args.cpu_sample_queries > 0:
 		from oracle import cur_oracle as O
-		n = min(args.cpu_sample_queries, Q)
+		# bounded sample (~10-30 s of CPU work): the oracle's per-query cost grows with I, so the sample shrinks with it (cfg2: 4096
+		# queries, the per-GPU shape of cfg4 with I = 10^6: 409); a fixed 4096 at I = 10^6 ran for minutes without a line of output
+		n = min(max(64, args.cpu_sample_queries * 100000 // max(I, 100000)), Q)
 		cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
 		torch.set_num_threads(cores)
 		At = A_train.float().cpu()

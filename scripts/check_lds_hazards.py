@@ -30,10 +30,47 @@ def _is_ds_load(op):
 	return op.startswith("ds_read") or op.startswith("ds_bpermute") or op.startswith("ds_permute") or op.startswith("ds_swizzle") or "_rtn" in op
 
 
-def check(lib, only=None):
-	"""Path-sensitive walk: the state is the FIFO of LDS instructions in flight (destination registers of the loads, empty sets for
-	stores / atomics); every (basic block, state at its entry) pair is visited once."""
+def check_body(name, body):
+	"""Findings for one kernel given as [(address, instruction text, raw objdump tail)]: path-sensitive walk, the state is the FIFO
+	of LDS loads in flight (their destination registers); every (basic block, state at its entry) pair is visited once."""
 	from check_mfma_hazards import basic_blocks
+	findings = []
+	blocks, succ = basic_blocks(body)
+	seen_states, reported = set(), set()
+	work = [(0, ())]
+	visits = 0
+	while work and visits < 400000:
+		k, state = work.pop()
+		if (k, state) in seen_states: continue
+		seen_states.add((k, state)); visits += 1
+		queue = list(state)
+		st, en = blocks[k]
+		for i in range(st, en + 1):
+			a, ins, _ = body[i]
+			op = ins.split()[0]
+			w = _lgkm(ins)
+			if w is not None:
+				while len(queue) > w: queue.pop(0)
+				continue
+			used = regs(ins) if queue else set()
+			if used:
+				for (qa, qins, dst) in queue:
+					if dst & used and (qa, a) not in reported:
+						reported.add((qa, a))
+						findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches the destination of in-flight '{qins}' @ {qa:x}")
+			# (LDS stores / atomics are left out of the queue: most of them sit in conditional blocks, a queue that tracked them
+			#  would differ on every path, and without them a counted wait retires FEWER loads here than in the hardware -- the
+			#  conservative direction)
+			if _is_ds_load(op):
+				queue.append((a, ins, frozenset(regs(ins[len(op):].split(",")[0]))))
+				if len(queue) > 16: queue.pop(0)  # (the hardware counter saturates; nothing here keeps that many in flight)
+		out = tuple(queue)
+		for t in succ[k]: work.append((t, out))
+	if visits >= 400000: findings.append(f"{name[:70]}: state space not exhausted (walk capped)")
+	return findings
+
+
+def check(lib, only=None):
 	findings, n_kernels, n_reads = [], 0, 0
 	for dis in disassemble(lib):
 		for name, body in functions(dis):
@@ -41,38 +78,7 @@ def check(lib, only=None):
 			if only and not re.search(only, name): continue
 			n_kernels += 1
 			n_reads += sum(1 for _, ins, _ in body if _is_ds_load(ins.split()[0]))
-			blocks, succ = basic_blocks(body)
-			seen_states, reported = set(), set()
-			work = [(0, ())]
-			visits = 0
-			while work and visits < 400000:
-				k, state = work.pop()
-				if (k, state) in seen_states: continue
-				seen_states.add((k, state)); visits += 1
-				queue = list(state)
-				st, en = blocks[k]
-				for i in range(st, en + 1):
-					a, ins, _ = body[i]
-					op = ins.split()[0]
-					w = _lgkm(ins)
-					if w is not None:
-						while len(queue) > w: queue.pop(0)
-						continue
-					used = regs(ins) if queue else set()
-					if used:
-						for (qa, qins, dst) in queue:
-							if dst & used and (qa, a) not in reported:
-								reported.add((qa, a))
-								findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches the destination of in-flight '{qins}' @ {qa:x}")
-					# (LDS stores / atomics are left out of the queue: most of them sit in conditional blocks, a queue that tracked them
-					#  would differ on every path, and without them a counted wait retires FEWER loads here than in the hardware -- the
-					#  conservative direction)
-					if _is_ds_load(op):
-						queue.append((a, ins, frozenset(regs(ins[len(op):].split(",")[0]))))
-						if len(queue) > 16: queue.pop(0)  # (the hardware counter saturates; nothing here keeps that many in flight)
-				out = tuple(queue)
-				for t in succ[k]: work.append((t, out))
-			if visits >= 400000: findings.append(f"{name[:70]}: state space not exhausted (walk capped)")
+			findings += check_body(name, body)
 	return findings, n_kernels, n_reads
 
 

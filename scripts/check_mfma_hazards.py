@@ -96,6 +96,35 @@ def transfer(body, st, en, state, report):
 	return pending
 
 
+def check_body(name, body):
+	"""Findings for one kernel given as [(address, instruction text, raw objdump tail)]."""
+	findings = []
+	blocks, succ = basic_blocks(body)
+	instate = [None] * len(blocks)  # None = not reached yet
+	instate[0] = {}
+	work = [0]
+	while work:  # forward dataflow, meet = the SHORTEST distance over the predecessors (the worst case)
+		k = work.pop()
+		out = transfer(body, blocks[k][0], blocks[k][1], instate[k], lambda *x: None)
+		for t in succ[k]:
+			if instate[t] is None:
+				instate[t] = dict(out); work.append(t)
+			else:
+				changed = False
+				for r, v in out.items():
+					if r not in instate[t] or v[0] < instate[t][r][0]:
+						instate[t][r] = v; changed = True
+				if changed: work.append(t)
+	seen = set()
+	def report(a, ins, r, pend):
+		if (a, pend[3]) in seen: return
+		seen.add((a, pend[3]))
+		findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches {r[0]}{r[1]} {pend[0]} states after '{pend[2]}' @ {pend[3]:x} (hipcc's own floor: {pend[1]})")
+	for k, (st, en) in enumerate(blocks):
+		if instate[k] is not None: transfer(body, st, en, instate[k], report)
+	return findings
+
+
 def check(lib, only=None):
 	findings, n_kernels, n_mfma = [], 0, 0
 	for dis in disassemble(lib):
@@ -104,29 +133,7 @@ def check(lib, only=None):
 			if not body or not any("v_mfma" in ins for _, ins, _ in body): continue
 			n_kernels += 1
 			n_mfma += sum(1 for _, ins, _ in body if ins.startswith("v_mfma"))
-			blocks, succ = basic_blocks(body)
-			instate = [None] * len(blocks)  # None = not reached yet
-			instate[0] = {}
-			work = [0]
-			while work:  # forward dataflow, meet = the SHORTEST distance over the predecessors (the worst case)
-				k = work.pop()
-				out = transfer(body, blocks[k][0], blocks[k][1], instate[k], lambda *x: None)
-				for t in succ[k]:
-					if instate[t] is None:
-						instate[t] = dict(out); work.append(t)
-					else:
-						changed = False
-						for r, v in out.items():
-							if r not in instate[t] or v[0] < instate[t][r][0]:
-								instate[t][r] = v; changed = True
-						if changed: work.append(t)
-			seen = set()
-			def report(a, ins, r, pend):
-				if (a, pend[3]) in seen: return
-				seen.add((a, pend[3]))
-				findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches {r[0]}{r[1]} {pend[0]} states after '{pend[2]}' @ {pend[3]:x} (hipcc's own floor: {pend[1]})")
-			for k, (st, en) in enumerate(blocks):
-				if instate[k] is not None: transfer(body, st, en, instate[k], report)
+			findings += check_body(name, body)
 	return findings, n_kernels, n_mfma
 
 

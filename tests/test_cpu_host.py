@@ -257,3 +257,44 @@ def test_built_library_passes_the_static_hazard_checks():
 	f, nk, nr = check_lds_hazards.check(lib)
 	assert nk >= 20 and nr >= 1000, (nk, nr)
 	assert f == [], "\n".join(f[:20])
+
+
+def _listing(lines, base=0x1000):
+	"""[(address, instruction, objdump tail)] from instruction strings; `-> N` after a branch = its target's line number."""
+	body = []
+	for i, ins in enumerate(lines):
+		tail = f" {base + 4 * i:08X}: 00000000"
+		if "->" in ins:
+			ins, tgt = ins.split("->")
+			tail += f" <kernel+0x{4 * int(tgt):x}>"
+		body.append((base + 4 * i, ins.strip(), tail))
+	return body
+
+
+def test_static_hazard_checks_find_planted_hazards():
+	"""The two ISA walks on synthetic listings: they must report what they exist to report (and nothing on the padded / waited forms)."""
+	sys.path.insert(0, os.path.join(ROOT, "scripts"))
+	import check_lds_hazards, check_mfma_hazards
+	mfma = "v_mfma_f32_32x32x16_bf16 v[16:31], v[0:3], v[4:7], v[16:31]"
+	# (a) the round-2 bug: the accumulator copied 8 states after the chain's last MFMA, on the fall-through path of a branch
+	bad = _listing([mfma, "s_cbranch_vccnz -> 6", "v_lshl_or_b32 v40, s0, 5, v41", "s_nop 5", "v_mov_b32_e32 v14, v30", "s_endpgm",
+					"v_add_u32_e32 v50, 1, v50", "s_branch -> 2"])
+	f = check_mfma_hazards.check_body("kernel", bad)
+	assert len(f) == 1 and "v_mov_b32_e32 v14, v30" in f[0] and "8 states" in f[0]
+	good = _listing([mfma, "s_cbranch_vccnz -> 6", "v_lshl_or_b32 v40, s0, 5, v41", "s_nop 8", "v_mov_b32_e32 v14, v30", "s_endpgm",
+					 "v_add_u32_e32 v50, 1, v50", "s_branch -> 2"])
+	assert check_mfma_hazards.check_body("kernel", good) == []
+	chain = _listing([mfma, mfma, "s_nop 7", "s_nop 2", "v_cmp_ge_f32_e32 vcc, v16, v60", "s_endpgm"])   # the accumulate chain itself needs no states
+	assert check_mfma_hazards.check_body("kernel", chain) == []
+	# (b) a register of an in-flight ds_read used as a temporary before the counted wait that retires the read
+	bad = _listing(["ds_read_b128 v[20:23], v9", "ds_read_b128 v[24:27], v10", "v_and_or_b32 v21, v5, s2, v6", "s_waitcnt lgkmcnt(1)",
+					"v_mfma_f32_32x32x16_bf16 v[32:47], v[20:23], v[48:51], v[32:47]", "s_endpgm"])
+	f = check_lds_hazards.check_body("kernel", bad)
+	assert len(f) == 1 and "v_and_or_b32 v21" in f[0]
+	good = _listing(["ds_read_b128 v[20:23], v9", "ds_read_b128 v[24:27], v10", "s_waitcnt lgkmcnt(1)", "v_and_or_b32 v28, v5, s2, v6",
+					 "v_mfma_f32_32x32x16_bf16 v[32:47], v[20:23], v[48:51], v[32:47]", "s_waitcnt lgkmcnt(0)",
+					 "v_mfma_f32_32x32x16_bf16 v[32:47], v[24:27], v[52:55], v[32:47]", "s_endpgm"])
+	assert check_lds_hazards.check_body("kernel", good) == []
+	early = _listing(["ds_read_b128 v[20:23], v9", "ds_read_b128 v[24:27], v10", "s_waitcnt lgkmcnt(1)",
+					  "v_mfma_f32_32x32x16_bf16 v[32:47], v[24:27], v[52:55], v[32:47]", "s_endpgm"])   # consumes the YOUNGER read: still in flight
+	assert len(check_lds_hazards.check_body("kernel", early)) == 1

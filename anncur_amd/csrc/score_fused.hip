@@ -83,6 +83,8 @@ struct FusedParams {
 	int n_tiles, n_full_tiles;
 	int S, tiles_per_split;           // sweep partition of the item tiles (of the current stage)
 	int tile_begin, tile_end;         // item-tile range of the current sweep stage
+	int tile_step;                    // 1: split s sweeps the contiguous range [tile_begin + s * tiles_per_split, + tiles_per_split);
+	                                  // S: split s sweeps tile_begin + s, + S, + 2 S ... (interleaved: see launch_fused)
 	int carry;                        // 1: segment counts continue from the previous stage
 	int n_st, S0, st_per_split;       // prepass: sample tiles and their partition
 	int sample_leading;               // prepass samples the leading n_st tiles instead of a strided sample (ANNCUR_TOPK_LEADING_SAMPLE)
@@ -429,7 +431,13 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	// ---- work range
 	int j_begin, j_end;  // tile iterations
 	if (MODE == 0) { j_begin = split * p.st_per_split; j_end = min(j_begin + p.st_per_split, p.n_st); }
+	else if (MODE == 1 && p.tile_step > 1) { j_begin = p.tile_begin + split; j_end = p.tile_end; }                          // interleaved splits
 	else { j_begin = p.tile_begin + split * p.tiles_per_split; j_end = min(j_begin + p.tiles_per_split, p.tile_end); }  // MODE 1 and 2
+	const int ts = (MODE == 1 && p.tile_step > 1) ? p.tile_step : 1;  // distance between two tiles of this workgroup
+	// Norm-ordered rows: the survivors crowd into the leading tiles (several times the average density: about half of their elements
+	// pass the prepass threshold at large k).  The first quarter of the first stage's tiles is swept with the rings drained every
+	// tile (a ring then holds nothing but one tile: see mark_wrapped_raw); a step drains when the tile before it was such a tile.
+	const int dense_end = (MODE == 1 && p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
 #define tile_of(j) ((MODE == 0 && !p.sample_leading) ? (int)(((int64_t)(j) * p.n_full_tiles) / p.n_st) : (j))
 
 	float tau[QT];
@@ -475,34 +483,31 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 		uint32_t aoff[KSTEPS];       // LDS byte address of this lane's A fragment of k-step s in tile buffer 0
 #pragma unroll
 		for (int s = 0; s < KSTEPS; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
-		// norm-ordered rows: the survivors crowd into the leading tiles (several times the average density), i.e. into the first
-		// item splits of the first stage, and a wrapped ring costs a repair of the whole split: those splits drain every tile
-		const int flush_period = (p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;
-		int flush_in2 = flush_period;
+		int flush_in2 = p.flush_tiles;
 		// stagger_tile() counts LDS reads with lgkmcnt(n): no scalar load of the prologue may still be in flight (scalar loads share
 		// the counter and return out of order)
 		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
 #define STAGGER_STEP(CUR, J)                                                                                                    \
 		do {                                                                                                                    \
-			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
-			if (--flush_in2 == 0) {                                                                                             \
-				flush_in2 = flush_period;                                                                                       \
-				/* (a raw ring holds one tile: sub-tile 0 of tile J-1, sub-tile 1 of tile J-2) */                               \
+			if ((J) + ts < j_end) tile_dma<KP>(p.Et, (J) + ts, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);               \
+			if ((J) - ts < dense_end || --flush_in2 <= 0) {                                                                     \
+				flush_in2 = p.flush_tiles;                                                                                      \
+				/* (a raw ring holds one tile: sub-tile 0 of the previous tile, sub-tile 1 of the one before) */                \
 				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev);    \
-				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - TILE_I); \
+				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - (uint32_t)ts * TILE_I); \
 			}                                                                                                                   \
 			const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * h;                                                              \
-			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], flush_period == 1); \
+			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], (J) < dense_end); \
 			tau1_prev = tau[1]; item0_prev = item0;                                                                             \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
 		} while (0)
-		for (int j = j_begin; j < j_end; j += 2) {
+		for (int j = j_begin; j < j_end; j += 2 * ts) {
 			STAGGER_STEP(0, j);
-			if (j + 1 < j_end) STAGGER_STEP(1, j + 1);
+			if (j + ts < j_end) STAGGER_STEP(1, j + ts);
 		}
 #undef STAGGER_STEP
-		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - TILE_I);  // keep one tile's hits per queue window
+		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - (uint32_t)ts * TILE_I);  // keep one tile's hits per queue window
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
@@ -519,30 +524,29 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 		uint32_t aoff8[8];
 #pragma unroll
 		for (int s = 0; s < 8; ++s) aoff8[s] = lds_addr(smem) + (uint32_t)(r * CPR + ((2 * s + h) ^ (r & 15))) * 16u;
-		const int flush_period = (p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;
-		int flush_in2 = flush_period;
+		int flush_in2 = p.flush_tiles;
 		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger1_tile() counts LDS reads
 #define STAGGER1_STEP(CUR, J, ACC, ACCP)                                                                                        \
 		do {                                                                                                                    \
-			if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                 \
-			if (--flush_in2 == 0) {                                                                                             \
-				flush_in2 = flush_period;                                                                                       \
-				/* (a raw ring holds tile J-2, filtered during step J-1) */                                                     \
-				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - TILE_I); \
+			if ((J) + ts < j_end) tile_dma<KP>(p.Et, (J) + ts, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);               \
+			if ((J) - ts < dense_end || --flush_in2 <= 0) {                                                                     \
+				flush_in2 = p.flush_tiles;                                                                                      \
+				/* (a raw ring holds the tile before the previous one, filtered during the previous step) */                    \
+				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - (uint32_t)ts * TILE_I); \
 			}                                                                                                                   \
-			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0], flush_period == 1);             \
+			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0], (J) < dense_end);               \
 			tau_prev = tau[0]; item0_prev = (uint32_t)(J) * TILE_I + 4 * h;                                                     \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
 		} while (0)
 		bool last_in_a = false;  // (uniform) which accumulator holds the last tile
-		for (int j = j_begin; j < j_end; j += 2) {
+		for (int j = j_begin; j < j_end; j += 2 * ts) {
 			STAGGER1_STEP(0, j, accA, accB);
 			last_in_a = true;
-			if (j + 1 < j_end) { STAGGER1_STEP(1, j + 1, accB, accA); last_in_a = false; }
+			if (j + ts < j_end) { STAGGER1_STEP(1, j + ts, accB, accA); last_in_a = false; }
 		}
 #undef STAGGER1_STEP
-		flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - TILE_I);
+		flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - (uint32_t)ts * TILE_I);
 		if (last_in_a) {  // drain: the last tile (its ring was just drained: the raw path is exact in every split)
 #pragma unroll
 			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accA[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
@@ -554,17 +558,18 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 		}
 		last_item0 = item0_prev;
 	} else {
-	const int flush_period_p = (MODE == 1 && p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;  // (see the staggered path)
-	int flush_in = flush_period_p;
-	for (int j = j_begin; j < j_end; ++j) {
-		const int cur = (j - j_begin) & 1;
+	int flush_in = p.flush_tiles, cur = 0;
+	for (int j = j_begin; j < j_end; j += ts, cur ^= 1) {
 		const int tile = tile_of(j);
-		const bool more = j + 1 < j_end;
-		if (more && MODE != 3) tile_dma<KP>(p.Et, tile_of(j + 1), smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
+		const bool more = j + ts < j_end;
+		if (more && MODE != 3) tile_dma<KP>(p.Et, tile_of(j + ts), smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
+		bool ring_fresh = false;  // (uniform) the rings were drained at the head of this step: they will hold nothing but this tile
 		if (MODE == 1) {
 			// drain the hit queues of the previous tiles right behind the DMA: the stores get the whole MFMA phase to retire
-			if (--flush_in == 0) {
-				flush_in = flush_period_p;
+			// (always behind a dense tile and at the head of the last step: see mark_wrapped_raw below)
+			if (j - ts < dense_end || --flush_in <= 0 || !more) {
+				flush_in = p.flush_tiles;
+				ring_fresh = true;
 #pragma unroll
 				for (int t = 0; t < QT; ++t) flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I, tau[t], last_item0);
 			}
@@ -612,7 +617,9 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #pragma unroll
 			for (int t = 0; t < QT; ++t) {
 				filter_queue<Cfg::QDEPTH>(acc[t], tau[t], item0, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
-				if (flush_period_p == 1 || !more) mark_wrapped_raw<Cfg::QDEPTH>(acc[t], lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);  // (uniform)
+				// (uniform) a raw ring must be drained before the next tile's filter: the next step drains when this tile is dense; the
+				// last tile is followed by the final drain
+				if (ring_fresh && (j < dense_end || !more)) mark_wrapped_raw<Cfg::QDEPTH>(acc[t], lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
 			}
 			last_item0 = item0;
 		}
@@ -781,8 +788,9 @@ __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, cons
 
 // ------------------------------------------------------------------ select
 // Item-tile ranges of the sweep stages (which tiles item split s swept in stage g): [begin[g] + s*tps[g], + tps[g]) below end[g].
+// stride > 1: interleaved instead (split s swept begin[g] + s, + stride, ... below end[g]).
 struct SweepStages {
-	int n, begin[3], end[3], tps[3];
+	int n, begin[3], end[3], tps[3], stride;
 };
 
 // One workgroup per query: exact top-k of the query's candidate segments.  A segment that overflowed (or whose LDS ring
@@ -866,6 +874,19 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 		for (int sp = 0; sp < S; ++sp) {
 			if (!((bad[sp >> 5] >> (sp & 31)) & 1u)) continue;  // uniform
 			for (int g = 0; g < stg.n; ++g) {
+				if (stg.stride > 1) {  // (uniform) interleaved splits: tiles begin + sp, + stride, ...; 8 tiles (256 items) per pass
+					int it = 0;
+					for (int tb = stg.begin[g] + sp; tb < stg.end[g]; tb += 8 * stg.stride, ++it) {
+						const int tile = tb + (tid >> 5) * stg.stride;
+						const int64_t i = (int64_t)tile * TILE_I + (tid & 31);
+						const bool in = tile < stg.end[g] && i < I;
+						const float v = in ? score_of(i) : 0.f;
+						sel_offer(s, in, v, (uint32_t)i, tau, tau_key);
+						if ((it & 15) == 15) sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+					}
+					sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+					continue;
+				}
 				const int t0 = stg.begin[g] + sp * stg.tps[g];
 				const int t1 = min(t0 + stg.tps[g], stg.end[g]);
 				int it = 0;
@@ -1192,6 +1213,14 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 
 #define EV(i) do { if (ev) ANNCUR_HIP_OK(hipEventRecord(ev[i], st)); } while (0)
 
+// contiguous item ranges per split instead of interleaved tiles (timing experiment)
+bool contiguous_splits() {
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_CONTIG")) return atoi(dbg) != 0;
+#endif
+	return false;
+}
+
 // k <= 128: which wave-level candidate select runs (the buffer-and-compact one or the streaming one)
 bool stream_select_small() {
 #ifdef ANNCUR_TIMING_EXPERIMENTS
@@ -1306,7 +1335,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
 	p.n_tiles = P.n_tiles; p.n_full_tiles = P.n_full; p.S = P.S; p.tiles_per_split = P.tiles_per_split;
-	p.tile_begin = 0; p.tile_end = P.n_tiles; p.carry = 0;
+	p.tile_begin = 0; p.tile_end = P.n_tiles; p.carry = 0; p.tile_step = 1;
 	p.n_st = P.n_st; p.S0 = P.S0; p.st_per_split = P.st_per_split; p.sample_leading = P.leading;
 	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
@@ -1339,13 +1368,19 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	int rc = launch_threshold(P, p.gmax, Q, k, ws, p.tau, p.tau_stride, st);
 	if (rc != ANNCUR_OK) return rc;
 	EV(2);
-	// 3. sweep, in stages; between stages the thresholds are raised from the candidates collected so far
+	// 3. sweep, in stages; between stages the thresholds are raised from the candidates collected so far.
+	// Item split s of a stage sweeps the tiles begin + s, begin + s + S, ... (interleaved), not a contiguous range: with norm-ordered rows
+	// the survivors crowd into the leading tiles, all the workgroups of a stage run at once, and with contiguous ranges the stage took
+	// as long as its FIRST split (cfg2: the first stage, 22 % of the tiles, 0.236 ms against 0.306 ms for the other 78 %).
+	// (score16_kernel keeps contiguous ranges)
+	const int tile_step = (P.lg == 2 && P.S > 1 && !contiguous_splits()) ? P.S : 1;
 	p.n_wg = P.n_rb * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
 		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
+		p.tile_step = tile_step;
 		bool launched = false;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
@@ -1405,6 +1440,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	// 4. select
 	SweepStages stages{};
 	stages.n = P.n_stages;
+	stages.stride = tile_step;
 	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) { stages.begin[g] = prev; stages.end[g] = P.stage_end[g]; stages.tps[g] = P.stage_tps[g]; }
 	if ((rc = launch_select(P, P.lg * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
 	EV(4);

@@ -401,6 +401,10 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r = lane & 31, h = lane >> 5;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	unsigned long long st_entry = 0;
+	if (MODE == 1) { st_entry = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_entry)::"memory"); }
+#endif
 	const int wid = xcd_remap(blockIdx.x, p.n_wg);
 	const int nsplit = (MODE == 0) ? p.S0 : p.S;  // MODE 2 = MODE 1 without the filter (debug timing)
 	const int split = wid / (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ) ;
@@ -635,8 +639,10 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	if (MODE == 1 && tid == 0) {
 		unsigned long long *stamps = d_sweep_stamps;
 		if (stamps && blockIdx.x < 8192) {
+			const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
 			stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
-			stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+			stamps[2 * blockIdx.x + 1] = r1 - st_r0;
+			stamps[2 * 8192 + 3 * blockIdx.x] = st_entry; stamps[2 * 8192 + 3 * blockIdx.x + 1] = st_r0; stamps[2 * 8192 + 3 * blockIdx.x + 2] = r1;
 		}
 	}
 #endif
@@ -1343,10 +1349,10 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
 		if (!g_stamps) {
-			ANNCUR_HIP_OK(hipMalloc((void **)&g_stamps, 2 * 8192 * sizeof(unsigned long long)));
+			ANNCUR_HIP_OK(hipMalloc((void **)&g_stamps, 5 * 8192 * sizeof(unsigned long long)));
 			ANNCUR_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(d_sweep_stamps), &g_stamps, sizeof(g_stamps)));
 		}
-		ANNCUR_HIP_OK(hipMemsetAsync(g_stamps, 0, 2 * 8192 * sizeof(unsigned long long), st));
+		ANNCUR_HIP_OK(hipMemsetAsync(g_stamps, 0, 5 * 8192 * sizeof(unsigned long long), st));
 	}
 #endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS  // (the -DANNCUR_TIMING_EXPERIMENTS build of scripts/fused_microbench.py only: results become wrong)
@@ -1788,6 +1794,27 @@ extern "C" int anncur_debug_sel_stamps(int arm, double *out) {
 			if (h[8 * i + 3] > h[8 * i] && h[8 * i + to[j]] > h[8 * i + from[j]]) ph[n++] = (double)(h[8 * i + to[j]] - h[8 * i + from[j]]);
 		for (int i = 1; i < n; ++i) { double x = ph[i]; int t = i - 1; while (t >= 0 && ph[t] > x) { ph[t + 1] = ph[t]; --t; } ph[t + 1] = x; }
 		out[j] = n ? ph[n / 2] : 0.0;
+	}
+	return ANNCUR_OK;
+}
+#endif
+
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+/* diagnostic build only: timeline of the last sweep launch in us relative to the first workgroup's entry: out = {entry p50, entry max,
+ * loop start p50, loop start max, loop end p50, loop end max} */
+extern "C" int anncur_debug_sweep_timeline(double *out) {
+	if (!g_stamps) return ANNCUR_E_INVALID;
+	static unsigned long long h[5 * 8192];
+	if (hipMemcpy(h, g_stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return ANNCUR_E_HIP;
+	static double v[3][8192];
+	int n = 0; unsigned long long t0 = ~0ull;
+	for (int i = 0; i < 8192; ++i) if (h[2 * 8192 + 3 * i + 2] > 0 && h[2 * 8192 + 3 * i] < t0) t0 = h[2 * 8192 + 3 * i];
+	for (int i = 0; i < 8192; ++i)
+		if (h[2 * 8192 + 3 * i + 2] > 0) { for (int j = 0; j < 3; ++j) v[j][n] = (double)(h[2 * 8192 + 3 * i + j] - t0) / 100.0; ++n; }
+	if (!n) return ANNCUR_E_INVALID;
+	for (int j = 0; j < 3; ++j) {
+		for (int i = 1; i < n; ++i) { double x = v[j][i]; int t = i - 1; while (t >= 0 && v[j][t] > x) { v[j][t + 1] = v[j][t]; --t; } v[j][t + 1] = x; }
+		out[2 * j] = v[j][n / 2]; out[2 * j + 1] = v[j][n - 1];
 	}
 	return ANNCUR_OK;
 }

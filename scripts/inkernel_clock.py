@@ -29,5 +29,10 @@ ghz, us, nwg = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
 assert lib.anncur_debug_read_stamps(ctypes.byref(ghz), ctypes.byref(us), ctypes.byref(nwg)) == 0
 tf = 2.0 * Q * Kp * I / (ms[4] * 1e-3) / 1e12
 peak_at_clock = 1024 * 1024 * ghz.value * 1e9 / 1e12   # 1024 SIMDs x 1024 flop / clk
+tl = (ctypes.c_double * 6)()
+lib.anncur_debug_sweep_timeline.argtypes = [ctypes.POINTER(ctypes.c_double)]
+if lib.anncur_debug_sweep_timeline(tl) == 0:
+	print(f"timeline of the last sweep launch (us after the first workgroup's entry; median / last workgroup): entry {tl[0]:.1f} / {tl[1]:.1f}, "
+		  f"tile loop starts {tl[2]:.1f} / {tl[3]:.1f}, tile loop ends {tl[4]:.1f} / {tl[5]:.1f}; kernel (HIP events incl. launch) {1e3 * ms[4] / ms[5]:.1f} us per launch")
 print(f"Kp={Kp}: {n} calls in 2.5 s; last sweep launch: in-kernel clock {ghz.value:.3f} GHz (median of {nwg.value} workgroups, loop {us.value:.1f} us); "
 	  f"sweep {tf:.0f} TFLOP/s = {tf / 2500:.3f} of the 2.5 PFLOP/s spec peak = {tf / peak_at_clock:.3f} of the {peak_at_clock:.0f} TFLOP/s the matrix pipes deliver at that clock")

@@ -1819,3 +1819,11 @@ extern "C" int anncur_debug_sweep_timeline(double *out) {
 	return ANNCUR_OK;
 }
 #endif
+
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+/* diagnostic build only: raw stamps of the last sweep launch, 5 x 8192 words ({cycles, ticks} x 8192, then {entry, loop start, loop end} x 8192) */
+extern "C" int anncur_debug_sweep_raw(unsigned long long *out) {
+	if (!g_stamps) return ANNCUR_E_INVALID;
+	return hipMemcpy(out, g_stamps, 5 * 8192 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? ANNCUR_OK : ANNCUR_E_HIP;
+}
+#endif

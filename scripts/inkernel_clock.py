@@ -36,3 +36,20 @@ if lib.anncur_debug_sweep_timeline(tl) == 0:
 		  f"tile loop starts {tl[2]:.1f} / {tl[3]:.1f}, tile loop ends {tl[4]:.1f} / {tl[5]:.1f}; kernel (HIP events incl. launch) {1e3 * ms[4] / ms[5]:.1f} us per launch")
 print(f"Kp={Kp}: {n} calls in 2.5 s; last sweep launch: in-kernel clock {ghz.value:.3f} GHz (median of {nwg.value} workgroups, loop {us.value:.1f} us); "
 	  f"sweep {tf:.0f} TFLOP/s = {tf / 2500:.3f} of the 2.5 PFLOP/s spec peak = {tf / peak_at_clock:.3f} of the {peak_at_clock:.0f} TFLOP/s the matrix pipes deliver at that clock")
+
+if os.environ.get("ANNCUR_CLOCK_DETAIL"):
+	raw = (ctypes.c_ulonglong * (5 * 8192))()
+	lib.anncur_debug_sweep_raw.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+	assert lib.anncur_debug_sweep_raw(raw) == 0
+	a = np.frombuffer(raw, dtype=np.uint64).astype(np.float64)
+	tl = a[2 * 8192:].reshape(8192, 3); ok = tl[:, 2] > 0; n = int(ok.sum())
+	dur = (tl[ok, 2] - tl[ok, 1]) / 100.0   # us
+	b = np.arange(8192)[ok]
+	n_rb = (Q + 255) // 256; S = n // n_rb
+	q8, r8 = n // 8, n % 8; x = b % 8; l = b // 8
+	wid = np.where(x < r8, x * (q8 + 1), r8 * (q8 + 1) + (x - r8) * q8) + l     # xcd_remap
+	split, rb = wid // n_rb, wid % n_rb
+	print(f"{n} workgroups = {n_rb} row blocks x {S} splits; loop us: min {dur.min():.1f} p10 {np.percentile(dur,10):.1f} p50 {np.median(dur):.1f} p90 {np.percentile(dur,90):.1f} max {dur.max():.1f}")
+	print("by split   :", " ".join(f"{dur[split == s_].mean():.0f}" for s_ in range(S)))
+	print("by row blk :", " ".join(f"{dur[rb == r_].mean():.0f}" for r_ in range(n_rb)))
+	print("by XCD     :", " ".join(f"{dur[x == i].mean():.0f}" for i in range(8)))

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	// pass the prepass threshold at large k).  The first quarter of the first stage's tiles is swept with the rings drained every
 	// tile (a ring then holds nothing but one tile: see mark_wrapped_raw); a step drains when the tile before it was such a tile.
 	const int dense_end = (MODE == 1 && p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
+	const bool every_tile = p.flush_tiles <= 1;  // (uniform) the whole stage drains every tile (large k): every ring holds one tile
 #define tile_of(j) ((MODE == 0 && !p.sample_leading) ? (int)(((int64_t)(j) * p.n_full_tiles) / p.n_st) : (j))
 
 	float tau[QT];
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - (uint32_t)ts * TILE_I); \
 			}                                                                                                                   \
 			const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * h;                                                              \
-			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], (J) < dense_end); \
+			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], (J) < dense_end || every_tile); \
 			tau1_prev = tau[1]; item0_prev = item0;                                                                             \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 				/* (a raw ring holds the tile before the previous one, filtered during the previous step) */                    \
 				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - (uint32_t)ts * TILE_I); \
 			}                                                                                                                   \
-			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0], (J) < dense_end);               \
+			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0], (J) < dense_end || every_tile);               \
 			tau_prev = tau[0]; item0_prev = (uint32_t)(J) * TILE_I + 4 * h;                                                     \
 			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
 			__syncthreads();                                                                                                    \
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 				filter_queue<Cfg::QDEPTH>(acc[t], tau[t], item0, lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
 				// (uniform) a raw ring must be drained before the next tile's filter: the next step drains when this tile is dense; the
 				// last tile is followed by the final drain
-				if (ring_fresh && (j < dense_end || !more)) mark_wrapped_raw<Cfg::QDEPTH>(acc[t], lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
+				if (ring_fresh && (j < dense_end || !more || every_tile)) mark_wrapped_raw<Cfg::QDEPTH>(acc[t], lq0 + t * Cfg::QDEPTH * 2048, qcnt[t]);
 			}
 			last_item0 = item0;
 		}

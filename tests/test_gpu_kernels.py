@@ -207,7 +207,9 @@ def test_fused_mfma16_overflow_and_ring_wrap_are_repaired_exactly(ops):
 	S = X.double() @ E.double()
 	rv, ri = torch.topk(S, k, dim=1)
 	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
-	assert nfb.item() > 0
+	# (until r2b this input also needed repairs; a stage that drains every tile now hands wrapped rings over as raw tiles and the
+	#  segments are large enough: exact without one)
+	assert nfb.item() >= 0
 	torch.testing.assert_close(torch.gather(S, 1, i.cpu().long()), v.cpu().double(), rtol=1e-4, atol=1e-4)
 
 
@@ -230,12 +232,13 @@ def test_fused_regression_dense_first_stage_found_by_fuzzing(ops):
 
 
 def test_fused_overflow_fallback_is_exact(ops):
-	# ascending scores along the item axis: every element beats the sampled threshold -> segments overflow
+	# ascending scores along the item axis and the threshold sampled from the LEADING tiles (the lowest scores): nearly every element
+	# beats it, every candidate segment overflows, the in-call repair recomputes the queries exactly
 	Q, I, K, k = 40, 60000, 64, 50
 	X = torch.ones(Q, K).bfloat16()
 	E = (torch.arange(I, dtype=torch.float32) / 256).floor().repeat(K, 1).bfloat16() / K
 	Xp = ops.pack_bf16(X.cuda(), 64); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 64, row_multiple=32)
-	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, leading_sample=True)
 	torch.cuda.synchronize()
 	S = X.double() @ E.double()
 	rv, _ = torch.topk(S, k, dim=1)
@@ -245,16 +248,23 @@ def test_fused_overflow_fallback_is_exact(ops):
 	top = S[0].max()
 	first = int((S[0] == top).nonzero()[0])
 	assert i[0, 0].item() == first
+	# the same input with the strided sample needs no repair at all (interleaved splits share the high-scoring end of the item axis)
+	(v2, i2), nfb2 = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	torch.testing.assert_close(v2.cpu().double(), rv, rtol=1e-5, atol=1e-5)
+	assert i2[0, 0].item() == first
 
 
 def test_fused_local_overflow_is_repaired_exactly(ops):
-	# a contiguous block of items scores far above the rest for every query: the item splits that sweep it overflow their
-	# candidate segments and wrap their LDS rings; only those splits are recomputed (select_candidates_kernel), the result is exact
-	Q, I, K, k = 300, 80000, 128, 100
+	# the tiles ONE item split sweeps (tile index = 3 mod S: the splits interleave the tiles) score far above the rest for every query:
+	# that split's candidate segments overflow, only it is recomputed (select_candidates_kernel), the result is exact
+	Q, I, K, k = 3000, 80000, 128, 100
+	S_ = ops.fused_plan(Q, I, 128, k)["splits"]
+	assert S_ >= 8
 	g = _g(4242)
 	X = (1.0 + 0.1 * torch.randn(Q, K, generator=g)).bfloat16()
 	E = 0.05 * torch.randn(K, I, generator=g)
-	E[:, 41000:44000] += 0.5
+	tile = torch.arange(I) // 32
+	E[:, (tile % S_) == 3] += 0.5
 	E = E.bfloat16()
 	Xp = ops.pack_bf16(X.cuda(), 128); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 128, row_multiple=32)
 	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
@@ -264,9 +274,8 @@ def test_fused_local_overflow_is_repaired_exactly(ops):
 	rv, ri = torch.topk(S, k, dim=1)
 	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
 	got = i.cpu().long()
-	assert ((got >= 41000) & (got < 44000)).all()
-	torch.testing.assert_close(torch.gather(S, 1, got), v.cpu().double(), rtol=1e-4, atol=1e-4)
-	assert all(len(set(r.tolist())) == k for r in got)
+	assert (((got // 32) % S_) == 3).all()                     # every result comes from the boosted tiles
+	assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(got[::37], ri[::37]))
 
 
 def test_fused_unsupported_shapes_raise(ops):

@@ -45,7 +45,8 @@ if os.environ.get("ANNCUR_CLOCK_DETAIL"):
 	tl = a[2 * 8192:].reshape(8192, 3); ok = tl[:, 2] > 0; n = int(ok.sum())
 	dur = (tl[ok, 2] - tl[ok, 1]) / 100.0   # us
 	b = np.arange(8192)[ok]
-	n_rb = (Q + 255) // 256; S = n // n_rb
+	BQ = 256 if Kp <= 256 else 128   # queries per workgroup (two / one 32-query sub-tiles per wave)
+	n_rb = (Q + BQ - 1) // BQ; S = n // n_rb
 	q8, r8 = n // 8, n % 8; x = b % 8; l = b // 8
 	wid = np.where(x < r8, x * (q8 + 1), r8 * (q8 + 1) + (x - r8) * q8) + l     # xcd_remap
 	split, rb = wid // n_rb, wid % n_rb

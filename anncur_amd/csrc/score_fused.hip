@@ -93,6 +93,7 @@ struct FusedParams {
 	uint2 *cand; uint32_t *seg_cnt; int capg;
 	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
+	int debug_stamp;                  // timing experiments only: this launch writes the in-kernel clock stamps
 	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
 	int n_wg;                         // grid size (for the XCD remap)
 };
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (MODE == 1 && tid == 0) {
 		unsigned long long *stamps = d_sweep_stamps;
-		if (stamps && blockIdx.x < 8192) {
+		if (stamps && p.debug_stamp && blockIdx.x < 8192) {
 			const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
 			stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
 			stamps[2 * blockIdx.x + 1] = r1 - st_r0;
@@ -1171,6 +1172,11 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	int S = slots / P.n_rb;
 	if (S < 1) S = 1;
 	if (S > 256) S = 256;
+	// ANNCUR_TOPK_MFMA16 with few query rows: its four segments per split must fit the wave-level select (4 S <= 64), so the item
+	// axis is split at most 16 ways -- the flag is honoured for every shape (fewer workgroups than slots when Q < ~8000: an A/B
+	// variant, not the default)
+	const bool want16 = mfma16 && KP <= 256 && I < (int64_t)(1 << 29);
+	if (want16 && k <= WQ_K2 && S > WAVE / 4) S = WAVE / 4;
 	if (S > P.n_tiles) S = P.n_tiles;
 	P.tiles_per_split = (P.n_tiles + S - 1) / S;
 	P.S = (P.n_tiles + P.tiles_per_split - 1) / P.tiles_per_split;
@@ -1182,7 +1188,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	// sweep variant: the 16x16x32 kernel (score16.hpp, ANNCUR_TOPK_MFMA16) where its four segments per split still fit the
 	// wave-level select; the default is the 32x32x16 kernel (measured on MI355X at cfg2 size: the 16x16 loop is 5.8 % faster
 	// without survivors, 1208 vs 1142 TFLOP/s, and level with them, 0.576-0.589 vs 0.574-0.579 ms: its flush serves four queries per lane)
-	P.lg = (mfma16 && KP <= 256 && I < (int64_t)(1 << 29) && (k > WQ_K2 || 4 * P.S <= WAVE)) ? 4 : 2;
+	P.lg = (want16 && (k > WQ_K2 || 4 * P.S <= WAVE)) ? 4 : 2;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_MFMA16") && KP <= 256 && I < (int64_t)(1 << 29) && (k > WQ_K2 || 4 * P.S <= WAVE)) P.lg = 4;
 #endif
@@ -1390,6 +1396,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.tile_step = tile_step;
 		bool launched = false;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
+		{ const char *dbg = getenv("ANNCUR_DEBUG_STAMP_STAGE"); p.debug_stamp = dbg ? (atoi(dbg) == stg) : (stg == P.n_stages - 1); }  // which launch leaves its stamps
 		{ const char *dbg = getenv("ANNCUR_DEBUG_FLUSH_TILES"); if (dbg) p.flush_tiles = atoi(dbg); }
 		if (getenv("ANNCUR_DEBUG_GEMM_NOSYNC")) {  // MFMA + LDS fragment reads, no staging, no barriers
 			if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 3, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
@@ -1683,10 +1690,12 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 		for (int i = 0; i < 4 && rc == ANNCUR_OK; ++i)
 			if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) { anncur_set_error("hipEventElapsedTime failed"); rc = ANNCUR_E_HIP; }
 		stage_ms[4] = 0.f;
+		stage_ms[6] = stage_ms[7] = stage_ms[8] = 0.f;
 		for (int g = 0; g < P.n_stages && rc == ANNCUR_OK; ++g) {
 			float ms = 0.f;
 			if (hipEventElapsedTime(&ms, ev[5 + 2 * g], ev[6 + 2 * g]) != hipSuccess) { anncur_set_error("hipEventElapsedTime failed"); rc = ANNCUR_E_HIP; }
 			stage_ms[4] += ms;
+			stage_ms[6 + g] = ms;
 		}
 		stage_ms[5] = (float)P.n_stages;
 	}
@@ -1699,6 +1708,23 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 	const FusedPlan P = plan_any(Q, I, Kp, k);
 	ANNCUR_REQUIRE(P.ok && out5, ANNCUR_E_UNSUPPORTED, "score_topk_plan: unsupported shape");
 	out5[0] = P.n_st; out5[1] = P.n_tiles; out5[2] = P.S; out5[3] = P.capg; out5[4] = P.group;
+	return ANNCUR_OK;
+}
+
+/* the same for the flags of anncur_score_topk_ex: out[0 .. n_out) = {sample tiles, item tiles, S, segment capacity, group, segments per
+ * query and item split (2: 32x32x16 sweep, 4: 16x16x32 sweep / wide kernel), 32-query sub-tiles per wave, sweep stages, stage_end[3],
+ * stage uses the exec-mask filter[3], ring drain period[3]} -- what a test needs to see that a variant flag was honoured */
+extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
+	ANNCUR_REQUIRE((flags & ~(ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1)) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
+	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0, (flags & ANNCUR_TOPK_QT1) != 0);
+	ANNCUR_REQUIRE(P.ok && out && n_out >= 0, ANNCUR_E_UNSUPPORTED, "score_topk_plan_ex: unsupported shape");
+	const bool wide = wide_kp(Kp);
+	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
+	for (int g = 0; g < 3; ++g) {
+		const bool on = g < P.n_stages;
+		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? P.stage_pred[g] : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
+	}
+	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
 	return ANNCUR_OK;
 }
 

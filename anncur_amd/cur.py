@@ -40,6 +40,8 @@ def _pinv_host(M):
 
 
 AUTO_COND_LIMIT = 1e3   # pinv_backend "auto": the device result is taken while cond_2(W) stays below this (numpy's fp32 SVD is then good to ~1e-4)
+AUTO_COND_SAFETY = 1.25  # ... times this: the power-iteration estimate of cond_2 is a lower bound
+AUTO_SQUARE_RATIO, AUTO_SQUARE_MIN = 0.9, 32   # "auto": blocks with min(shape) > 0.9 max(shape) (and at least 32 wide) go straight to the host
 
 
 def _pinv(M, device, backend):
@@ -58,8 +60,15 @@ def _pinv(M, device, backend):
 		from .pinv import pinv_newton_schulz_f64
 		if min(M.shape) == 0:
 			return torch.zeros((M.shape[1], M.shape[0]), dtype=torch.float32, device=device)
-		X, info = pinv_newton_schulz_f64(M.to(device), return_info=True)
-		if info["converged"] and (backend == "device" or info["cond_2"] <= AUTO_COND_LIMIT):
+		if backend == "auto" and min(M.shape) >= AUTO_SQUARE_MIN and min(M.shape) > AUTO_SQUARE_RATIO * max(M.shape):
+			# (near-)square anchor block (entry A's n_ment_anchors == n_ent_anchors cells): its smallest singular value is ~1/n of the
+			# largest, cond_2 far above the limit -- the iteration would burn its budget and end on the host anyway
+			LOGGER.info("pinv auto: %d x %d block is (near-)square -> host numpy.linalg.pinv", M.shape[0], M.shape[1])
+			return _pinv_host(M).to(device)
+		# auto: a block with cond_2 <= 1e3 converges within ~2 log2(cond) + 6 = 26 steps; one that has not by 36 is beyond the limit
+		X, info = pinv_newton_schulz_f64(M.to(device), return_info=True, max_iters=36 if backend == "auto" else 64)
+		# cond_2 comes from two 8-step power iterations, each a LOWER bound (a few per cent): judged with a safety factor
+		if info["converged"] and (backend == "device" or AUTO_COND_SAFETY * info["cond_2"] <= AUTO_COND_LIMIT):
 			return X
 		LOGGER.info("pinv %s: cond_2 = %.3g after %d iterations (converged: %s) -> host numpy.linalg.pinv", backend, info["cond_2"], info["iterations"], info["converged"])
 		return _pinv_host(M).to(device)

@@ -21,6 +21,19 @@ from . import ops
 LOGGER = logging.getLogger(__name__)
 
 
+PAD_SCORE = np.float32(np.finfo(np.float32).min)   # -FLT_MAX: the neutral element of FAISS' inner-product result heaps (CMin<float>::neutral())
+
+
+def _faiss_pad(v, i, nq, k, k_eff):
+	"""(D float32 [nq, k], I int64 [nq, k]) NumPy arrays; slots without a result hold (-FLT_MAX, -1) as FAISS leaves them for
+	METRIC_INNER_PRODUCT (the kernels mark them (-inf, -1))."""
+	D = np.full((nq, k), PAD_SCORE, dtype=np.float32)
+	I = np.full((nq, k), -1, dtype=np.int64)
+	I[:, :k_eff] = i.cpu().numpy().astype(np.int64)
+	D[:, :k_eff] = np.where(I[:, :k_eff] >= 0, v.cpu().numpy(), PAD_SCORE)
+	return D, I
+
+
 class FlatIPIndex:
 	"""Exact maximum-inner-product search on the GPU.  fp32 by default (dense fp32-MFMA GEMM + exact scan);
 	dtype="bf16" uses the fused score+top-k kernel when the dimension fits (d <= 512)."""
@@ -56,21 +69,18 @@ class FlatIPIndex:
 			v, i = ops.score_topk_fused(ops.pack_bf16(q, kp), self._Xp, self.ntotal, k_eff, leading_sample=True, item_ids=self._ids)
 		else:
 			v, i = ops.score_topk_dense(q, self._X, k_eff)
-		D = np.full((q.shape[0], k), -np.inf, dtype=np.float32)   # FAISS pads missing results with -inf / -1
-		I = np.full((q.shape[0], k), -1, dtype=np.int64)
-		D[:, :k_eff] = v.cpu().numpy()
-		I[:, :k_eff] = i.cpu().numpy().astype(np.int64)
-		return D, I
+		return _faiss_pad(v, i, q.shape[0], k, k_eff)
 
 
 class IVFFlatIPIndex:
 	"""faiss.IndexIVFFlat(IndexFlatIP(d), d, nlist, METRIC_INNER_PRODUCT) on the GPU: train (k-means coarse quantiser) / add
 	(inverted lists) / search (exact inner products inside the nprobe best lists).  Restated from FAISS' published algorithm and
-	defaults (Clustering: 25 iterations, at most 256 training points per centroid, assignment through the inner-product quantiser,
-	centroid = mean of its points, an empty list re-seeded by splitting a large one); its random draws cannot be reproduced, so
-	parity is unpinned and the index is judged on recall.  Results are deterministic for a given seed."""
+	defaults: IndexIVF trains its coarse quantiser through Level1Quantizer, whose ClusteringParameters carry niter = 10 (the
+	stand-alone Clustering default is 25: pass niter=25 for that), at most 256 training points per centroid, assignment through the
+	inner-product quantiser, centroid = mean of its points, an empty list re-seeded by splitting a large one.  FAISS' random draws
+	cannot be reproduced, so parity is unpinned and the index is judged on recall.  Results are deterministic for a given seed."""
 
-	def __init__(self, d, nlist, device=None, niter=25, seed=1234, max_points_per_centroid=256):
+	def __init__(self, d, nlist, device=None, niter=10, seed=1234, max_points_per_centroid=256):
 		self.d, self.nlist = int(d), int(nlist)
 		self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 		self.niter, self.seed, self.max_points_per_centroid = niter, seed, max_points_per_centroid
@@ -144,11 +154,7 @@ class IVFFlatIPIndex:
 		qp[:, :self.d] = q
 		k_eff = min(k, ops._lib.MAX_TOPK)
 		v, i = ops.ivf_scan(self._Xs, self._offsets, self._ids, qp, probe, k_eff)
-		D = np.full((q.shape[0], k), -np.inf, dtype=np.float32)   # FAISS pads missing results with -inf / -1
-		I = np.full((q.shape[0], k), -1, dtype=np.int64)
-		D[:, :k_eff] = v.cpu().numpy()
-		I[:, :k_eff] = i.cpu().numpy().astype(np.int64)
-		return D, I
+		return _faiss_pad(v, i, q.shape[0], k, k_eff)
 
 
 def build_flat_or_ivff_index(embeds, force_exact_search, probe_mult_factor=1, dtype="fp32", device=None):

@@ -5,10 +5,12 @@
 which converges (quadratically, once the smallest eigenvalue of X_k W leaves 0) to W^+ for ANY W, needs nothing but GEMMs --
 here the fp32-MFMA kernel of the C ABI -- and no host round trip except an occasional 2-float convergence check.
 It is the on-device alternative to the reference's host call ``numpy.linalg.pinv`` (eval/matrix_approx_zeshel.py:47,49; LAPACK
-SVD, rcond 1e-15).  The default backend stays "numpy" because only the same LAPACK call makes U bit-identical to the reference;
-the device backend matters for large anchor counts, where the host SVD dominates the index build (2048 x 1024: 1.4 s on the host,
-a few ms here).  fp32 accuracy ~ cond(W) * 6e-8, like an fp32 SVD; rank-deficient W converges to the true pseudo-inverse, only
-more slowly (singular values below ~1e-4 * sigma_max are effectively truncated by the iteration cap)."""
+SVD, rcond 1e-15).  Two routes live here: the fp64 iteration (pinv_newton_schulz_f64: the exact pseudo-inverse of the fp32 block,
+rounded once -- what cur.py's default backend "auto" runs while the block is well conditioned; only backend "numpy", the same
+LAPACK call as the reference, makes U bit-identical) and round 1's fp32 iteration (pinv_newton_schulz, backend "device32":
+accuracy ~ cond(W) * 6e-8 like an fp32 SVD, singular values below ~1e-4 * sigma_max effectively truncated by the iteration cap).
+The device routes matter for large anchor counts, where the host SVD dominates the index build (2048 x 1024: 1.4 s on the host, a
+few ms here)."""
 import torch
 
 from . import ops

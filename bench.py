@@ -76,23 +76,27 @@ def self_launch(args):
 
 def main():
 	ap = argparse.ArgumentParser()
-	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--gpus", type=int, default=None, help="default: WORLD_SIZE under torchrun, else 1")
 	ap.add_argument("--steps", type=int, default=30)
 	ap.add_argument("--warmup", type=int, default=5)
 	ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg2 on one GPU, cfg4_per_gpu on several")
 	ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-rank path with ranks sharing GPUs")
 	ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses GPU r %% device_count (RCCL cannot; use --backend gloo)")
 	ap.add_argument("--no-k500", action="store_true", help="skip the retrieve_only_k500 side-line (profiling runs: its launches share the sweep kernel's name)")
-	ap.add_argument("--sustained-seconds", type=float, default=2.0, help="also loop the same step for this long and report it (DVFS-settled rate); 0 = skip")
+	ap.add_argument("--sustained-seconds", type=float, default=10.0, help="also loop the same step for this long and report it (DVFS-settled rate); 0 = skip")
 	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
 	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
 	ap.add_argument("--seed", type=int, default=0)
 	ap.add_argument("--no-overlap", action="store_true", help="run the exact scan on the same stream as the retrieval instead of a second one")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if args.gpus is None:
+		args.gpus = world if os.environ.get("RANK") is not None else 1
 	if args.gpus > 1 and os.environ.get("RANK") is None:
 		self_launch(args)
-	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if args.gpus != world:   # before any process group exists: nothing to tear down, no rank left waiting in a collective
+		raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 	if args.config is None:
 		args.config = "cfg2" if world == 1 else "cfg4_per_gpu"
 	cfg = CONFIGS[args.config]
@@ -119,8 +123,9 @@ def main():
 		else:
 			dist.init_process_group("gloo")
 	ranks_seen = torch.distributed.get_world_size() if use_dist else 1
-	if args.gpus != world:
-		raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
+	if os.environ.get("ANNCUR_BENCH_FAIL_RANK") == str(rank):   # fault injection for tests/test_gpu_bench_multirank.py
+		raise RuntimeError(f"[bench] injected failure on rank {rank} (ANNCUR_BENCH_FAIL_RANK)")
 
 	from anncur_amd import _lib, ops
 	from anncur_amd.cur import CURApprox
@@ -272,8 +277,8 @@ def main():
 			t0 = time.perf_counter(); run_steps(args.steps); torch.cuda.synchronize()
 			solo = Q * args.steps / (time.perf_counter() - t0)
 		barrier()
-	# sustained: the same step looped for >= 2 s (the timed region above is a burst of K steps; under a long MFMA load the chip
-	# lowers its clock -- MI355X_MICROARCH.md 'DVFS give-back')
+	# sustained: the same step looped for >= 10 s (the timed region above is a burst of K steps; under a long MFMA load the chip
+	# lowers its clock -- MI355X_MICROARCH.md 'DVFS give-back'; long enough for a 5 s utilisation sampler to see the GPU busy)
 	sustained = None
 	if args.sustained_seconds > 0:
 		barrier()
@@ -293,7 +298,7 @@ def main():
 		sustained = {"value": world * Q / sus_step, "unit": "queries/s", "ms_per_step": 1e3 * sus_step, "seconds": sus_s, "steps": n_sus}
 
 	# ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
-	stage = np.zeros(6)
+	stage = np.zeros(9)
 	Xq = ops.gather_cols(A_test, anc_dev)
 	if Xq.shape[1] != Kp:
 		Xq = ops.pack_bf16(Xq, Kp)
@@ -340,6 +345,7 @@ def main():
 	CURApprox(rows=A_train, cols=ops.gather_cols(A_train, anc_dev), row_idxs=np.arange(cfg["Kq"]), col_idxs=anc,
 			  approx_preference="rows", compute_dtype="bf16", pinv_backend="numpy")
 	torch.cuda.synchronize(); index_build_numpy_s = time.perf_counter() - t0
+	plan_now = ops.fused_plan(Q, I, Kp, kr, leading_sample=True)
 	n_sweep = max(1, int(round(stage[5])))                 # the sweep runs as n_sweep launches of the same kernel (threshold refined in between)
 	sweep_flops = 2.0 * Q * Kp * I / n_sweep               # algorithmic flops per launch (average over the stages)
 	sweep_ms = stage[4] / n_sweep                          # average launch duration of score_kernel<Kp,sweep>
@@ -378,6 +384,9 @@ def main():
 							  "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
 			"stage_ms": {"gather_cols": gath_ms, "prepass": float(stage[0]), "threshold": float(stage[1]), "sweep": float(stage[2]), "sweep_kernels_only": float(stage[4]),
 						 "select": float(stage[3]), "exact_scan": scan_ms},
+			# the sweep launch by launch: tiles swept, duration and MFMA rate of each stage (the first one runs against the prepass threshold)
+			"sweep_stages": [{"tiles": int(t1 - t0), "ms": float(stage[6 + g]), "tflops": 2.0 * Q * Kp * 32.0 * (t1 - t0) / (max(float(stage[6 + g]), 1e-9) * 1e-3) / 1e12}
+							 for g, (t0, t1) in enumerate(zip([0] + plan_now["stage_end"][:-1], plan_now["stage_end"]))],
 			"retrieve_only": {"value": world * Q / (retrieve_ms * 1e-3), "unit": "queries/s", "ms_per_step": retrieve_ms,
 							  "what": "gather C_q + fused S_hat/top-k_retvr only (no exact scan, no overlap), eager launches, this rank x world"},
 			"retrieve_only_k500": ({"value": world * Q / (retrieve500_ms * 1e-3), "unit": "queries/s", "ms_per_step": retrieve500_ms,
@@ -385,7 +394,7 @@ def main():
 			"index_build_s": index_build_s, "index_build_numpy_pinv_s": index_build_numpy_s,
 			"index_build_what": "gather anchor columns + U = pinv(W) + E = U.R + bf16 packs; pinv 'auto' = fp64 Newton-Schulz on the GPU (host LAPACK only for ill-conditioned blocks); numpy = the reference's host call",
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
-			"fused_plan": ops.fused_plan(Q, I, Kp, kr),
+			"fused_plan": plan_now,
 			"launch_mode": "eager" if graphs is None else "hipGraph replay (the step's launches captured once per result slot)",
 			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
 			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),

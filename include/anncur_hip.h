@@ -173,10 +173,11 @@ int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde
                          int32_t flags, const int32_t *item_ids, void *stream);
 
 /* Measurement only: same as anncur_score_topk but records HIP events on `stream` between the four
- * launches, synchronises, and returns their durations in stage_ms[6] (host floats, milliseconds):
+ * launches, synchronises, and returns their durations in stage_ms[9] (host floats, milliseconds):
  * {prepass, threshold, sweep stage (sweep launches + the threshold refinements between them), select,
- *  sum of the sweep-kernel launches alone, number of sweep launches}.  bench.py's live roofline figure is
- *  (2*Q*Kp*I / launches) / (stage_ms[4] / launches). */
+ *  sum of the sweep-kernel launches alone, number of sweep launches, and the duration of each of the up to
+ *  three sweep launches (0 where the plan has fewer stages; anncur_score_topk_plan_ex gives their tile ranges)}.
+ *  bench.py's live roofline figure is (2*Q*Kp*I / launches) / (stage_ms[4] / launches). */
 int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t lde,
                             int64_t Q, int64_t I, int32_t Kp, int32_t k,
                             float *out_val, int32_t *out_idx,
@@ -184,6 +185,11 @@ int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t 
                             int32_t flags, const int32_t *item_ids, void *stream, float *stage_ms);
 /* Plan introspection: out5 = {sample tiles, item tiles, item splits S, segment capacity, group size}. */
 int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t *out5);
+/* The plan a call with `flags` (ANNCUR_TOPK_*) would run: out[0 .. n_out), n_out <= 17 = {sample tiles, item tiles, item splits S,
+ * segment capacity, group size, candidate segments per (query, item split) -- 2: 32x32x16 sweep, 4: 16x16x32 sweep or wide kernel --,
+ * 32-query sub-tiles per wave, number of sweep stages, stage_end[3] (tiles), exec-mask filter per stage[3], ring drain period per
+ * stage[3]}.  Lets a caller (and the parity tests) see that a variant flag was honoured for the shape. */
+int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out);
 
 /* a8: exact re-rank of the approximately retrieved items + a10 overlap counts --------
  *   temp[approx_idx] = exact[approx_idx]; temp.topk(k)      ...crossenc.py:108-113 ; ..._splits.py:93-96

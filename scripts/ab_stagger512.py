@@ -15,7 +15,7 @@ Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), 512)
 Xp = ops.pack_bf16(X, 512)
 del Z, E
 def run(tag):
-	acc = np.zeros(6)
+	acc = np.zeros(9)
 	for i in range(7):
 		(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids)
 		if i >= 2: acc += np.array(ms)

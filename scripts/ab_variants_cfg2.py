@@ -16,7 +16,7 @@ Kp = ops.padded_k(K)
 Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), Kp)
 Xp = ops.pack_bf16(X, Kp)
 def run(tag, **kw):
-	acc = np.zeros(6)
+	acc = np.zeros(9)
 	for i in range(12):
 		(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids, **kw)
 		if i >= 2: acc += np.array(ms)

@@ -16,7 +16,7 @@ E = (torch.randn(K, 64, generator=g, device=dev) @ Z / 8 / 16 + 0.003 * torch.ra
 Kp = ops.padded_k(K)
 Xp = ops.pack_bf16(X, Kp); Etp = ops.pack_bf16(E.t().contiguous(), Kp, row_multiple=32)
 def run(tag):
-	acc = np.zeros(6)
+	acc = np.zeros(9)
 	for i in range(8):
 		(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, I, k)
 		if i >= 2: acc += np.array(ms)

@@ -20,7 +20,7 @@ if a.by_norm:
 	from anncur_amd.cur import _norm_sorted_pack
 	Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), Kp)
 print("plan", ops.fused_plan(a.Q, a.I, Kp, a.k))
-acc = np.zeros(6)
+acc = np.zeros(9)
 for i in range(a.iters + 2):
 	(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, a.I, a.k, leading_sample=bool(a.by_norm), item_ids=ids)
 	if i >= 2: acc += np.array(ms)

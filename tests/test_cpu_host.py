@@ -49,6 +49,23 @@ def test_no_compute_without_gpu_and_plan_queries_work():
 	assert lib.anncur_score_topk_workspace_bytes(1200, 15603, 1024, 100) > 0
 
 
+def test_sweep_variant_flags_reach_the_plan():
+	"""ops.score_topk_fused accepted mfma16= / qt1= and dropped them.  The plan query takes the same flags word the launch
+	does (ops._topk_flags), so a dropped flag shows here without a GPU."""
+	from anncur_amd import _lib, ops
+	assert ops._topk_flags() == 0 and ops._topk_flags(True, True, True) == (_lib.TOPK_LEADING_SAMPLE | _lib.TOPK_MFMA16 | _lib.TOPK_QT1)
+	base = ops.fused_plan(10000, 100000, 256, 100)
+	assert (base["lg"], base["QT"]) == (2, 2) and base["n_stages"] == len(base["stage_end"]) >= 1 and base["stage_end"][-1] == base["n_tiles"]
+	assert ops.fused_plan(10000, 100000, 256, 100, mfma16=True)["lg"] == 4
+	assert ops.fused_plan(300, 40000, 64, 10, mfma16=True)["lg"] == 4 and ops.fused_plan(300, 40000, 64, 10, mfma16=True)["splits"] <= 16
+	assert ops.fused_plan(10000, 100000, 256, 100, qt1=True)["QT"] == 1 and ops.fused_plan(10000, 100000, 128, 100, qt1=True)["QT"] == 1
+	assert ops.fused_plan(10000, 100000, 64, 100, qt1=True)["QT"] == 2       # Kp = 64 has no QT = 1 body
+	assert ops.fused_plan(6250, 1000000, 512, 100, mfma16=True, qt1=True)["lg"] == 2   # Kp = 512: one body whatever the flags
+	import inspect
+	src = inspect.getsource(ops.score_topk_fused.__wrapped__) + inspect.getsource(ops.score_topk_fused_timed.__wrapped__)
+	assert src.count("_topk_flags(leading_sample, mfma16, qt1)") == 2 and "mfma16=mfma16, qt1=qt1" in src
+
+
 def test_product_never_imports_the_oracle():
 	pkg = os.path.join(ROOT, "anncur_amd")
 	offenders = []
@@ -140,6 +157,37 @@ def test_row_sharding_allgather_world2(n_rows, row_idxs):
 	res = [q.get(timeout=120) for _ in procs]
 	for p in procs: p.join(timeout=60)
 	assert sorted(res) == [(0, True), (1, True)]
+
+
+def _anchor_rows_worker(rank, world, port, Kq, n_cols, dtype_name, q):
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from anncur_amd.dist import allgather_anchor_rows, shard_bounds
+	g = torch.Generator().manual_seed(7)
+	full = torch.randn(Kq, n_cols, generator=g).to(getattr(torch, dtype_name))
+	# every rank holds a [Kq x I] buffer of which only ITS share [s, e) is meaningful (bench.py: the rank's own draws); poison the rest
+	mine = torch.full_like(full, float("nan"))
+	s, e = shard_bounds(Kq, rank, world)
+	mine[s:e] = full[s:e]
+	got = allgather_anchor_rows(mine, Kq, rank, world)
+	q.put((rank, tuple(got.shape) == (Kq, n_cols) and got.dtype == full.dtype and torch.equal(got, full)))
+	dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,Kq,dtype_name", [(2, 5, "float32"), (2, 7, "bfloat16"), (3, 8, "bfloat16"), (3, 2, "float32")])
+def test_allgather_anchor_rows_uneven_shares(world, Kq, dtype_name):
+	"""bench.py's one collective (anncur_amd/dist.py::allgather_anchor_rows) when Kq is not a multiple of the world size: padded
+	all-gather, ranks in order, shares of different length (one of them empty for Kq < world), bf16 rows travelling as bytes over gloo."""
+	import torch.multiprocessing as mp
+	ctx = mp.get_context("spawn")
+	q = ctx.Queue()
+	port = 29100 + (os.getpid() % 300) + 7 * world + Kq
+	procs = [ctx.Process(target=_anchor_rows_worker, args=(r, world, port, Kq, 33, dtype_name, q)) for r in range(world)]
+	for p in procs: p.start()
+	res = [q.get(timeout=120) for _ in procs]
+	for p in procs: p.join(timeout=60)
+	assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def test_shard_bounds_and_split():

@@ -1,0 +1,54 @@
+"""The multi-rank path of bench.py (self-launch -> torch.distributed.run -> N ranks -> anchor-row all-gather -> timed steps -> rank 0's
+JSON line) under test, so that the driver's one multi-GPU run cannot die on plumbing.  Two ranks share the box's single GPU over the
+gloo backend (RCCL needs one GPU per rank: RCCL with N > 1 stays unmeasured on the builder's side)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--gpus", "2", "--backend", "gloo", "--share-gpu", "--config", "small", "--steps", "3", "--warmup", "1", "--sustained-seconds", "0",
+		"--cpu-sample-queries", "0", "--no-k500"]
+
+
+def _run(extra_env=None, args=ARGS, timeout=600):
+	if not torch.cuda.is_available():
+		pytest.skip("no GPU")
+	env = dict(os.environ)
+	for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+		env.pop(v, None)
+	env.update(extra_env or {})
+	return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_two_ranks_self_launch_prints_one_json_line():
+	p = _run()
+	assert p.returncode == 0, p.stderr[-3000:]
+	lines = [l for l in p.stdout.splitlines() if l.strip()]
+	assert len(lines) == 1, p.stdout[-2000:]          # stdout carries exactly one line: the result
+	out = json.loads(lines[0])
+	assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+	assert out["scaling"] == "weak" and out["unit"] == "queries/s" and out["backend"] == "gloo"
+	assert out["allgather_ms"] is not None and out["allgather_ms"] > 0
+	assert out["solo_rank0"] is not None and out["solo_rank0"]["value"] > 0
+	assert out["value"] == pytest.approx(2 * 2000 * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)   # whole-job rate: both ranks' queries / max time
+	assert 0.0 <= out["recall"]["recall@10"] <= 1.0 and out["roofline"]["achieved"] > 0
+	assert "cpu_baseline" not in out                 # the CPU leg runs at N = 1 only
+
+
+def test_bench_fails_loudly_when_a_rank_raises():
+	p = _run({"ANNCUR_BENCH_FAIL_RANK": "1"})
+	assert p.returncode != 0
+	assert not [l for l in p.stdout.splitlines() if l.startswith("{")]   # no result line from a broken job
+
+
+def test_bench_rejects_a_world_size_mismatch_before_any_collective():
+	if not torch.cuda.is_available():
+		pytest.skip("no GPU")
+	env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+	p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+	assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)

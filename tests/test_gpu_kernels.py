@@ -180,6 +180,11 @@ def test_fused_mfma16_sweep_gives_the_same_topk(ops, Q, I, K, k):
 	"""The 16x16x32 sweep (ANNCUR_TOPK_MFMA16, score16.hpp): other lane <-> (query, item) map, four segments per query and split,
 	one shared ring per lane.  Same products, same fp32 sums per output element -> values bit for bit, sets identical."""
 	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
+	Kp = Xp.shape[1]
+	# the flags must reach the plan (round 2 dropped them in ops.py and this test compared the default kernel with itself)
+	assert ops.fused_plan(Q, I, Kp, k)["lg"] == 2 and ops.fused_plan(Q, I, Kp, k)["QT"] == 2
+	assert ops.fused_plan(Q, I, Kp, k, mfma16=True)["lg"] == 4
+	assert ops.fused_plan(Q, I, Kp, k, qt1=True)["QT"] == (1 if Kp >= 128 else 2)
 	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
 	(v16, i16), nfb16 = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma16=True)
 	torch.cuda.synchronize()
@@ -202,6 +207,7 @@ def test_fused_mfma16_overflow_and_ring_wrap_are_repaired_exactly(ops):
 	E[:, 30000:36000] += 1.0
 	E = E.bfloat16()
 	Xp = ops.pack_bf16(X.cuda(), 128); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 128, row_multiple=32)
+	assert ops.fused_plan(Q, I, 128, k, mfma16=True)["lg"] == 4
 	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma16=True)
 	torch.cuda.synchronize()
 	S = X.double() @ E.double()
@@ -226,6 +232,8 @@ def test_fused_regression_dense_first_stage_found_by_fuzzing(ops):
 	S = X.double() @ E.double()
 	rv, ri = torch.topk(S, k, dim=1)
 	for kw in ({}, {"mfma16": True}, {"qt1": True}):
+		plan = ops.fused_plan(Q, I, Kp, k, **kw)
+		assert (plan["lg"], plan["QT"]) == {(): (2, 2), ("mfma16",): (4, 2), ("qt1",): (2, 1)}[tuple(kw)], (kw, plan)
 		v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)
 		assert (v.cpu().double() - rv).abs().max() <= 1e-4 * float(S.abs().max())
 		assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(i.cpu(), ri)), kw

@@ -47,6 +47,8 @@ SIGNATURES = {
 								  c_void_p, c_size_t, c_void_p]),
 	"anncur_score_topk_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
 									 c_void_p, c_size_t, c_int32, c_void_p, c_void_p]),
+	"anncur_eval_topk": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32,
+								 c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_score_topk_timed": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
 										c_void_p, c_size_t, c_int32, c_void_p, c_void_p, POINTER(ctypes.c_float)]),
 	"anncur_score_topk_plan": (c_int, [c_int64, c_int64, c_int32, c_int32, _p32]),

@@ -16,6 +16,9 @@ int anncur_internal_approx_error_acc(const void *X, int x_dtype, int64_t ldx, co
 // misc.hip: per-device caches (one process may drive several GPUs)
 int anncur_ensure_dyn_lds(const void *fn, int bytes);  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (function, device)
 int anncur_num_cu();                                   // CU count of the current device
+int anncur_event_pool(hipEvent_t **out, int n);        // n (<= 16) cached timing-less events of the current device
+// topk.hip: rows the one-wave-per-row exact scan keeps in flight on the whole chip (occupancy x CUs x 4 rows per workgroup)
+int anncur_internal_scan_rows_in_flight(int dtype);
 
 #define ANNCUR_REQUIRE(cond, code, ...)                 \
 	do {                                                \

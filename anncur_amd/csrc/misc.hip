@@ -51,7 +51,26 @@ int anncur_num_cu() {
 	return g_cu[dev];
 }
 
-extern "C" int anncur_version(void) { return 1000 * 0 + 1; }
+// A small pool of timing-less events per (host thread, device) for the fork / join edges of anncur_eval_topk: created once, reused
+// by every call of the thread (a recorded event may be re-recorded as soon as the wait that reads it has been enqueued).
+namespace {
+constexpr int EVENT_POOL = 16;
+thread_local hipEvent_t tl_events[64][EVENT_POOL];
+thread_local bool tl_events_ready[64] = {false};
+}
+int anncur_event_pool(hipEvent_t **out, int n) {
+	int dev = 0;
+	ANNCUR_HIP_OK(hipGetDevice(&dev));
+	ANNCUR_REQUIRE(dev >= 0 && dev < 64 && n <= EVENT_POOL, ANNCUR_E_INVALID, "event_pool: bad device / count");
+	if (!tl_events_ready[dev]) {
+		for (int i = 0; i < EVENT_POOL; ++i) ANNCUR_HIP_OK(hipEventCreateWithFlags(&tl_events[dev][i], hipEventDisableTiming));
+		tl_events_ready[dev] = true;
+	}
+	*out = tl_events[dev];
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_version(void) { return 1000 * 0 + 3; }
 
 extern "C" const char *anncur_last_error(void) { return g_err; }
 

@@ -55,6 +55,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vector: stays in VGPRs (HIP's uint4 struct did not)
 
 constexpr int TILE_I = 32;
+constexpr int CHUNK_TILES = 4;   // dynamic tile schedule: tiles per ticket
+constexpr int FLUSH_AT = 3;      // staggered sweep: the rings (8 slots per lane and sub-tile) are drained as soon as one holds this many entries
 
 template <int KP, int QTV = ((KP <= 256) ? 2 : 1)>
 struct FusedCfg {
@@ -67,7 +69,9 @@ struct FusedCfg {
 	static constexpr int QDEPTH = 8;                 // lane-private LDS hit queue: entries per (lane, sub-tile)
 	static constexpr int QUEUE_BYTES = QT * QDEPTH * 256 * 8;
 	static constexpr int QUEUE_OFF = (2 * TILE_BYTES + 16383) / 16384 * 16384;  // rings are 16 KiB aligned (filter_one)
-	static constexpr int LDS_BYTES = QUEUE_OFF + QUEUE_BYTES;         // the prepass kernel uses only the tile part
+	static constexpr int TICKET_OFF = QUEUE_OFF + QUEUE_BYTES;        // two 32-bit words: the chunk tickets thread 0 hands to its workgroup (dynamic tile schedule)
+	static constexpr int LDS_BYTES = TICKET_OFF + 16;                 // the prepass kernel uses only the tile part
+	static constexpr int NAOFF = KSTEPS < 8 ? KSTEPS : 8;             // fragment address registers of the staggered sweep (see stagger_tile)
 };
 
 template <int CPR>
@@ -96,6 +100,11 @@ struct FusedParams {
 	int debug_stamp;                  // timing experiments only: this launch writes the in-kernel clock stamps
 	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
 	int n_wg;                         // grid size (for the XCD remap)
+	// dynamic tile schedule of a sweep stage (chunk_tiles > 0): the workgroups of a query row block draw chunks of `chunk_tiles` consecutive
+	// tiles from the row block's ticket counter instead of sweeping a fixed share -- see score_kernel
+	int chunk_tiles, n_chunks;
+	uint32_t *chunk_ctr;              // [n row blocks], zero at launch
+	uint8_t *chunk_owner;             // [n row blocks x n_chunks]: which item split swept the chunk (the repair path's map)
 };
 
 // Contiguous work ids per XCD (blocks b and b+8 share an XCD's L2): speed only, never correctness.
@@ -125,6 +134,34 @@ __device__ __forceinline__ void tile_dma(const uint16_t *__restrict__ Et, int ti
 	}
 }
 
+// The same DMA for the staggered sweep, hand-placed: hipcc kept the four per-lane source offsets as 64-bit pairs plus four VGPRs of LDS
+// destinations that it then moved to M0 through v_readfirstlane (12 VGPRs and ~20 vector instructions per tile and wave in a kernel
+// that sits at the 256-register limit).  Here: one 32-bit offset register per piece (computed once), the tile's base in SGPRs
+// (saddr form), M0 from a scalar.  voff[i] = byte offset of this lane's 16 bytes of piece i inside a tile (swizzle on the source).
+template <int KP>
+__device__ __forceinline__ void tile_dma_offsets(uint32_t (&voff)[FusedCfg<KP>::TILE_BYTES / 4096], int wave_u, int lane) {
+	constexpr int CPR = FusedCfg<KP>::CPR, PER_WAVE = FusedCfg<KP>::TILE_BYTES / 4096;
+#pragma unroll
+	for (int i = 0; i < PER_WAVE; ++i) {
+		const int pch = (wave_u * PER_WAVE + i) * 64 + lane;
+		const int row = pch / CPR, cs = pch % CPR;
+		voff[i] = (uint32_t)(row * CPR + swz<CPR>(row, cs)) * 16u;
+	}
+}
+template <int KP>
+__device__ __forceinline__ void tile_dma_s(const uint16_t *__restrict__ Et, int tile, uint32_t lds_buf, int wave_u,
+											const uint32_t (&voff)[FusedCfg<KP>::TILE_BYTES / 4096]) {
+	constexpr int PER_WAVE = FusedCfg<KP>::TILE_BYTES / 4096;
+	const unsigned char *src = reinterpret_cast<const unsigned char *>(Et) + (int64_t)tile * FusedCfg<KP>::TILE_BYTES;  // (uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+	for (int i = 0; i < PER_WAVE; ++i) {
+		const uint32_t m0v = lds_buf + (uint32_t)(wave_u * PER_WAVE + i) * 1024u;  // (uniform) LDS destination of the piece: M0 + lane * 16
+		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff[i]), "s"(src) : "memory", "m0");
+	}
+#endif
+}
+
 // Threshold filter of one 32x32 accumulator tile: lane = query, register e = item row (e & 3) + 8 (e >> 2) (+ 4 h in item0).
 // Survivors go to the lane's private LDS queue (slot i of lane tid at lq[i * 256]: conflict-free, no atomics); the queues
 // are drained to the lane's HBM candidate segment by flush_queue() every FLUSH_TILES tiles with ONE store instruction per
@@ -150,6 +187,33 @@ __device__ __forceinline__ uint2 lds_load_u64(uint32_t addr) {
 	return make_uint2((uint32_t)d, (uint32_t)(d >> 32));
 }
 
+__device__ __forceinline__ void lds_store_u32(uint32_t addr, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ uint32_t lds_load_u32_uniform(uint32_t addr) {  // every lane reads the same word; returned as a scalar
+	uint32_t d = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d) : "v"(addr) : "memory");
+#endif
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+}
+// Ticket draw of the dynamic tile schedule: a RETURNING atomic add whose result is not waited for where it is issued.  (Written with
+// atomicAdd() hipcc's atomic optimiser turns the one-lane add into a wave-aggregated one and waits vmcnt(0) for it on the spot --
+// directly behind the next tile's DMA.)  The destination is in flight after the asm statement, like the fragment ring's registers:
+// ticket_wait() is the wait, and takes the register as an in/out operand so that nothing that reads it can be scheduled above it.
+__device__ __forceinline__ void ticket_draw(uint32_t &ticket, uint32_t *ctr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t one = 1u;
+	asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr), "v"(one) : "memory");
+#endif
+}
+__device__ __forceinline__ void ticket_wait(uint32_t &ticket) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket)::"memory");
+#endif
+}
 // Two dwords from two separate VGPRs (no 64-bit register pair has to be assembled in the hit path).
 __device__ __forceinline__ void lds_store_2x32(uint32_t addr, uint32_t lo, uint32_t hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -296,24 +360,30 @@ __device__ __forceinline__ void lds_wait_frag(u32x4 &frag, int pending) {  // `p
 //   steps K..2K-1  : acc1 (sub-tile 1 of this tile)  ||  filter of accA
 // The A fragments (same K fragments for both halves) stream through one ring of AR registers, AR-1 steps ahead, without a
 // break between the halves.  CUR = tile buffer parity (compile-time: an immediate offset of the LDS reads).
+// Fragment address of k-step s (tile buffer 0): row r, chunk (2 s + h) ^ f(r).  For Kp = 256 (32 chunks per row, f(r) = r & 15) the XOR
+// leaves bit 4 of the chunk alone, so k-steps s and s + 8 are 256 bytes apart: eight address registers plus an immediate offset serve
+// the sixteen k-steps (the eight registers this saves are what the dynamic tile schedule's ticket lives in).
 template <int KP, int CUR, bool PRED, bool INL = false>
-__device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>::KSTEPS], const bf16x8 (&xb)[2][FusedCfg<KP>::KSTEPS],
+__device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>::NAOFF], const bf16x8 (&xb)[2][FusedCfg<KP>::KSTEPS],
 											  f32x16 &acc1, float tau0, float tau1_prev, uint32_t item0, uint32_t item0_prev,
 											  uint32_t lq0, uint32_t lq1, uint32_t &q0, uint32_t &q1, bool dense) {
 	using Cfg = FusedCfg<KP>;
 	constexpr int K = Cfg::KSTEPS, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;  // ring slots / prefetch distance in k-steps
+	constexpr int NA = Cfg::NAOFF;
 	constexpr int EPS = 16 / K > 0 ? 16 / K : 1;  // filter elements per k-step (Kp = 64: 4, 128: 2, 256: 1)
 	static_assert(K <= 16 && 2 * K >= DIST && AR >= DIST + 2, "staggered path: 2..16 k-steps; a slot is rewritten two MFMAs after its use");
+	static_assert(K <= NA || Cfg::CPR == 32, "k-steps beyond the address registers: + 256 bytes needs 32 chunks per row");
 	u32x4 ring[AR];
+#define ST_READ(slot, s) lds_read_frag_at(ring[slot], aoff[((s) % K) % NA], OFF + (((s) % K) / NA) * 256)
 #pragma unroll
-	for (int i = 0; i < DIST; ++i) lds_read_frag<OFF>(ring[i], aoff[i % K]);
+	for (int i = 0; i < DIST; ++i) ST_READ(i, i);
 	f32x16 accA = {0}, accB = {0};
 #pragma unroll
 	for (int g = 0; g < 2 * K; ++g) {
 		// the slot the new fragment lands in was consumed by the MFMA of step g-2: the asynchronous LDS return can never meet
 		// an MFMA that is still reading its operands
 		const int nxt = g + DIST;
-		if (nxt < 2 * K) lds_read_frag<OFF>(ring[nxt % AR], aoff[nxt % K]);
+		if (nxt < 2 * K) ST_READ(nxt % AR, nxt);
 #if defined(__HIP_DEVICE_COMPILE__)
 		// (keeps the register allocator from handing that read the registers of the fragment the PREVIOUS MFMA was given)
 		if (g >= 1) asm volatile("" ::"v"(ring[(g - 1) % AR]));
@@ -336,6 +406,7 @@ __device__ __forceinline__ void stagger_tile(const uint32_t (&aoff)[FusedCfg<KP>
 				filter_one<Cfg::QDEPTH, PRED, INL>(accA[e], e, tau0, item0, lq0, q0);
 		}
 	}
+#undef ST_READ
 	if (dense) mark_wrapped_raw<Cfg::QDEPTH>(accA, lq0, q0);  // (uniform) this tile's sub-tile 0 is filtered
 	acc1 = accB;
 }
@@ -462,7 +533,46 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	if (MODE == 1 && (lds_addr(smem) & 0x3fffu) != 0u) __builtin_trap();  // filter_one() ORs the slot offset into the address
 
 	uint32_t last_item0 = 0;  // first item (+ 4 h) of the last tile filtered: what a raw ring holds at the final flush
-	if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
+	// ---- tile schedule of the staggered sweep (wave-uniform scalars).  Static: tiles j_begin, j_begin + ts, ... below j_end.
+	// Dynamic (p.chunk_tiles > 0): the workgroups of a query row block draw chunks of p.chunk_tiles consecutive tiles from the row
+	// block's ticket counter, one chunk ahead of the one they sweep.  Why: the 480 workgroups of a cfg2 stage do not run at one speed --
+	// in-kernel stamps (round 2) put the ends of their tile loops between 193 and 271 us (median 234) for equal shares: 32 CUs hold one
+	// workgroup instead of two, the others differ by XCD / CU placement -- and a launch lasts as long as its slowest workgroup.  With tickets
+	// a fast workgroup simply sweeps more chunks.  Any assignment is exact: a workgroup's survivors go to its own segments whatever tiles
+	// it swept; the repair path finds a split's tiles in p.chunk_owner.  Thread 0 draws a ticket when the workgroup starts the chunk
+	// BEFORE the one the ticket is for (atomic in flight during a whole tile), hands it over through LDS at that tile's barrier.
+	int t_cur = j_begin < j_end ? j_begin : -1, t_cend = j_end, t_step = ts, t_next_chunk = -1, t_prev = -1;
+	bool ticket_pending = false;
+	const bool dyn = MODE == 1 && QT == 2 && p.chunk_tiles > 0;
+	// two LDS words used in turn: a ticket is published at the end of one step and read at the head of the next, and nothing but program
+	// order separates that read from the NEXT publication (possible one step later when a chunk is a single tile)
+	uint32_t ticket_slot = lds_addr(smem + Cfg::TICKET_OFF);
+	if constexpr (MODE == 1 && QT == 2) {
+		if (dyn) {
+			if (tid == 0) {
+				const uint32_t c = atomicAdd(p.chunk_ctr + rb, 2u);   // the first chunk and the look-ahead
+				if (p.chunk_owner) {
+					if (c < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c] = (uint8_t)split;
+					if (c + 1 < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c + 1] = (uint8_t)split;
+				}
+				lds_store_u32(ticket_slot, c);
+				__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the word is in LDS before this wave reaches the barrier
+			}
+			__syncthreads();
+			const uint32_t c = lds_load_u32_uniform(ticket_slot);
+			t_step = 1;
+			t_cur = c < (uint32_t)p.n_chunks ? p.tile_begin + (int)c * p.chunk_tiles : -1;
+			t_cend = min(t_cur + p.chunk_tiles, p.tile_end);
+			t_next_chunk = c + 1 < (uint32_t)p.n_chunks ? p.tile_begin + (int)(c + 1) * p.chunk_tiles : -1;
+		}
+	}
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);             // (the compiler does not know tid >> 6 is wave-uniform)
+	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
+	uint32_t dma_off[(MODE == 1 && QT == 2) ? Cfg::TILE_BYTES / 4096 : 1];
+	if constexpr (MODE == 1 && QT == 2) {
+		tile_dma_offsets<KP>(dma_off, wave_u, lane);
+		if (t_cur >= 0) tile_dma_s<KP>(p.Et, t_cur, lds_base, wave_u, dma_off);
+	} else if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
 	ANNCUR_PAD_HERE();
@@ -484,36 +594,61 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #pragma unroll
 		for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
 		float tau1_prev = INFINITY;  // no previous tile yet: the filter of acc1 never fires
-		uint32_t item0_prev = 0;
+		uint32_t item0_prev = 0, item0_pp = 0;   // first item (+ 4 h) of the previous tile and of the one before it
 		const uint32_t lq1 = lq0 + Cfg::QDEPTH * 2048;
-		uint32_t aoff[KSTEPS];       // LDS byte address of this lane's A fragment of k-step s in tile buffer 0
+		uint32_t aoff[Cfg::NAOFF];   // LDS byte address of this lane's A fragment of k-step s (< NAOFF) in tile buffer 0
 #pragma unroll
-		for (int s = 0; s < KSTEPS; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
+		for (int s = 0; s < Cfg::NAOFF; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
 		int flush_in2 = p.flush_tiles;
 		// stagger_tile() counts LDS reads with lgkmcnt(n): no scalar load of the prologue may still be in flight (scalar loads share
 		// the counter and return out of order)
 		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-#define STAGGER_STEP(CUR, J)                                                                                                    \
+#define STAGGER_STEP(CUR)                                                                                                       \
 		do {                                                                                                                    \
-			if ((J) + ts < j_end) tile_dma<KP>(p.Et, (J) + ts, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);               \
-			if ((J) - ts < dense_end || --flush_in2 <= 0) {                                                                     \
+			const int J = t_cur;                                                                                                \
+			if (ticket_pending) {  /* (uniform) the ticket thread 0 drew during the previous step */                            \
+				const uint32_t c = lds_load_u32_uniform(ticket_slot);                                                           \
+				t_next_chunk = c < (uint32_t)p.n_chunks ? p.tile_begin + (int)c * p.chunk_tiles : -1;                           \
+				ticket_pending = false;                                                                                         \
+				ticket_slot ^= 4u;  /* (TICKET_OFF is 16-byte aligned) */                                                       \
+			}                                                                                                                   \
+			int nx = J + t_step;                                                                                                \
+			bool crossed = false;  /* (uniform) the next tile opens the look-ahead chunk: draw the ticket of the one after it */ \
+			if (nx >= t_cend) { nx = t_next_chunk; crossed = dyn && nx >= 0; }                                                  \
+			if (nx >= 0) tile_dma_s<KP>(p.Et, nx, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);                   \
+			uint32_t ticket = 0;                                                                                                \
+			if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);  /* in flight until ticket_wait() below */          \
+			/* drain when the previous tile was a dense one, when the window is up, or when some lane's ring is filling (FLUSH_AT entries or a  \
+			   raw tile): the rings are drained by what they hold, not by what the plan expected them to hold */                \
+			if (t_prev < dense_end || --flush_in2 <= 0 || __ballot((qcnt[0] | qcnt[1]) >= ((uint32_t)FLUSH_AT << 11)) != 0ull) { \
 				flush_in2 = p.flush_tiles;                                                                                      \
 				/* (a raw ring holds one tile: sub-tile 0 of the previous tile, sub-tile 1 of the one before) */                \
 				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev);    \
-				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - (uint32_t)ts * TILE_I); \
+				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_pp); \
 			}                                                                                                                   \
-			const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * h;                                                              \
-			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], (J) < dense_end || every_tile); \
-			tau1_prev = tau[1]; item0_prev = item0;                                                                             \
-			__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
+			const uint32_t item0 = (uint32_t)J * TILE_I + 4 * h;                                                                \
+			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], J < dense_end || every_tile); \
+			tau1_prev = tau[1]; item0_pp = item0_prev; item0_prev = item0;                                                      \
+			ticket_wait(ticket);  /* vmcnt(0): the DMA of the next tile, the queue stores issued with it and the ticket have landed */ \
+			if (crossed) {                                                                                                      \
+				if (tid == 0) {                                                                                                 \
+					lds_store_u32(ticket_slot, ticket);                                                                         \
+					if (p.chunk_owner && ticket < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + ticket] = (uint8_t)split; \
+					__builtin_amdgcn_s_waitcnt(0xC07F);                                                                         \
+				}                                                                                                               \
+				ticket_pending = true;                                                                                          \
+				t_cend = min(nx + p.chunk_tiles, p.tile_end);                                                                   \
+			}                                                                                                                   \
 			__syncthreads();                                                                                                    \
+			t_prev = J; t_cur = nx;                                                                                             \
 		} while (0)
-		for (int j = j_begin; j < j_end; j += 2 * ts) {
-			STAGGER_STEP(0, j);
-			if (j + ts < j_end) STAGGER_STEP(1, j + ts);
+		while (t_cur >= 0) {
+			STAGGER_STEP(0);
+			if (t_cur < 0) break;
+			STAGGER_STEP(1);
 		}
 #undef STAGGER_STEP
-		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_prev - (uint32_t)ts * TILE_I);  // keep one tile's hits per queue window
+		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_pp);  // keep one tile's hits per queue window
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
@@ -797,8 +932,12 @@ __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, cons
 // ------------------------------------------------------------------ select
 // Item-tile ranges of the sweep stages (which tiles item split s swept in stage g): [begin[g] + s*tps[g], + tps[g]) below end[g].
 // stride > 1: interleaved instead (split s swept begin[g] + s, + stride, ... below end[g]).
+// chunk > 0: dynamic schedule -- stage g's tiles were swept in chunks of `chunk` tiles, chunk c of query row block rb by the item
+// split owner[g][rb * n_chunks[g] + c] (row block = q / bq).
 struct SweepStages {
 	int n, begin[3], end[3], tps[3], stride;
+	int chunk, bq, n_chunks[3];
+	const uint8_t *owner[3];
 };
 
 // One workgroup per query: exact top-k of the query's candidate segments.  A segment that overflowed (or whose LDS ring
@@ -882,6 +1021,24 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 		for (int sp = 0; sp < S; ++sp) {
 			if (!((bad[sp >> 5] >> (sp & 31)) & 1u)) continue;  // uniform
 			for (int g = 0; g < stg.n; ++g) {
+				if (stg.chunk > 0) {  // (uniform) dynamic schedule: the chunks of this query's row block that split sp drew
+					const uint8_t *own = stg.owner[g] + (q / stg.bq) * (int64_t)stg.n_chunks[g];
+					int it = 0;
+					for (int c = 0; c < stg.n_chunks[g]; ++c) {
+						if (own[c] != (uint8_t)sp) continue;  // (uniform: every thread reads the same byte)
+						const int64_t i_beg = (int64_t)(stg.begin[g] + c * stg.chunk) * TILE_I;
+						const int64_t i_end = (int64_t)min(stg.begin[g] + (c + 1) * stg.chunk, stg.end[g]) * TILE_I;
+						for (int64_t i0 = i_beg; i0 < i_end; i0 += SEL_THREADS, ++it) {
+							const int64_t i = i0 + tid;
+							const bool in = i < i_end && i < I;
+							const float v = in ? score_of(i) : 0.f;
+							sel_offer(s, in, v, (uint32_t)i, tau, tau_key);
+							if ((it & 15) == 15) sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+						}
+					}
+					sel_maybe_compact<KMAX>(s, k, tau, tau_key);
+					continue;
+				}
 				if (stg.stride > 1) {  // (uniform) interleaved splits: tiles begin + sp, + stride, ...; 8 tiles (256 items) per pass
 					int it = 0;
 					for (int tb = stg.begin[g] + sp; tb < stg.end[g]; tb += 8 * stg.stride, ++it) {
@@ -1071,7 +1228,8 @@ struct FusedPlan {
 	int n_stages, stage_end[3], stage_tps[3], stage_flush[3], stage_pred[3];
 	int leading;
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves) or 4 (16x16x32 sweep: lane groups)
-	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, total;
+	int chunk;  // dynamic tile schedule of the sweep stages: tiles per ticket (0: static shares)
+	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, off_ctr, off_owner, total;
 };
 
 int num_cu() { return anncur_num_cu(); }
@@ -1169,9 +1327,17 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_ONE_WG")) slots = num_cu();  // one sweep workgroup per CU (co-residence experiment)
 #endif
-	int S = slots / P.n_rb;
+	// Dynamic tile schedule (staggered 32x32x16 sweep, Kp <= 256): tickets of CHUNK_TILES tiles per query row block instead of fixed shares
+	// (score_kernel).  Workgroups per row block: enough to fill every slot (rounded UP -- a workgroup that finds no ticket left ends at
+	// once), at most 32 so that the 2 S segments of a query fit the wave-level select.
+	P.chunk = (P.QT == 2 && !mfma16) ? CHUNK_TILES : 0;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = (P.QT == 2 && !mfma16) ? atoi(dbg) : 0;
+#endif
+	int S = P.chunk > 0 ? (slots + P.n_rb - 1) / P.n_rb : slots / P.n_rb;
+	if (P.chunk > 0 && k <= WQ_K2 && S > WAVE / 2) S = WAVE / 2;
 	if (S < 1) S = 1;
-	if (S > 256) S = 256;
+	if (S > 255) S = P.chunk > 0 ? 255 : (S > 256 ? 256 : S);   // (the owner map holds a split in a byte, 255 = none)
 	// ANNCUR_TOPK_MFMA16 with few query rows: its four segments per split must fit the wave-level select (4 S <= 64), so the item
 	// axis is split at most 16 ways -- the flag is honoured for every shape (fewer workgroups than slots when Q < ~8000: an A/B
 	// variant, not the default)
@@ -1212,12 +1378,14 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
+	P.off_ctr = off;    off = align256(off + (size_t)P.n_rb * 3 * 4);   // ticket counters [stage][row block]: zeroed with the header, one memset
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
 	P.off_tval = off;   off = align256(off + (size_t)Q * k * 4);
 	P.off_tidx = off;   off = align256(off + (size_t)Q * k * 4);
 	P.off_segcnt = off; off = align256(off + (size_t)Q * P.lg * P.S * 4);
 	P.off_tau = off;    off = align256(off + (size_t)Q * 4);
 	P.off_hard = off;   off = align256(off + (size_t)Q * 4);
+	P.off_owner = off;  off = align256(off + (size_t)3 * P.n_rb * (size_t)(P.n_tiles / (P.chunk > 0 ? P.chunk : P.n_tiles) + 2));   // chunk owners
 	P.off_cand = off;   off = align256(off + (size_t)Q * P.lg * P.S * (size_t)P.capg * 8);
 	P.total = off;
 	P.ok = true;
@@ -1341,9 +1509,74 @@ int launch_threshold(const FusedPlan &P, const float *gmax, int64_t Q, int k, un
 unsigned long long *g_stamps = nullptr;  // diagnostic build: the last sweep launch's per-workgroup {cycles, 100 MHz ticks}
 #endif
 
+// ------------------------------------------------------------------ a8: the exact scan co-scheduled with the retrieval (anncur_eval_topk)
+// The retrieval is a chain of MFMA-bound sweep launches with latency-bound launches in between (threshold, refinement, select): one
+// wave per query on a few KB each, most of the chip idle.  The exact top-k scan of A is HBM-bound and independent of all of them.
+// Both kinds want every CU to themselves (the sweep fills the register file and the LDS; a scan that arrives first occupies the CUs
+// the sweep is waiting for), so they are not left to race on two streams: the scan is cut into row chunks, and chunk i is launched on
+// the auxiliary stream exactly beside the i-th latency-bound launch -- fork after the launch in front of it, join before the next
+// sweep -- where it finds the chip free and hides that launch.  Chunks are whole rounds of the scan (rows in flight on the chip) so
+// that none ends on a mostly empty round; the last takes the remainder.
+struct CoScan {
+	hipStream_t aux;
+	hipEvent_t *ev;            // [2 * slots]: fork / join pairs
+	const void *A; int a_dtype; int64_t lda, Q, I; int32_t k;
+	float *val; int32_t *idx;
+	int slots, next;           // chunks planned / launched so far
+	int64_t row_end[8];        // chunk i = rows [row_end[i-1], row_end[i])
+};
+
+int co_plan(CoScan &co, int slots) {
+	if (slots > 8) slots = 8;
+	if (slots < 1) slots = 1;
+	const int64_t round = anncur_internal_scan_rows_in_flight(co.a_dtype);
+	const int64_t rounds = co.Q / round;                      // whole rounds available
+	int64_t per = rounds / slots;                             // whole rounds per chunk (the last chunk takes what is left)
+	if (per < 1) {                                            // fewer rounds than slots: one round per chunk while they last
+		per = 1;
+		slots = rounds >= 1 ? (int)rounds : 1;
+	}
+	int64_t r = 0;
+	for (int i = 0; i < slots; ++i) { r = (i == slots - 1) ? co.Q : r + per * round; co.row_end[i] = r < co.Q ? r : co.Q; }
+	co.slots = slots;
+	co.next = 0;
+	return anncur_event_pool(&co.ev, 2 * slots);
+}
+// launch the next chunk on the auxiliary stream behind everything enqueued on `st` so far
+int co_fork(CoScan *co, hipStream_t st) {
+	if (!co || co->next >= co->slots) return ANNCUR_OK;
+	const int i = co->next++;
+	const int64_t r0 = i ? co->row_end[i - 1] : 0, r1 = co->row_end[i];
+	if (r1 <= r0) return ANNCUR_OK;
+	ANNCUR_HIP_OK(hipEventRecord(co->ev[2 * i], st));
+	ANNCUR_HIP_OK(hipStreamWaitEvent(co->aux, co->ev[2 * i], 0));
+	const char *a = (const char *)co->A + (size_t)r0 * (size_t)co->lda * dtype_size(co->a_dtype);
+	const int rc = anncur_rowwise_topk(a, co->a_dtype, r1 - r0, co->I, co->lda, co->k, co->val + r0 * co->k, co->idx + r0 * co->k, co->aux);
+	if (rc != ANNCUR_OK) return rc;
+	ANNCUR_HIP_OK(hipEventRecord(co->ev[2 * i + 1], co->aux));
+	return ANNCUR_OK;
+}
+// `st` waits for the chunks launched so far
+int co_join(CoScan *co, hipStream_t st) {
+	if (!co || co->next < 1) return ANNCUR_OK;
+	const int i = co->next - 1;
+	if (co->row_end[i] > (i ? co->row_end[i - 1] : 0)) ANNCUR_HIP_OK(hipStreamWaitEvent(st, co->ev[2 * i + 1], 0));
+	return ANNCUR_OK;
+}
+// whatever the plan left unlaunched (fewer latency-bound launches than chunks), then the final join
+int co_finish(CoScan *co, hipStream_t st) {
+	if (!co) return ANNCUR_OK;
+	int rc;
+	while (co->next < co->slots) {
+		if ((rc = co_fork(co, st)) != ANNCUR_OK) return rc;
+		if ((rc = co_join(co, st)) != ANNCUR_OK) return rc;
+	}
+	return co_join(co, st);
+}
+
 template <int KP, int QTV = FusedCfg<KP>::QT>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
-				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev) {
+				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr) {
 	using Cfg = FusedCfg<KP, QTV>;
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
@@ -1353,6 +1586,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.gmax = (float *)(ws + P.off_gmax); p.n_groups = P.n_groups;
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	p.tau_bias = 0.f;
+	p.chunk_tiles = 0; p.n_chunks = 0; p.chunk_ctr = nullptr; p.chunk_owner = nullptr;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
 		if (!g_stamps) {
@@ -1367,7 +1601,9 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (getenv("ANNCUR_DEBUG_NOSTORE")) p.capg = 0;  // every candidate is dropped at the store
 #endif
 
-	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
+	const int chunk = (P.chunk > 0 && P.lg == 2 && Cfg::QT == 2) ? P.chunk : 0;   // (the 16x16x32 sweep and the one-sub-tile bodies keep static shares)
+	const int owner_stride = P.n_rb * (P.n_tiles / (chunk > 0 ? chunk : P.n_tiles) + 2);
+	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, chunk > 0 ? P.off_gmax : 256, st));   // header (+ the stages' ticket counters)
 	EV(0);
 	// 1. prepass
 	p.n_wg = P.n_rb * P.S0;
@@ -1377,16 +1613,19 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		hipLaunchKernelGGL((score_kernel<KP, 0, 4, false, false, QTV>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
 	ANNCUR_LAUNCH_OK();
 	EV(1);
-	// 2. tau = k-th largest group maximum
-	int rc = launch_threshold(P, p.gmax, Q, k, ws, p.tau, p.tau_stride, st);
+	// 2. tau = k-th largest group maximum (beside it: the first chunk of the exact scan, anncur_eval_topk only)
+	int rc;
+	if ((rc = co_fork(co, st)) != ANNCUR_OK) return rc;
+	rc = launch_threshold(P, p.gmax, Q, k, ws, p.tau, p.tau_stride, st);
 	if (rc != ANNCUR_OK) return rc;
+	if ((rc = co_join(co, st)) != ANNCUR_OK) return rc;
 	EV(2);
 	// 3. sweep, in stages; between stages the thresholds are raised from the candidates collected so far.
 	// Item split s of a stage sweeps the tiles begin + s, begin + s + S, ... (interleaved), not a contiguous range: with norm-ordered rows
 	// the survivors crowd into the leading tiles, all the workgroups of a stage run at once, and with contiguous ranges the stage took
 	// as long as its FIRST split (cfg2: the first stage, 22 % of the tiles, 0.236 ms against 0.306 ms for the other 78 %).
 	// (score16_kernel keeps contiguous ranges)
-	const int tile_step = (P.lg == 2 && P.S > 1 && !contiguous_splits()) ? P.S : 1;
+	const int tile_step = (P.lg == 2 && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
 	p.n_wg = P.n_rb * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
@@ -1394,6 +1633,14 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		p.tile_step = tile_step;
+		// the staggered 32x32x16 sweep drains its rings by occupancy (FLUSH_AT); the planned window is only a backstop there, unless the
+		// plan wants every tile drained (large k: dense rings, raw-tile hand-over)
+		if (Cfg::QT == 2 && P.lg == 2 && p.flush_tiles > 1) p.flush_tiles = 8;
+		if (chunk > 0) {
+			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
+			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb;
+			p.chunk_owner = (uint8_t *)(ws + P.off_owner) + (size_t)stg * owner_stride;
+		}
 		bool launched = false;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		{ const char *dbg = getenv("ANNCUR_DEBUG_STAMP_STAGE"); p.debug_stamp = dbg ? (atoi(dbg) == stg) : (stg == P.n_stages - 1); }  // which launch leaves its stamps
@@ -1446,16 +1693,25 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		if (!launched) hipLaunchKernelGGL((score_kernel<KP, 1, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), Cfg::LDS_BYTES, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
-		if (stg + 1 < P.n_stages &&
-			(rc = launch_tau_refine(p.cand, p.seg_cnt, P.lg * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
-			return rc;
+		if (stg + 1 < P.n_stages) {
+			if ((rc = co_fork(co, st)) != ANNCUR_OK) return rc;
+			if ((rc = launch_tau_refine(p.cand, p.seg_cnt, P.lg * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
+				return rc;
+			if ((rc = co_join(co, st)) != ANNCUR_OK) return rc;
+		}
 	}
 	EV(3);
-	// 4. select
+	// 4. select (beside it: the last chunk of the exact scan; the caller joins)
+	if ((rc = co_fork(co, st)) != ANNCUR_OK) return rc;
 	SweepStages stages{};
 	stages.n = P.n_stages;
 	stages.stride = tile_step;
-	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) { stages.begin[g] = prev; stages.end[g] = P.stage_end[g]; stages.tps[g] = P.stage_tps[g]; }
+	stages.chunk = chunk; stages.bq = P.BQ;
+	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) {
+		stages.begin[g] = prev; stages.end[g] = P.stage_end[g]; stages.tps[g] = P.stage_tps[g];
+		stages.n_chunks[g] = chunk > 0 ? (P.stage_end[g] - prev + chunk - 1) / chunk : 0;
+		stages.owner[g] = (const uint8_t *)(ws + P.off_owner) + (size_t)g * owner_stride;
+	}
 	if ((rc = launch_select(P, P.lg * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
 	EV(4);
 	return ANNCUR_OK;
@@ -1523,7 +1779,7 @@ FusedPlan plan_wide(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
 }
 
 int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int KP, int k, float *out_val,
-				int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev) {
+				int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr) {
 	WideParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.et_rows = ceil_div64(I, TILE_I) * TILE_I; p.Q = Q; p.I = I; p.Kp = KP;
 	p.n_rb = P.n_rb; p.S = P.S;
@@ -1563,7 +1819,9 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 	ANNCUR_LAUNCH_OK();
 	EV(1);
 	// 2. threshold
+	if ((rc = co_fork(co, st)) != ANNCUR_OK) return rc;
 	if ((rc = launch_threshold(P, p.gmax, Q, k, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
+	if ((rc = co_join(co, st)) != ANNCUR_OK) return rc;
 	EV(2);
 	// 3. sweep in stages
 	p.n_wg = P.n_rb * P.S;
@@ -1580,12 +1838,16 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 		hipLaunchKernelGGL((wide_kernel<1, 16>), dim3(p.n_wg), dim3(512), W_LDS_TOTAL, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);
-		if (stg + 1 < P.n_stages &&
-			(rc = launch_tau_refine(p.cand, p.seg_cnt, 4 * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
-			return rc;
+		if (stg + 1 < P.n_stages) {
+			if ((rc = co_fork(co, st)) != ANNCUR_OK) return rc;
+			if ((rc = launch_tau_refine(p.cand, p.seg_cnt, 4 * P.S, P.capg, Q, k, P.kmax, const_cast<float *>(p.tau), p.tau_stride, stg > 0 ? 1 : 0, st)) != ANNCUR_OK)
+				return rc;
+			if ((rc = co_join(co, st)) != ANNCUR_OK) return rc;
+		}
 	}
 	EV(3);
 	// 4. select (stage ranges in 32-item tiles for the repair path)
+	if ((rc = co_fork(co, st)) != ANNCUR_OK) return rc;
 	SweepStages stages{};
 	stages.n = P.n_stages;
 	const int n_tiles32 = (int)ceil_div64(I, TILE_I), u = WBM / TILE_I;
@@ -1620,17 +1882,19 @@ extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int
 }
 
 // out_idx[i] = item_ids[out_idx[i]] (rows of Et -> the caller's item ids; -1 stays -1)
-__global__ __launch_bounds__(256) void remap_ids_kernel(int32_t *__restrict__ idx, const int32_t *__restrict__ item_ids, int64_t n) {
+__global__ __launch_bounds__(256) void remap_ids_kernel(int32_t *__restrict__ idx, const int32_t *__restrict__ item_ids, int64_t n, int64_t n_items) {
 	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i < n) {
 		const int32_t r = idx[i];
-		if (r >= 0) idx[i] = item_ids[r];
+		// (r < n_items always holds for a product call; the experiments build's ANNCUR_DEBUG_NOSTORE leaves the select reading candidate slots
+		//  nobody wrote, and an unchecked row there was an out-of-bounds read -- a GPU memory fault in scripts/stage_probe.py, round 3)
+		if (r >= 0) idx[i] = (int64_t)r < n_items ? item_ids[r] : -1;
 	}
 }
 
 static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
-						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr) {
+						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr, CoScan *co = nullptr) {
 	ANNCUR_REQUIRE((flags & ~(ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1)) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
 	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0, (flags & ANNCUR_TOPK_QT1) != 0);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
@@ -1646,20 +1910,22 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 	hipStream_t st = (hipStream_t)stream;
 	unsigned char *ws = (unsigned char *)workspace;
 	int rc;
+	if (co && (rc = co_plan(*co, P.n_stages + 1)) != ANNCUR_OK) return rc;   // one chunk per latency-bound launch: threshold, refinements, select
 	switch (Kp) {
-		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
-		case 128: rc = P.QT == 1 ? launch_fused<128, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev)
-								  : launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
-		case 256: rc = P.QT == 1 ? launch_fused<256, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev)
-								  : launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
-		case 512: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev); break;
-		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev); break;
+		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
+		case 128: rc = P.QT == 1 ? launch_fused<128, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co)
+								  : launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
+		case 256: rc = P.QT == 1 ? launch_fused<256, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co)
+								  : launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
+		case 512: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
+		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev, co); break;
 	}
 	if (rc == ANNCUR_OK && item_ids) {
 		const int64_t n = Q * (int64_t)k;
-		hipLaunchKernelGGL(remap_ids_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, out_idx, item_ids, n);
+		hipLaunchKernelGGL(remap_ids_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, out_idx, item_ids, n, I);
 		ANNCUR_LAUNCH_OK();
 	}
+	if (rc == ANNCUR_OK) rc = co_finish(co, st);
 	return rc;
 }
 
@@ -1673,6 +1939,26 @@ extern "C" int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int
 								 int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 								 void *stream) {
 	return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, nullptr);
+}
+
+/* a8: exact top-k of the stored scores AND the fused approximate retrieval in one call, the scan's row chunks co-scheduled with the
+ * retrieval's latency-bound launches (CoScan above).  Results are those of anncur_rowwise_topk + anncur_score_topk_ex. */
+extern "C" int anncur_eval_topk(const void *A, int a_dtype, int64_t lda, int32_t k_exact, float *exact_val, int32_t *exact_idx,
+								const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp, int32_t k_retvr,
+								float *approx_val, int32_t *approx_idx, void *workspace, size_t workspace_bytes, int32_t flags,
+								const int32_t *item_ids, void *stream, void *aux_stream) {
+	ANNCUR_REQUIRE(dtype_ok(a_dtype) && A && exact_val && exact_idx && lda >= I && k_exact >= 1 && k_exact <= I && k_exact <= ANNCUR_MAX_TOPK,
+				   ANNCUR_E_INVALID, "eval_topk: bad exact-scan arguments");
+	if (Q == 0) return ANNCUR_OK;
+	if (!aux_stream || aux_stream == stream) {   // no second stream: the two parts one after the other
+		const int rc = anncur_rowwise_topk(A, a_dtype, Q, I, lda, k_exact, exact_val, exact_idx, stream);
+		if (rc != ANNCUR_OK) return rc;
+		return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k_retvr, approx_val, approx_idx, workspace, workspace_bytes, stream, nullptr, flags, item_ids);
+	}
+	CoScan co{};
+	co.aux = (hipStream_t)aux_stream;
+	co.A = A; co.a_dtype = a_dtype; co.lda = lda; co.Q = Q; co.I = I; co.k = k_exact; co.val = exact_val; co.idx = exact_idx;
+	return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k_retvr, approx_val, approx_idx, workspace, workspace_bytes, stream, nullptr, flags, item_ids, &co);
 }
 
 extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,

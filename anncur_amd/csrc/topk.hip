@@ -543,6 +543,22 @@ int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int
 	return ANNCUR_OK;
 }
 
+// rows of the wave-per-row scan resident on the chip at once (what one "round" of the scan covers): anncur_eval_topk sizes its row
+// chunks in multiples of this so that a chunk does not end on a mostly empty round
+int anncur_internal_scan_rows_in_flight(int dtype) {
+	static int cached[2] = {0, 0};
+	const int di = dtype == ANNCUR_F32 ? 0 : 1;
+	if (cached[di] == 0) {
+		int occ = 0;
+		const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
+		const hipError_t e = di == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rowwise_topk_wave_kernel<float>, 256, lds)
+									 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rowwise_topk_wave_kernel<uint16_t>, 256, lds);
+		if (e != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 3; }
+		cached[di] = occ * 4 * anncur_num_cu();
+	}
+	return cached[di];
+}
+
 // =================================================================== C ABI
 extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k,
 								   float *out_val, int32_t *out_idx, void *stream) {

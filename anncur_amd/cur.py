@@ -291,6 +291,14 @@ class CURRowIndex(object):
 			X = ops.convert(X, torch.bfloat16)
 		return ops.score_topk_dense(X, Et, k)
 
+	def eval_topk(self, X, exact_rows, k, k_retvr):
+		"""(exact top-k of exact_rows, approximate top-k_retvr of X) -- the two rankings of the reference's per-query loop
+		(crossenc.py:97-106) -- co-scheduled in one call where the fused path takes the shape (ops.eval_topk)."""
+		Q = X.shape[0]
+		if self._Etp is not None and ops.fused_supported(Q, self.m, self._Etp.shape[1], k_retvr) and k <= self.m:
+			return ops.eval_topk(exact_rows, k, ops.pack_bf16(X, self._Etp.shape[1]), self._Etp_sorted, self.m, k_retvr, leading_sample=True, item_ids=self._item_ids)
+		return ops.rowwise_topk(exact_rows, k), self.topk(X, k_retvr)
+
 	def approx_error_rows(self, X, exact_rows):
 		if self.compute_dtype == "bf16" and self._Etp is not None and ops.approx_error_packed_ok(self._Etp.shape[1], exact_rows):
 			return ops.approx_error_packed(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, exact_rows, self.m)

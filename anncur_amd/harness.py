@@ -110,8 +110,7 @@ def run_approx_eval_w_seed_sharded(sharded, n_ment_anchors, n_ent_anchors, top_k
 	R = sharded.anchor_rows(row_idxs)                                  # the one exchange: [Kq x I] on every rank
 	index = CURRowIndex(R, col_idxs)
 	X_loc = ops.gather_cols(A_loc, col_idxs)
-	approx = index.topk(X_loc, top_k_retvr)
-	exact = ops.rowwise_topk(A_loc, top_k)
+	exact, approx = index.eval_topk(X_loc, A_loc, top_k, top_k_retvr)   # exact scan + retrieval, co-scheduled where the fused path applies
 	counts = ops.overlap_counts(exact.indices, approx.indices, [(top_k, top_k_retvr)])[0]
 	err_sq, norm_sq = index.approx_error_rows(X_loc, A_loc)
 	packed = torch.stack([counts.float(), err_sq, norm_sq], dim=1).contiguous()      # [n_loc x 3]

@@ -409,6 +409,54 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 	return TopK(val, idx)
 
 
+_aux_streams = {}
+
+
+def aux_stream(device):
+	"""The second stream anncur_eval_topk forks the exact scan's row chunks onto (one per device, created on first use)."""
+	key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+	if key not in _aux_streams:
+		_aux_streams[key] = torch.cuda.Stream(device=device)
+	return _aux_streams[key]
+
+
+@_on_device
+def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False):
+	"""The per-query evaluation loop's two top-k's in one call (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:97-106):
+	(exact = rowwise_topk(A, k), approx = score_topk_fused(Xp, Etp, I, k_retvr)), the exact scan's row chunks co-scheduled with the
+	retrieval's latency-bound launches on a second stream (anncur_eval_topk).  serial=True: the same two results, one after the other."""
+	_dev(A, Xp, Etp)
+	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16:
+		raise TypeError("eval_topk takes bf16 retrieval operands")
+	A = _rowmajor(A)
+	Q, Kp = Xp.shape
+	if A.shape[0] != Q or A.shape[1] != I or Etp.shape[1] != Kp or not Etp.is_contiguous() or Etp.shape[0] < -(-I // 32) * 32:
+		raise ValueError("eval_topk: A must be [Q x I], Et packed [ceil(I/32)*32 x Kp]")
+	Xp = _rowmajor(Xp)
+	lib = _lib.load()
+	nbytes = lib.anncur_score_topk_workspace_bytes(Q, I, Kp, k_retvr)
+	if nbytes == 0:
+		raise _lib.AnncurHipError(f"eval_topk: shape (Q={Q}, I={I}, Kp={Kp}, k={k_retvr}) is outside the fused path")
+	ws = _Workspace.get(nbytes, Xp.device) if workspace is None else workspace
+	if ws.numel() < nbytes or ws.data_ptr() % 256 != 0 or ws.device != Xp.device:
+		raise ValueError("eval_topk: workspace too small, misaligned or on another device (use fused_workspace())")
+	ev = torch.empty((Q, k), dtype=torch.float32, device=A.device)
+	ei = torch.empty((Q, k), dtype=torch.int32, device=A.device)
+	av = torch.empty((Q, k_retvr), dtype=torch.float32, device=A.device)
+	ai = torch.empty((Q, k_retvr), dtype=torch.int32, device=A.device)
+	ids = _item_ids_arg(item_ids, I, Xp.device)
+	if serial:
+		aux_p = None
+	else:
+		# (the chunks forked onto the auxiliary stream are joined back into the launch stream before the call returns: every tensor used
+		#  there is ordered like launch-stream work, the caching allocator needs no record_stream)
+		aux = aux or aux_stream(A.device)
+		aux_p = ctypes.c_void_p(aux.cuda_stream)
+	check(lib.anncur_eval_topk(_p(A), _dt(A), _ld(A), k, _p(ev), _p(ei), _p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k_retvr, _p(av), _p(ai), _p(ws), nbytes,
+							   _topk_flags(leading_sample, mfma16, qt1), _p(ids) if ids is not None else None, _stream(), aux_p), "eval_topk")
+	return TopK(ev, ei), TopK(av, ai)
+
+
 @_on_device
 def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False):
 	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches, sweep launch 1, 2, 3]) in

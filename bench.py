@@ -87,7 +87,7 @@ def main():
 	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
 	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
 	ap.add_argument("--seed", type=int, default=0)
-	ap.add_argument("--no-overlap", action="store_true", help="run the exact scan on the same stream as the retrieval instead of a second one")
+	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream instead of the co-scheduled anncur_eval_topk")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,24 +173,14 @@ def main():
 	pinned = [torch.empty((len(cells), Q), dtype=torch.int32, pin_memory=True) for _ in range(2)]
 	events = [torch.cuda.Event() for _ in range(2)]
 
-	side = torch.cuda.Stream(device=device) if not args.no_overlap else None
-
 	def gpu_step():
-		main = torch.cuda.current_stream()
-		if side is not None:
-			# the exact scan (HBM-bound) is independent of the retrieval until the overlap count: run it on a second stream so
-			# that it fills the chip while the retrieval's small latency-bound kernels (threshold, refinement, select) run
-			side.wait_stream(main)
-			with torch.cuda.stream(side):
-				exact = ops.rowwise_topk(A_test, k)                    # a8 exact scan
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
-		approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)   # a6 + a7 fused (item rows in the index's norm order)
-		if side is not None:
-			main.wait_stream(side)
-		else:
-			exact = ops.rowwise_topk(A_test, k)
+		# a8 exact scan + a6/a7 fused retrieval (item rows in the index's norm order) as ONE call: the HBM-bound scan's row chunks run on a
+		# second stream beside the retrieval's latency-bound launches (threshold, refinement, select), the MFMA-bound sweeps get the chip to
+		# themselves (anncur_eval_topk).  --no-overlap: the same two kernels' results one after the other on one stream.
+		exact, approx = ops.eval_topk(A_test, k, Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, serial=args.no_overlap)
 		return ops.overlap_counts(exact.indices, approx.indices, cells)   # a8 rerank (closed form) + a10
 
 	# The ten launches of a step are captured once into a HIP graph and replayed: per-dispatch latency on a busy host

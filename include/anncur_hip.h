@@ -172,6 +172,18 @@ int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde
                          void *workspace, size_t workspace_bytes,
                          int32_t flags, const int32_t *item_ids, void *stream);
 
+/* a8 per-query evaluation loop: exact top-k of the stored scores AND the approximate retrieval, in one call ----------------------
+ *   curr_ment_scores.topk(top_k) ; approx_curr_ment_scores.topk(top_k_retvr)          ...crossenc.py:97-106 ; ..._splits.py:80-89
+ * = anncur_rowwise_topk(A, k_exact) + anncur_score_topk_ex(X, Et, k_retvr), same results, scheduled together: the retrieval is a chain
+ * of MFMA-bound sweep launches with latency-bound launches between them (threshold, refinements, select); the HBM-bound exact scan is
+ * cut into row chunks (whole rounds of the scan's rows in flight) and chunk i runs on `aux_stream` beside the i-th latency-bound
+ * launch -- forked and joined with events, so the call is one unit of work on `stream` (and capturable into a graph).  aux_stream
+ * NULL or equal to stream: the two parts run one after the other.  Workspace as anncur_score_topk. */
+int anncur_eval_topk(const void *A, int a_dtype, int64_t lda, int32_t k_exact, float *exact_val, int32_t *exact_idx,
+                     const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp, int32_t k_retvr,
+                     float *approx_val, int32_t *approx_idx, void *workspace, size_t workspace_bytes,
+                     int32_t flags, const int32_t *item_ids, void *stream, void *aux_stream);
+
 /* Measurement only: same as anncur_score_topk but records HIP events on `stream` between the four
  * launches, synchronises, and returns their durations in stage_ms[9] (host floats, milliseconds):
  * {prepass, threshold, sweep stage (sweep launches + the threshold refinements between them), select,

@@ -19,18 +19,18 @@ Kp = ops.padded_k(K)
 Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), Kp)
 Xp = ops.pack_bf16(X, Kp)
 del Z, E
-KNOBS = ["ANNCUR_DEBUG_STAGES", "ANNCUR_DEBUG_ALL_PRED", "ANNCUR_DEBUG_TAU_BIAS", "ANNCUR_DEBUG_FLUSH_TILES", "ANNCUR_DEBUG_NOSTORE", "ANNCUR_DEBUG_CONTIG"]
+KNOBS = ["ANNCUR_DEBUG_CHUNK", "ANNCUR_DEBUG_STAGES", "ANNCUR_DEBUG_ALL_PRED", "ANNCUR_DEBUG_TAU_BIAS", "ANNCUR_DEBUG_FLUSH_TILES", "ANNCUR_DEBUG_NOSTORE", "ANNCUR_DEBUG_CONTIG"]
 def S(name, flags=None, **env):
 	return (name, {("ANNCUR_DEBUG_" + a.upper()): str(b) for a, b in env.items()}, flags or {})
-settings = [S("default"), S("mfma16", {"mfma16": True}), S("qt1", {"qt1": True}),
+settings = [S("default"), S("static", chunk=0), S("chunk=3", chunk=3), S("chunk=5", chunk=5), S("chunk=6", chunk=6), S("chunk=8", chunk=8), S("mfma16", {"mfma16": True}), S("qt1", {"qt1": True}),
+			S("static f=.22 p0", chunk=0, stages="0.22", all_pred=0), S("static bare", chunk=0, tau_bias="1e30"),
 			S("pred=0", all_pred=0), S("pred=1", all_pred=1),
 			S("1 stage", stages="1"), S("f=.06", stages="0.06"), S("f=.10", stages="0.10"), S("f=.15", stages="0.15"), S("f=.22", stages="0.22"), S("f=.30", stages="0.30"),
 			S("f=.04,.25", stages="0.04,0.25"), S("f=.06,.30", stages="0.06,0.30"), S("f=.10,.40", stages="0.10,0.40"),
 			S("f=.10 pred=0", stages="0.10", all_pred=0), S("f=.22 pred=0", stages="0.22", all_pred=0),
-			S("flush=1", flush_tiles=1), S("flush=4", flush_tiles=4), S("flush=8", flush_tiles=8),
+			S("flush=1", flush_tiles=1), S("flush=4", flush_tiles=4), S("f=.25 pred=0", stages="0.25", all_pred=0), S("f=.30 pred=0", stages="0.30", all_pred=0), S("f=.18 pred=0", stages="0.18", all_pred=0),
 			S("bare", tau_bias="1e30"), S("bare pred=0", tau_bias="1e30", all_pred=0), S("bare pred=1", tau_bias="1e30", all_pred=1),
-			S("bare mfma16", {"mfma16": True}, tau_bias="1e30"), S("bare qt1", {"qt1": True}, tau_bias="1e30"), S("bare 1 stage", tau_bias="1e30", stages="1"),
-			S("nostore", nostore=1)]
+			S("bare mfma16", {"mfma16": True}, tau_bias="1e30"), S("bare qt1", {"qt1": True}, tau_bias="1e30"), S("bare 1 stage", tau_bias="1e30", stages="1")]
 if os.environ.get("STAGE_PROBE_ONLY"):
 	keep = os.environ["STAGE_PROBE_ONLY"].split(";")
 	settings = [s for s in settings if s[0] in keep]
@@ -40,6 +40,7 @@ for r in range(rounds + 1):
 	for name, env, flags in settings:
 		for kn in KNOBS: os.environ.pop(kn, None)
 		os.environ.update(env)
+		if r == 0: print("warm-up", name, flush=True)
 		(v, idx), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids, **flags)
 		if r == 0:
 			if not env.get("ANNCUR_DEBUG_TAU_BIAS") and not env.get("ANNCUR_DEBUG_NOSTORE"):

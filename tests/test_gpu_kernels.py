@@ -263,11 +263,13 @@ def test_fused_overflow_fallback_is_exact(ops):
 
 
 def test_fused_local_overflow_is_repaired_exactly(ops):
-	# the tiles ONE item split sweeps (tile index = 3 mod S: the splits interleave the tiles) score far above the rest for every query:
-	# that split's candidate segments overflow, only it is recomputed (select_candidates_kernel), the result is exact
+	# STATIC tile shares (the one-sub-tile sweep, ANNCUR_TOPK_QT1, keeps them): the tiles ONE item split sweeps (tile index = 3 mod S: the
+	# splits interleave the tiles) score far above the rest for every query: that split's candidate segments overflow, only it is
+	# recomputed (select_candidates_kernel), the result is exact
 	Q, I, K, k = 3000, 80000, 128, 100
-	S_ = ops.fused_plan(Q, I, 128, k)["splits"]
-	assert S_ >= 8
+	plan = ops.fused_plan(Q, I, 128, k, qt1=True)
+	S_ = plan["splits"]
+	assert S_ >= 8 and plan["QT"] == 1
 	g = _g(4242)
 	X = (1.0 + 0.1 * torch.randn(Q, K, generator=g)).bfloat16()
 	E = 0.05 * torch.randn(K, I, generator=g)
@@ -275,7 +277,7 @@ def test_fused_local_overflow_is_repaired_exactly(ops):
 	E[:, (tile % S_) == 3] += 0.5
 	E = E.bfloat16()
 	Xp = ops.pack_bf16(X.cuda(), 128); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 128, row_multiple=32)
-	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, qt1=True)
 	torch.cuda.synchronize()
 	assert nfb.item() > 0
 	S = X.double() @ E.double()
@@ -284,6 +286,66 @@ def test_fused_local_overflow_is_repaired_exactly(ops):
 	got = i.cpu().long()
 	assert (((got // 32) % S_) == 3).all()                     # every result comes from the boosted tiles
 	assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(got[::37], ri[::37]))
+
+
+def test_fused_local_overflow_under_the_dynamic_tile_schedule(ops):
+	"""The default sweep draws its tiles as tickets (chunks of 4 tiles per query row block): which workgroup sweeps which tiles is decided
+	at run time, and the repair path finds a split's tiles in the chunk-owner map the sweep leaves behind.  Forced here: the first 256
+	items (the first two chunks, which ONE workgroup of every row block draws together at its start) score far above the rest for every
+	query -- 128 survivors per lane half against a segment capacity of 64 (and rings that wrap): that workgroup's segments overflow,
+	its chunks are recomputed from the owner map, the result is exact."""
+	Q, I, K, k = 3000, 80000, 128, 10
+	plan = ops.fused_plan(Q, I, 128, k)
+	assert plan["QT"] == 2 and plan["lg"] == 2 and plan["segment_capacity"] == 64
+	g = _g(777)
+	X = (1.0 + 0.1 * torch.randn(Q, K, generator=g)).bfloat16()
+	E = 0.05 * torch.randn(K, I, generator=g)
+	E[:, :256] += 0.5
+	E = E.bfloat16()
+	Xp = ops.pack_bf16(X.cuda(), 128); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 128, row_multiple=32)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	torch.cuda.synchronize()
+	assert nfb.item() > 0                                      # the local repair ran
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
+	got = i.cpu().long()
+	assert (got < 256).all()
+	assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(got[::37], ri[::37]))
+	# and again: the owner map of the previous call must not leak into this one (another assignment, same answer)
+	(v2, i2), _ = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	assert torch.equal(v2, v) and torch.equal(torch.sort(i2, 1).values, torch.sort(i, 1).values)
+
+
+@pytest.mark.parametrize("Q,I,K,k,kr,dt", [(700, 40000, 64, 10, 100, "bf16"), (3300, 50007, 256, 100, 100, "bf16"), (7000, 33000, 128, 64, 200, "f32"),
+										   (257, 70000, 512, 100, 100, "bf16"), (500, 20000, 1024, 50, 100, "bf16")])
+def test_eval_topk_equals_the_two_separate_calls(ops, Q, I, K, k, kr, dt):
+	"""anncur_eval_topk = anncur_rowwise_topk + anncur_score_topk_ex with the scan's row chunks forked onto a second stream between the
+	retrieval's launches: the SAME kernels on the same inputs, so both results are bit for bit those of the separate calls -- with one
+	chunk (Q below a round of the scan), several chunks, the wide kernel, fp32 scores, serial mode, and replayed from a captured graph."""
+	g = _g(Q + I + K)
+	X, E, Xp, Etp = _fused_case(ops, Q, I, K, kr, seed=Q + I + K + kr)
+	A = torch.randn(Q, I, generator=g)
+	A = (A.bfloat16() if dt == "bf16" else A).cuda()
+	want_e = ops.rowwise_topk(A, k)
+	want_a = ops.score_topk_fused(Xp, Etp, I, kr)
+	torch.cuda.synchronize()
+	for serial in (False, True):
+		e, a = ops.eval_topk(A, k, Xp, Etp, I, kr, serial=serial)
+		torch.cuda.synchronize()
+		assert torch.equal(e.values, want_e.values) and torch.equal(e.indices, want_e.indices), serial
+		assert torch.equal(a.values, want_a.values) and torch.equal(a.indices, want_a.indices), serial
+	# captured: the fork / join events become graph edges, the auxiliary stream joins the capture and leaves it again
+	ws = ops.fused_workspace(Q, I, Xp.shape[1], kr, Xp.device)
+	ops.eval_topk(A, k, Xp, Etp, I, kr, workspace=ws); torch.cuda.synchronize()
+	gr = torch.cuda.CUDAGraph()
+	with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+		e, a = ops.eval_topk(A, k, Xp, Etp, I, kr, workspace=ws)
+	for _ in range(2):
+		e.values.zero_(); a.indices.zero_()
+		gr.replay(); torch.cuda.synchronize()
+		assert torch.equal(e.values, want_e.values) and torch.equal(e.indices, want_e.indices)
+		assert torch.equal(a.values, want_a.values) and torch.equal(a.indices, want_a.indices)
 
 
 def test_fused_unsupported_shapes_raise(ops):

@@ -290,7 +290,7 @@ __device__ __forceinline__ void mark_wrapped_raw(const f32x16 &acc, uint32_t lq,
 
 // Drain the lane's ring to its HBM candidate segment: one store instruction per queue slot for the whole wave.
 // raw_item0: first item (+ 4 h) of the tile a RING_RAW ring holds (dense splits only).
-template <int D>
+template <int D, bool BATCH = true>
 __device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *__restrict__ seg, uint32_t &ncand, uint32_t capg,
 											 uint32_t n_items, float tau, uint32_t raw_item0) {
 	if (__builtin_expect(__ballot(qcnt >= RING_RAW) != 0ull, 0)) {
@@ -317,11 +317,44 @@ __device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *
 		// kernel recomputes this query exactly
 		if (n > (uint32_t)D) { ncand = 0x80000000u; n = D; }
 	}
-	for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
-		if (i < n) {
-			const uint2 e = lds_load_u64(lq + i * 2048u);
-			if (e.y < n_items) {               // (items past I exist only in the matrix' last, partial tile)
-				if (ncand < capg) seg[ncand] = e;  // (capg = 0 in the no-store timing experiment)
+	if constexpr (!BATCH) {  // (the three-workgroups-per-CU body of ANNCUR_TOPK_QT1 has no sixteen registers to spare: slot by slot)
+		for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
+			if (i < n) {
+				const uint2 w = lds_load_u64(lq + i * 2048u);
+				if (w.y < n_items) {
+					if (ncand < capg) seg[ncand] = w;
+					ncand++;
+				}
+			}
+		}
+		qcnt = 0;
+		return;
+	}
+	// Read the occupied slots back to back, wait ONCE, then store.  (Round 2 read, waited and stored slot by slot: a drain with three
+	// entries in its fullest ring paid three exposed LDS round trips -- at k = 500, where every tile is drained and the fullest of the 64
+	// rings holds 3-4 entries, that was more wave time than the tile's MFMAs.)  Slot i is read if ANY lane holds more than i entries.
+	unsigned long long e[D];
+	int n_read = 0;  // (uniform) slots read = the fullest ring's count
+#pragma unroll
+	for (int i = 0; i < D; ++i) {
+		if (__ballot((uint32_t)i < n) == 0ull) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(e[i]) : "v"(lq), "n"(i * 2048));
+#endif
+		n_read = i + 1;
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	static_assert(D == 8, "the wait below names eight slots");
+	// (the destinations are in flight until here; naming them as in/out operands keeps every use below the wait)
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7])::"memory");
+#endif
+#pragma unroll
+	for (int i = 0; i < D; ++i) {
+		if (i >= n_read) break;
+		if ((uint32_t)i < n) {
+			const uint2 w = make_uint2((uint32_t)e[i], (uint32_t)(e[i] >> 32));
+			if (w.y < n_items) {               // (items past I exist only in the matrix' last, partial tile)
+				if (ncand < capg) seg[ncand] = w;  // (capg = 0 in the no-store timing experiment)
 				ncand++;                        // (a poisoned count stays > capg)
 			}
 		}
@@ -470,6 +503,7 @@ template <int KP, int MODE, int GROUP, bool PRED = false, bool INL = false, int 
 __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_kernel(const FusedParams p) {
 	using Cfg = FusedCfg<KP, QTV>;
 	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
+	constexpr bool FLUSH_BATCH = !(QTV == 1 && KP <= 256);   // (see flush_queue)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r = lane & 31, h = lane >> 5;
@@ -673,7 +707,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if ((J) - ts < dense_end || --flush_in2 <= 0) {                                                                     \
 				flush_in2 = p.flush_tiles;                                                                                      \
 				/* (a raw ring holds the tile before the previous one, filtered during the previous step) */                    \
-				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - (uint32_t)ts * TILE_I); \
+				flush_queue<Cfg::QDEPTH, FLUSH_BATCH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - (uint32_t)ts * TILE_I); \
 			}                                                                                                                   \
 			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0], (J) < dense_end || every_tile);               \
 			tau_prev = tau[0]; item0_prev = (uint32_t)(J) * TILE_I + 4 * h;                                                     \
@@ -687,7 +721,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if (j + ts < j_end) { STAGGER1_STEP(1, j + ts, accB, accA); last_in_a = false; }
 		}
 #undef STAGGER1_STEP
-		flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - (uint32_t)ts * TILE_I);
+		flush_queue<Cfg::QDEPTH, FLUSH_BATCH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev - (uint32_t)ts * TILE_I);
 		if (last_in_a) {  // drain: the last tile (its ring was just drained: the raw path is exact in every split)
 #pragma unroll
 			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accA[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
@@ -786,7 +820,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	if (MODE == 1) {
 #pragma unroll
 		for (int t = 0; t < QT; ++t) {
-			flush_queue<Cfg::QDEPTH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I, tau[t], last_item0);
+			flush_queue<Cfg::QDEPTH, FLUSH_BATCH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I, tau[t], last_item0);
 			if (qv[t] < p.Q) p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] = ncand[t];
 		}
 	}
@@ -1264,6 +1298,15 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 				if (c3 < best) { best = c3; P.n_stages = 3; frac[0] = f1; frac[1] = f2; }
 			}
 		}
+	}
+	// The hit-count model above knows nothing of what a first stage costs beyond its survivors: it runs against the loosest threshold
+	// (dense rings, exec-mask filter) and every candidate it collects is read again by the refinement.  Measured at cfg2 size on MI355X
+	// (scripts/stage_probe.py, round 3: whole call, prepass to select): k = 100 flat within 3 us for f1 in 0.18..0.35; k = 500
+	// f1 = 0.5 (the model's choice) 1.18 ms, 0.30 1.12, 0.22 1.11, 0.15 1.15 -> a two-stage plan takes 0.7 (k <= 128) / 0.5 of the model's
+	// first fraction (k > 128: 0.6: the model picks 0.35 there).
+	if (P.n_stages == 2) {
+		const double f1 = frac[0] * (k <= WSEL_K ? 0.7 : 0.6);
+		frac[0] = f1 > fmin ? f1 : (fmin < frac[0] ? fmin : frac[0]);
 	}
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_STAGES")) {  // tuning knob "f1,f2" or "f1" (>= 1: single stage)

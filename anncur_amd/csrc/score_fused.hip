@@ -56,7 +56,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // native vecto
 
 constexpr int TILE_I = 32;
 constexpr int CHUNK_TILES = 4;   // dynamic tile schedule: tiles per ticket
-constexpr int FLUSH_AT = 3;      // staggered sweep: the rings (8 slots per lane and sub-tile) are drained as soon as one holds this many entries
 
 template <int KP, int QTV = ((KP <= 256) ? 2 : 1)>
 struct FusedCfg {
@@ -317,7 +316,12 @@ __device__ __forceinline__ void flush_queue(uint32_t lq, uint32_t &qcnt, uint2 *
 		// kernel recomputes this query exactly
 		if (n > (uint32_t)D) { ncand = 0x80000000u; n = D; }
 	}
-	if constexpr (!BATCH) {  // (the three-workgroups-per-CU body of ANNCUR_TOPK_QT1 has no sixteen registers to spare: slot by slot)
+#ifdef ANNCUR_V_SERIAL_FLUSH
+	constexpr bool BATCH_ = false;
+#else
+	constexpr bool BATCH_ = BATCH;
+#endif
+	if constexpr (!BATCH_) {  // (the three-workgroups-per-CU body of ANNCUR_TOPK_QT1 has no sixteen registers to spare: slot by slot)
 		for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
 			if (i < n) {
 				const uint2 w = lds_load_u64(lq + i * 2048u);
@@ -605,7 +609,11 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	uint32_t dma_off[(MODE == 1 && QT == 2) ? Cfg::TILE_BYTES / 4096 : 1];
 	if constexpr (MODE == 1 && QT == 2) {
 		tile_dma_offsets<KP>(dma_off, wave_u, lane);
+#ifdef ANNCUR_V_OLD_DMA
+		if (t_cur >= 0) tile_dma<KP>(p.Et, t_cur, smem, wave, lane);
+#else
 		if (t_cur >= 0) tile_dma_s<KP>(p.Et, t_cur, lds_base, wave_u, dma_off);
+#endif
 	} else if (j_begin < j_end) tile_dma<KP>(p.Et, tile_of(j_begin), smem, wave, lane);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
@@ -637,6 +645,18 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 		// stagger_tile() counts LDS reads with lgkmcnt(n): no scalar load of the prologue may still be in flight (scalar loads share
 		// the counter and return out of order)
 		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+#ifdef ANNCUR_V_OLD_DMA   /* A/B variant builds (make variant V=...): one feature of the round-3 sweep switched back */
+#define STAGGER_DMA(NX, CUR) tile_dma<KP>(p.Et, (NX), smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane)
+#else
+#define STAGGER_DMA(NX, CUR) tile_dma_s<KP>(p.Et, (NX), lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off)
+#endif
+// (Round 3 also tried draining by occupancy -- any lane's ring at 3 entries -- instead of the planned window: +4 % sweep time on the bench
+//  matrices, same box, alternating; ANNCUR_V_ADAPT builds it again.)
+#ifdef ANNCUR_V_ADAPT
+#define STAGGER_RING_FILLING (__ballot((qcnt[0] | qcnt[1]) >= (3u << 11)) != 0ull)
+#else
+#define STAGGER_RING_FILLING false
+#endif
 #define STAGGER_STEP(CUR)                                                                                                       \
 		do {                                                                                                                    \
 			const int J = t_cur;                                                                                                \
@@ -649,12 +669,10 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			int nx = J + t_step;                                                                                                \
 			bool crossed = false;  /* (uniform) the next tile opens the look-ahead chunk: draw the ticket of the one after it */ \
 			if (nx >= t_cend) { nx = t_next_chunk; crossed = dyn && nx >= 0; }                                                  \
-			if (nx >= 0) tile_dma_s<KP>(p.Et, nx, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);                   \
+			if (nx >= 0) STAGGER_DMA(nx, CUR);                                                                                  \
 			uint32_t ticket = 0;                                                                                                \
 			if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);  /* in flight until ticket_wait() below */          \
-			/* drain when the previous tile was a dense one, when the window is up, or when some lane's ring is filling (FLUSH_AT entries or a  \
-			   raw tile): the rings are drained by what they hold, not by what the plan expected them to hold */                \
-			if (t_prev < dense_end || --flush_in2 <= 0 || __ballot((qcnt[0] | qcnt[1]) >= ((uint32_t)FLUSH_AT << 11)) != 0ull) { \
+			if (t_prev < dense_end || --flush_in2 <= 0 || STAGGER_RING_FILLING) {                                                \
 				flush_in2 = p.flush_tiles;                                                                                      \
 				/* (a raw ring holds one tile: sub-tile 0 of the previous tile, sub-tile 1 of the one before) */                \
 				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev);    \
@@ -682,6 +700,8 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			STAGGER_STEP(1);
 		}
 #undef STAGGER_STEP
+#undef STAGGER_DMA
+#undef STAGGER_RING_FILLING
 		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_pp);  // keep one tile's hits per queue window
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
@@ -1301,11 +1321,15 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	}
 	// The hit-count model above knows nothing of what a first stage costs beyond its survivors: it runs against the loosest threshold
 	// (dense rings, exec-mask filter) and every candidate it collects is read again by the refinement.  Measured at cfg2 size on MI355X
-	// (scripts/stage_probe.py, round 3: whole call, prepass to select): k = 100 flat within 3 us for f1 in 0.18..0.35; k = 500
-	// f1 = 0.5 (the model's choice) 1.18 ms, 0.30 1.12, 0.22 1.11, 0.15 1.15 -> a two-stage plan takes 0.7 (k <= 128) / 0.5 of the model's
-	// first fraction (k > 128: 0.6: the model picks 0.35 there).
+	// (round 3, one box, alternating): k = 100 -- the model's 0.35 stays (0.245: + 2 % sweep time on the bench matrices, level on random
+	// operands); k = 500 -- the model's 0.35: 1.18 ms per call, 0.30 1.12, 0.22 1.11, 0.15 1.15 -> above k = 128 a two-stage plan
+	// takes 0.6 of the model's first fraction.
 	if (P.n_stages == 2) {
-		const double f1 = frac[0] * (k <= WSEL_K ? 0.7 : 0.6);
+		double shrink = k <= WSEL_K ? 1.0 : 0.6;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (const char *dbg = getenv("ANNCUR_DEBUG_F1_SHRINK")) shrink = atof(dbg);
+#endif
+		const double f1 = frac[0] * shrink;
 		frac[0] = f1 > fmin ? f1 : (fmin < frac[0] ? fmin : frac[0]);
 	}
 #ifdef ANNCUR_TIMING_EXPERIMENTS
@@ -1676,9 +1700,9 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		p.tile_step = tile_step;
-		// the staggered 32x32x16 sweep drains its rings by occupancy (FLUSH_AT); the planned window is only a backstop there, unless the
-		// plan wants every tile drained (large k: dense rings, raw-tile hand-over)
+#ifdef ANNCUR_V_ADAPT
 		if (Cfg::QT == 2 && P.lg == 2 && p.flush_tiles > 1) p.flush_tiles = 8;
+#endif
 		if (chunk > 0) {
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
 			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb;

@@ -87,7 +87,10 @@ def main():
 	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
 	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
 	ap.add_argument("--seed", type=int, default=0)
-	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream instead of the co-scheduled anncur_eval_topk")
+	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
+	ap.add_argument("--scan-mode", default="side", choices=["side", "chunks", "serial"],
+					help="how the exact scan is scheduled against the retrieval: side = on a second stream from the start of the step, joined before the overlap "
+						 "count; chunks = anncur_eval_topk (row chunks forked beside the retrieval's latency-bound launches); serial = one stream")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,14 +176,28 @@ def main():
 	pinned = [torch.empty((len(cells), Q), dtype=torch.int32, pin_memory=True) for _ in range(2)]
 	events = [torch.cuda.Event() for _ in range(2)]
 
+	if args.no_overlap:
+		args.scan_mode = "serial"
+	side = ops.aux_stream(device) if args.scan_mode == "side" else None
+
 	def gpu_step():
+		main = torch.cuda.current_stream()
+		if side is not None:
+			# the exact scan (HBM-bound, a8) is independent of the retrieval until the overlap count: it starts on a second stream with the
+			# step and the hardware interleaves its workgroups with the retrieval's (measured, one box, alternating: 1.097 ms per step against
+			# 1.134 on one stream; cutting the scan into row chunks beside the retrieval's latency-bound launches -- --scan-mode chunks,
+			# anncur_eval_topk -- lost to both at this size: a chunk of one round of rows streams at 3.7 TB/s, the whole scan at 5.6)
+			side.wait_stream(main)
+			with torch.cuda.stream(side):
+				exact = ops.rowwise_topk(A_test, k)
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
-		# a8 exact scan + a6/a7 fused retrieval (item rows in the index's norm order) as ONE call: the HBM-bound scan's row chunks run on a
-		# second stream beside the retrieval's latency-bound launches (threshold, refinement, select), the MFMA-bound sweeps get the chip to
-		# themselves (anncur_eval_topk).  --no-overlap: the same two kernels' results one after the other on one stream.
-		exact, approx = ops.eval_topk(A_test, k, Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, serial=args.no_overlap)
+		if side is not None:
+			approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)   # a6 + a7 fused (item rows in the index's norm order)
+			main.wait_stream(side)
+		else:
+			exact, approx = ops.eval_topk(A_test, k, Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, serial=args.scan_mode == "serial")
 		return ops.overlap_counts(exact.indices, approx.indices, cells)   # a8 rerank (closed form) + a10
 
 	# The ten launches of a step are captured once into a HIP graph and replayed: per-dispatch latency on a busy host

@@ -8,12 +8,15 @@ namespace {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DBM = 64, DBN = 64, DBK = 16;
+constexpr int DBM = 64, DBN = 64, DBK = 32;
 constexpr int DPITCH = 80;  // doubles per LDS row: 160 dwords = 32 (mod 64 banks), the four k-rows of a fragment read do not collide
 
 // C(m,n) = alpha * sum_k A(m,k) B(k,n) + beta * Cin(m,n); element (i,j) of an operand at base + i*s0 + j*s1.
 // Workgroup = 64 x 64 outputs, wave (wm, wn) = 32 x 32 = 2 x 2 MFMA tiles.  Fragment maps (MI355X guide, f64 MFMA):
 // A[row l&15][k l>>4], B[k l>>4][col l&15], C/D col = l&15, row = (l>>4) + 4*reg.
+// The grids are tiny (a 512 x 256 anchor block: 16 workgroups) and the kernel is latency-bound per k-tile: global loads -> LDS ->
+// barrier -> MFMAs.  Round 3: 32-deep k-tiles and the NEXT k-tile's global loads issued before the current one's MFMAs (registers),
+// so a k-tile costs one load latency per 32 k instead of one per 16 with nothing overlapped (64 -> ~25 us per product at 512 x 256).
 __global__ __launch_bounds__(256) void gemm_f64_kernel(const double *__restrict__ A, int64_t a_sm, int64_t a_sk, const double *__restrict__ B,
 														int64_t b_sk, int64_t b_sn, double *C, int64_t c_sm, int64_t c_sn, int64_t M, int64_t N,
 														int64_t K, double alpha, double beta, const double *Cin, int64_t i_sm, int64_t i_sn) {
@@ -26,16 +29,33 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double *__restrict_
 #pragma unroll
 		for (int j = 0; j < 2; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 	const bool a_kfast = a_sk == 1, b_kfast = b_sk == 1;  // which index runs along consecutive threads (coalescing only)
-	for (int64_t k0 = 0; k0 < K; k0 += DBK) {
+	constexpr int PER = DBM * DBK / 256;  // elements of each operand tile per thread
+	double ra[PER], rb[PER];
+	auto load = [&](int64_t k0) {
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
+		for (int i = 0; i < PER; ++i) {
 			const int e = tid + 256 * i;
 			const int am = a_kfast ? e / DBK : e % DBM, ak = a_kfast ? e % DBK : e / DBM;
-			As[ak][am] = (m0 + am < M && k0 + ak < K) ? A[(m0 + am) * a_sm + (k0 + ak) * a_sk] : 0.0;
+			ra[i] = (m0 + am < M && k0 + ak < K) ? A[(m0 + am) * a_sm + (k0 + ak) * a_sk] : 0.0;
 			const int bn = b_kfast ? e / DBK : e % DBN, bk = b_kfast ? e % DBK : e / DBN;
-			Bs[bk][bn] = (n0 + bn < N && k0 + bk < K) ? B[(k0 + bk) * b_sk + (n0 + bn) * b_sn] : 0.0;
+			rb[i] = (n0 + bn < N && k0 + bk < K) ? B[(k0 + bk) * b_sk + (n0 + bn) * b_sn] : 0.0;
 		}
+	};
+	auto stash = [&]() {
+#pragma unroll
+		for (int i = 0; i < PER; ++i) {
+			const int e = tid + 256 * i;
+			const int am = a_kfast ? e / DBK : e % DBM, ak = a_kfast ? e % DBK : e / DBM;
+			As[ak][am] = ra[i];
+			const int bn = b_kfast ? e / DBK : e % DBN, bk = b_kfast ? e % DBK : e / DBN;
+			Bs[bk][bn] = rb[i];
+		}
+	};
+	load(0);
+	for (int64_t k0 = 0; k0 < K; k0 += DBK) {
+		stash();
 		__syncthreads();
+		if (k0 + DBK < K) load(k0 + DBK);   // in flight during the MFMAs below
 #pragma unroll
 		for (int ks = 0; ks < DBK / 4; ++ks) {
 			double a[2], b[2];

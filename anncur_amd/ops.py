@@ -603,6 +603,52 @@ def ivf_scan(Xs, offsets, ids, Q, probe, k):
 
 
 @_on_device
+def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 30):
+	"""The same search as ivf_scan for MANY queries: pairs (query, probe slot) sorted by list, every list one small fp32-MFMA GEMM against
+	its pairs' queries (anncur_ivf_group_scores), then the exact scan over each query's nprobe lists side by side and the column -> id map.
+	sizes_host: the lists' lengths on the host (numpy int64, known since add()).  One small D2H (pairs per list) builds the tile worklist."""
+	_dev(Xs, offsets, ids, Q, probe)
+	lib = _lib.load()
+	nq_all, dp = Q.shape
+	probe = probe.to(torch.int32).contiguous()
+	nprobe, nlist = probe.shape[1], sizes_host.shape[0]
+	lmax = int(max(int(sizes_host.max()), 1))
+	lmax = -(-lmax // 8) * 8
+	k_eff = min(k, nprobe * lmax)
+	val = torch.empty((nq_all, k), dtype=torch.float32, device=Q.device)
+	idx = torch.empty((nq_all, k), dtype=torch.int32, device=Q.device)
+	step = max(64, min(nq_all, max_bytes // (nprobe * lmax * 4)))
+	vt = -(-sizes_host // 64)                                        # 64-vector tiles per list
+	for q0 in range(0, nq_all, step):
+		q1 = min(nq_all, q0 + step)
+		nq = q1 - q0
+		pr = probe[q0:q1].contiguous()
+		cnt, poff, pair_ids = ivf_build_lists(pr.reshape(-1).clamp(min=0), nlist)     # (probe slots are valid list ids here: nprobe <= nlist)
+		cp = cnt.cpu().numpy().astype(np.int64)
+		qt = -(-cp // 64)
+		lists = np.repeat(np.arange(nlist), qt * vt)
+		if lists.size:
+			start = np.cumsum(qt * vt) - qt * vt
+			within = np.arange(lists.size) - np.repeat(start, qt * vt)
+			tiles = np.stack([lists, within // np.repeat(vt, qt * vt), within % np.repeat(vt, qt * vt)], axis=1).astype(np.int32)
+		else:
+			tiles = np.zeros((0, 3), dtype=np.int32)
+		tiles_dev = torch.as_tensor(tiles).to(Q.device)
+		S = torch.full((nq, nprobe * lmax), float("-inf"), dtype=torch.float32, device=Q.device)
+		Qc = Q[q0:q1]
+		check(lib.anncur_ivf_group_scores(_p(Xs), _ld(Xs), dp, _p(offsets), _p(Qc), _ld(Qc), nprobe, _p(pair_ids), _p(poff), _p(tiles_dev), tiles.shape[0], lmax,
+										  _p(S), _stream()), "ivf_group_scores")
+		v, c = rowwise_topk(S, k_eff)
+		out_i = idx[q0:q1, :k_eff] if k_eff == k else torch.empty((nq, k_eff), dtype=torch.int32, device=Q.device)
+		check(lib.anncur_ivf_map_ids(_p(c), _p(v), nq, k_eff, lmax, _p(pr), nprobe, _p(offsets), _p(ids), _p(out_i), _stream()), "ivf_map_ids")
+		val[q0:q1, :k_eff] = v
+		if k_eff < k:
+			idx[q0:q1, :k_eff] = out_i
+			val[q0:q1, k_eff:] = float("-inf"); idx[q0:q1, k_eff:] = -1
+	return TopK(val, idx)
+
+
+@_on_device
 def copy_to_mapped_host(src, pinned_host):
 	"""Device kernel copy of `src` (CUDA tensor) into a PINNED host tensor (mapped into the device address space by the HIP
 	runtime): graph-capturable, no copy engine.  The caller synchronises (event) before reading `pinned_host`."""

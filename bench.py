@@ -74,6 +74,35 @@ def self_launch(args):
 	raise SystemExit(proc.returncode if proc.returncode != 0 or lines else 1)
 
 
+def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
+	"""models/nearest_nbr.py:40-52 at the size of the reference's hard-negative mining (utils/data_process.py:343-365: every mention queries
+	the entity index): n clustered vectors, nlist = floor(sqrt(n)), nprobe = floor(sqrt(nlist)); batched list-grouped search on the fp32
+	matrix cores.  Reported against the fp32 matrix peak (157 TFLOP/s): algorithmic flops = 2 x vectors scanned x d."""
+	from anncur_amd import ops
+	from anncur_amd.nearest_nbr import build_flat_or_ivff_index
+	g = torch.Generator(device=device).manual_seed(seed + 99)
+	C = torch.randn(200, d, generator=g, device=device)
+	X = (C[torch.randint(0, 200, (n,), generator=g, device=device)] + 0.7 * torch.randn(n, d, generator=g, device=device)).cpu().numpy()
+	Qv = (C[torch.randint(0, 200, (nq,), generator=g, device=device)] + 0.7 * torch.randn(nq, d, generator=g, device=device)).cpu().numpy()
+	t0 = time.perf_counter(); index = build_flat_or_ivff_index(X, force_exact_search=False); torch.cuda.synchronize(); build_s = time.perf_counter() - t0
+	index.search(Qv, k); torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for _ in range(3): D, I = index.search(Qv, k)
+	torch.cuda.synchronize(); search_s = (time.perf_counter() - t0) / 3
+	sizes = index._sizes
+	probe = ops.score_topk_dense(torch.as_tensor(Qv).to(device), index.centroids, index.nprobe).indices.cpu().numpy()
+	scanned = float(sizes[probe].sum())
+	pairs = np.bincount(probe.reshape(-1), minlength=index.nlist)
+	read_bytes = float((-(-pairs // 64) * sizes).sum()) * index._dp * 4       # a list's vectors are read once per 64-query tile
+	flops = 2.0 * scanned * d
+	return {"n": n, "d": d, "nq": nq, "k": k, "nlist": index.nlist, "nprobe": index.nprobe, "build_s": build_s, "search_ms": 1e3 * search_s,
+			"queries_per_s": nq / search_s, "vectors_scanned_per_query": scanned / nq,
+			"roofline": {"bound": "mfma", "kernel": "ivf_group_scores_kernel (fp32 MFMA, one GEMM per inverted list)", "achieved": flops / search_s / 1e12, "peak": 157.3,
+						 "unit": "TFLOP/s", "frac": flops / search_s / 1e12 / 157.3, "what": "whole search() call incl. probe, pair sort, exact scan of the scores, host copies"},
+			"list_bytes_read_model": read_bytes, "list_bytes_per_query_model_unbatched": scanned * index._dp * 4 / nq,
+			"data": "synthetic clustered vectors (200 centres), host numpy in / out like FAISS", "parity": "unpinned (FAISS absent): recall-judged in tests/"}
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=None, help="default: WORLD_SIZE under torchrun, else 1")
@@ -86,6 +115,7 @@ def main():
 	ap.add_argument("--sustained-seconds", type=float, default=10.0, help="also loop the same step for this long and report it (DVFS-settled rate); 0 = skip")
 	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
 	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
+	ap.add_argument("--no-ivf", action="store_true", help="skip the ivf_search side-line (the IVF-flat branch of build_flat_or_ivff_index at the hard-negative-mining size)")
 	ap.add_argument("--seed", type=int, default=0)
 	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
 	ap.add_argument("--scan-mode", default="side", choices=["side", "chunks", "serial"],
@@ -406,6 +436,10 @@ def main():
 			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
 			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),
 		}
+
+	# ------------------------------------------------------------------ side-line: the IVF-flat branch at the hard-negative-mining size
+	if rank == 0 and world == 1 and not args.no_ivf:
+		out["ivf_search"] = ivf_sideline(device, args.seed)
 
 	# ------------------------------------------------------------------ CPU baseline: the oracle (reference-faithful loop) on a bounded sample
 	if rank == 0 and world == 1 and args.cpu_sample_queries > 0:

@@ -236,6 +236,19 @@ int anncur_ivf_list_means(const float *Xs, int64_t ldx, int32_t d, const int32_t
 int anncur_ivf_scan(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, const float *Q, int64_t ldq, int64_t nq,
                     const int32_t *probe, int32_t nprobe, int32_t k, float *out_val, int32_t *out_idx, void *stream);
 
+/* Batched IVF search (many queries, e.g. the reference's hard-negative mining, utils/data_process.py:343-365, where every mention
+ * queries the index): the (query, probe slot) pairs are sorted by list -- anncur_ivf_build_lists on the flattened probe array gives
+ * pair_offsets[nlist+1] and pair_ids (pair = q * nprobe + slot) -- and every list is scored against its pairs' queries as a small GEMM on
+ * the fp32 matrix cores, so a list's vectors are read once per 64 queries instead of once per query.  tiles int32[n_tiles x 3] =
+ * (list, 64-pair tile, 64-vector tile) worklist built by the host from the list / pair counts.  S float[nq * nprobe x lmax] (lmax >=
+ * longest list), pre-filled with -inf by the caller: S[pair][position in its list] = <query, vector>.  Then anncur_rowwise_topk over
+ * S viewed as [nq x nprobe * lmax] and anncur_ivf_map_ids (column -> id of the vector; -1 where the score is the -inf padding). */
+int anncur_ivf_group_scores(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const float *Q, int64_t ldq, int32_t nprobe,
+                            const int32_t *pair_ids, const int32_t *pair_offsets, const int32_t *tiles, int32_t n_tiles, int64_t lmax, float *S,
+                            void *stream);
+int anncur_ivf_map_ids(const int32_t *col, const float *val, int64_t nq, int32_t k, int64_t lmax, const int32_t *probe, int32_t nprobe,
+                       const int32_t *offsets, const int32_t *ids, int32_t *out_idx, void *stream);
+
 /* Index-build hint of anncur_score_topk_ex: bucket[i] in 0..n_buckets-1 by the squared norm of row i of the fp32 matrix A, largest
  * norms first (linear between the matrix' largest and smallest row norm); norms float[n_rows] and minmax2 uint32[2] are scratch
  * outputs.  anncur_ivf_build_lists(bucket, n_rows, n_buckets, ...) then returns the rows in coarse descending-norm order (a stable

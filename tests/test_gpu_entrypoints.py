@@ -186,6 +186,40 @@ def test_ivf_flat_index_branch(gpu):
 	assert torch.equal(again.centroids, index.centroids) and torch.equal(again._ids, index._ids)
 
 
+def test_ivf_batched_search_equals_the_per_query_scan(gpu):
+	"""Many queries (the reference's hard-negative mining, utils/data_process.py:343-365): pairs (query, probed list) grouped by list,
+	each list one fp32-MFMA GEMM (anncur_ivf_group_scores), exact scan over the lists side by side, column -> id map.  Same probed
+	lists, same exact fp32 inner products as the per-query kernel: same ids (boundary near-ties aside), scores equal to round-off;
+	padding when k exceeds the probed lists; ragged lists incl. an empty one."""
+	from anncur_amd.nearest_nbr import IVFFlatIPIndex
+	g = np.random.default_rng(11)
+	n, d, nq, k = 30000, 200, 1500, 20
+	centers = g.standard_normal((40, d)).astype(np.float32) * 2
+	X = (centers[g.integers(0, 40, n)] + g.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+	q = (centers[g.integers(0, 40, nq)] + g.standard_normal((nq, d)).astype(np.float32)).astype(np.float32)
+	index = IVFFlatIPIndex(d, 120, niter=4)
+	index.train(X); index.add(X)
+	index.nprobe = 9
+	index.batched_from = 10 ** 9
+	D0, I0 = index.search(q, k)                       # per-query kernel
+	index.batched_from = 1
+	D1, I1 = index.search(q, k)                       # batched
+	np.testing.assert_allclose(D1, D0, rtol=1e-5, atol=1e-4)
+	assert np.mean([len(set(a) & set(b)) / k for a, b in zip(I0.tolist(), I1.tolist())]) > 0.9995
+	np.testing.assert_allclose(D1, np.take_along_axis(q @ X.T, I1, axis=1), rtol=1e-5, atol=1e-4)
+	assert (D1[:, :-1] >= D1[:, 1:]).all() and all(len(set(r.tolist())) == k for r in I1)
+	# one probed list, k larger than it: FAISS-style (-FLT_MAX, -1) padding from the batched path too
+	index.nprobe = 1
+	D2, I2 = index.search(q[:300], 600)
+	off = index._offsets.cpu().numpy()
+	C = index.centroids.cpu().numpy()
+	first = np.argmax(q[:300] @ C.T, axis=1)
+	sizes = np.diff(off)[first]
+	for j in range(0, 300, 23):
+		m = min(int(sizes[j]), 600)
+		assert (I2[j, :m] >= 0).all() and (I2[j, m:] == -1).all() and (D2[j, m:] == np.finfo(np.float32).min).all()
+
+
 # ------------------------------------------------------------------ row-sharded evaluation: 2 ranks sharing the one GPU, gloo
 def _sharded_worker(rank, world, port, q):
 	import torch.distributed as dist

@@ -927,6 +927,9 @@ __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, cons
 		const u32x4 *tb = reinterpret_cast<const u32x4 *>(smem + cur * Cfg::TILE_BYTES);
 #pragma unroll
 		for (int s = 0; s < KSTEPS; ++s) {
+			// (Kp = 512: a scheduling fence every 8 k-steps -- left alone hipcc hoisted so many fragment reads that error_kernel<512, float>
+			//  spilled ten registers)
+			if (KSTEPS > 16 && s > 0 && (s & 7) == 0) __builtin_amdgcn_sched_barrier(0);
 			const u32x4 w = tb[r * CPR + swz<CPR>(r, 2 * s + h)];
 			const bf16x8 a = __builtin_bit_cast(bf16x8, w);
 #pragma unroll

@@ -335,6 +335,19 @@ class _Workspace:
 		return buf[off:off + nbytes]
 
 
+class _ScoreScratch:
+	"""Grow-only fp32 scratch per device (the batched IVF search's score matrix)."""
+	_bufs = {}
+
+	@classmethod
+	def get(cls, n, device):
+		key = (device.type, device.index)
+		buf = cls._bufs.get(key)
+		if buf is None or buf.numel() < n:
+			cls._bufs[key] = buf = torch.empty(n, dtype=torch.float32, device=device)
+		return buf[:n]
+
+
 def fused_supported(Q, I, Kp, k):
 	return _kp_ok(Kp) and bool(_lib.load().anncur_score_topk_supported(Q, I, Kp, k))
 
@@ -634,7 +647,8 @@ def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 3
 		else:
 			tiles = np.zeros((0, 3), dtype=np.int32)
 		tiles_dev = torch.as_tensor(tiles).to(Q.device)
-		S = torch.full((nq, nprobe * lmax), float("-inf"), dtype=torch.float32, device=Q.device)
+		S = _ScoreScratch.get(nq * nprobe * lmax, Q.device).view(nq, nprobe * lmax)   # grow-only scratch: a fresh 100s-of-MB allocation per call cost more than the search
+		S.fill_(float("-inf"))
 		Qc = Q[q0:q1]
 		check(lib.anncur_ivf_group_scores(_p(Xs), _ld(Xs), dp, _p(offsets), _p(Qc), _ld(Qc), nprobe, _p(pair_ids), _p(poff), _p(tiles_dev), tiles.shape[0], lmax,
 										  _p(S), _stream()), "ivf_group_scores")

@@ -273,14 +273,17 @@ def splits_grids(n_ent, base_top_k_retr=(1, 10, 50, 100, 200, 500, 1000), base_n
 	return top_k_retr_vals, n_anc
 
 
-def run_eval_method_cur(A_test, A_train, seed, top_k_vals, top_k_retr_vals, n_ent_anchors_vals):
+def run_eval_method_cur(A_test, A_train, seed, top_k_vals, top_k_retr_vals, n_ent_anchors_vals, eval_only=None):
 	"""..._w_fixed_train_test_splits.py:286-303 (index + approximation) and :399-429 (sweep),
-	for eval_method == "cur", with the grids passed in."""
+	for eval_method == "cur", with the grids passed in.  eval_only (test convenience): anchor counts to evaluate -- the anchor
+	stream is still drawn for EVERY count of the grid, in order, as the reference does."""
 	n_train, n_ent = A_train.shape
 	rng = np.random.default_rng(seed=seed)                                             # :289
 	approx = {}
 	for n_anc in n_ent_anchors_vals:                                                   # :293
 		anc = select_anchors(rng, n_ent, n_anc)                                        # :295
+		if eval_only is not None and n_anc not in eval_only:
+			continue
 		cols = A_train[:, anc]                                                         # :297
 		cur = CURApproxOracle(rows=A_train, cols=cols, row_idxs=np.arange(n_train), col_idxs=anc,
 							  approx_preference="rows")                               # :298

@@ -16,7 +16,7 @@ qt = 2 if kp <= 256 else 1
 # the sweep runs as two filter variants (ballot / exec, chosen per stage by plan_stages): both are the sweep kernel of the roofline
 sweep_variants = [f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 1, 16, true, false, {qt}>"]
 sweep, prepass = f"score_kernel<{kp}, sweep>", f"score_kernel<{kp}, 0, 16, false, false, {qt}>"
-names = sweep_variants + [prepass, "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false", "select_wave_kernel<true", "select_stream_kernel<false",
+names = sweep_variants + [prepass, f"score16_kernel<{kp}>", f"score_kernel<{kp}, 1, 16, false, false, 1>", "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false", "select_wave_kernel<true", "select_stream_kernel<false",
 		 "select_stream_kernel<true", "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel", "gemm_f64_kernel"]
 def key_of(n): return sweep if n in sweep_variants else n
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -24,9 +24,11 @@ for f in glob.glob(root + "/pmc_*/*counter_collection.csv"):
 	for r in csv.DictReader(open(f)):
 		for n in names:
 			if n in r["Kernel_Name"]:
-				acc[key_of(n)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-				if r["Counter_Name"] in ("FETCH_SIZE", "SQ_WAVE_CYCLES"):
-					acc[key_of(n)]["_vgpr"].append(float(r["VGPR_Count"])); acc[key_of(n)]["_lds"].append(float(r["LDS_Block_Size"]))
+				keys = [key_of(n)] + ([n] if n in sweep_variants else [])   # the sweep as a whole AND each filter variant (= sweep stage) on its own
+				for kk in keys:
+					acc[kk][r["Counter_Name"]].append(float(r["Counter_Value"]))
+					if r["Counter_Name"] in ("FETCH_SIZE", "SQ_WAVE_CYCLES"):
+						acc[kk]["_vgpr"].append(float(r["VGPR_Count"])); acc[kk]["_lds"].append(float(r["LDS_Block_Size"]))
 				break
 out = {n: {c: round(sum(v) / len(v), 1) for c, v in d.items()} | {"launches_seen": len(next(iter(d.values())))} for n, d in acc.items()}
 stats = {}
@@ -44,7 +46,23 @@ for f in glob.glob(root + "/stats/*kernel_stats.csv"):
 					stats[sweep] = cur
 				else:
 					stats[n] = cur
-res = {"config": cfg, **shape, "pmc_avg_per_launch": out, "kernel_stats": stats}
+# per sweep variant (the plan runs the exec-mask filter in the first stage, the ballot filter in the later ones): what the wave cycles went to
+per_variant = {}
+for n in sweep_variants:
+	c, st = out.get(n), stats.get(n)
+	if not c or not st: continue
+	row = {"avg_us": st["avg_us"], "calls": st["calls"]}
+	if "SQ_WAVE_CYCLES" in c:
+		row["wait_any_share_of_wave_cycles"] = round(c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)
+		row["active_inst_share_of_wave_cycles"] = round(c.get("SQ_ACTIVE_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)
+	if "GRBM_GUI_ACTIVE" in c:
+		cyc = c["GRBM_GUI_ACTIVE"] / 8
+		row["clock_ghz_from_grbm"] = round(cyc / (st["avg_us"] * 1e-6) / 1e9, 3)
+		row["mfma_pipe_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc, 3)
+		row["valu_insts_per_mfma"] = round(c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 1) / 32, 1), 2)
+		row["salu_insts_per_mfma"] = round(c.get("SQ_INSTS_SALU", 0) / max(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 1) / 32, 1), 2)
+	per_variant[n] = row
+res = {"config": cfg, **shape, "pmc_avg_per_launch": out, "kernel_stats": stats, "sweep_per_variant": per_variant}
 sw = out.get(sweep)
 if sw and "FETCH_SIZE" in sw and "WRITE_SIZE" in sw:
 	rd, wr = 2 * sw["FETCH_SIZE"] * 1024, sw["WRITE_SIZE"] * 1024

@@ -155,7 +155,7 @@ def test_entry_B_default_grids_including_zero_anchors():
 		pytest.skip("no GPU")
 	from anncur_amd import harness
 	from oracle import cur_oracle as O
-	A_train, A_test = O.synth_protocol_b(40, 30, 1200, rank=16, noise=0.05, seed=11)
+	A_train, A_test = O.synth_protocol_b(40, 1000, 1200, rank=16, noise=0.05, seed=11)   # 1000 queries: a wrong anchor stream cannot hide in the tolerance
 	grids = harness.default_grids_B(1200, "cur")
 	assert grids["n_ent_anchors_vals"][0] == 0 and grids["top_k_retr_vals"][0] == 0
 	got = harness.run_eval_method_cur(A_test.cuda(), A_train.cuda(), 0, grids)
@@ -165,12 +165,13 @@ def test_entry_B_default_grids_including_zero_anchors():
 	assert cell0["exact_vs_reranked_approx_retvr~common_mean"] == pytest.approx(round(want0, 4), abs=1e-4)
 	# the oracle over the same anchor-count sequence (one rng stream) for a few cells with at least as many train rows as anchors
 	anc_vals = grids["n_ent_anchors_vals"]
-	want = O.run_eval_method_cur(A_test, A_train, seed=0, top_k_vals=[1, 10], top_k_retr_vals=[100], n_ent_anchors_vals=[a for a in anc_vals if a > 0])
+	want = O.run_eval_method_cur(A_test, A_train, seed=0, top_k_vals=[1, 10], top_k_retr_vals=[100], n_ent_anchors_vals=[a for a in anc_vals if a > 0],
+								 eval_only=(10, 20, 30))
 	for n_anc in (10, 20, 30):
 		for k in (1, 10):
 			g = got[f"top_k={k}"]["k_retvr=100"][f"anc_n_m=40_anc_n_e={n_anc}"][KEY]
 			w = want[f"top_k={k}"]["k_retvr=100"][f"anc_n_m=40_anc_n_e={n_anc}"][KEY]
-			assert g == pytest.approx(w, abs=0.04), (n_anc, k, g, w)          # 30 queries: one swapped near-tie moves the mean by 1/300
+			assert g == pytest.approx(w, abs=5e-3), (n_anc, k, g, w)          # 1000 queries: a swapped boundary near-tie moves the mean by 1e-3 at most
 	assert "k_retvr=0" not in got.get("top_k=1", {})                          # k_retvr = 0 < top_k: skipped like the reference
 
 

@@ -325,7 +325,7 @@ def test_entry_point_B_other_methods_match_reference_restatement(gpu, tmp_path):
 	from eval import run_retrieval_eval_wrt_exact_crossenc_w_fixed_train_test_splits as epB
 	from oracle import cur_oracle as O
 	g = torch.Generator().manual_seed(11)
-	n_ent, n_train, n_test, r, n_fixed = 700, 50, 45, 12, 40
+	n_ent, n_train, n_test, r, n_fixed = 700, 50, 1200, 12, 40   # (1200 queries: one swapped boundary near-tie moves a mean by < 1e-3)
 	Z = torch.randn(r, n_ent, generator=g)
 	A_train = torch.randn(n_train, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_train, n_ent, generator=g)
 	A_test = torch.randn(n_test, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_test, n_ent, generator=g)
@@ -362,7 +362,7 @@ def test_entry_point_B_other_methods_match_reference_restatement(gpu, tmp_path):
 	anc_ids = topk_ents[:n_fixed].numpy()
 	S_fix = A_test[:, anc_ids] @ e2e[:, :n_fixed].t()
 	f1 = epB.main(common + ["--eval_method", "fixed_anc_ent", "--e2e_fname", str(tmp_path / "e2e.pkl"), "--n_fixed_anc_ent", str(n_fixed), "--misc", "fae"])
-	check(f1, sweep({a: S_fix for a in ancs}), 0.03)
+	check(f1, sweep({a: S_fix for a in ancs}), 5e-3)
 	# fixed_anc_ent_cur (splits.py:327-358): R = e2e[:, :n].T, anchors from rng(0) consumed over the anchor counts, U = pinv(R[:, anc])
 	R = e2e[:, :n_fixed].t()
 	rng = np.random.default_rng(seed=0)
@@ -372,7 +372,7 @@ def test_entry_point_B_other_methods_match_reference_restatement(gpu, tmp_path):
 		U = torch.tensor(np.linalg.pinv(R[:, anc].numpy()))
 		approx[n_anc] = A_test[:, anc] @ (U @ R)
 	f2 = epB.main(common + ["--eval_method", "fixed_anc_ent_cur", "--e2e_fname", str(tmp_path / "e2e.pkl"), "--n_fixed_anc_ent", str(n_fixed), "--misc", "faec"])
-	check(f2, sweep(approx), 0.05)
+	check(f2, sweep(approx), 5e-3)
 	# bienc (splits.py:283): scores = mention_embeds @ label_embeds.T from precomputed embeddings
 	f3 = epB.main(common + ["--eval_method", "bienc", "--mention_embeds_file", str(tmp_path / "ment.npy"), "--entity_embeds_file", str(tmp_path / "ent.npy"), "--misc", "bi"])
-	check(f3, sweep({a: ment_emb @ ent_emb.t() for a in ancs}), 0.03)
+	check(f3, sweep({a: ment_emb @ ent_emb.t() for a in ancs}), 5e-3)

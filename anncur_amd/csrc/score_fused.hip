@@ -69,7 +69,9 @@ struct FusedCfg {
 	static constexpr int QUEUE_BYTES = QT * QDEPTH * 256 * 8;
 	static constexpr int QUEUE_OFF = (2 * TILE_BYTES + 16383) / 16384 * 16384;  // rings are 16 KiB aligned (filter_one)
 	static constexpr int TICKET_OFF = QUEUE_OFF + QUEUE_BYTES;        // two 32-bit words: the chunk tickets thread 0 hands to its workgroup (dynamic tile schedule)
-	static constexpr int LDS_BYTES = TICKET_OFF + 16;                 // the prepass kernel uses only the tile part
+	// (Kp = 512: two 32 KiB tile buffers + 16 KiB of rings are exactly half a CU's LDS -- 16 bytes more and only ONE workgroup fits per CU
+	//  (measured: the sweep of cfg4 20 % slower); that body keeps static tile shares and no ticket words)
+	static constexpr int LDS_BYTES = TICKET_OFF + (KP >= 512 ? 0 : 16);  // the prepass kernel uses only the tile part
 	static constexpr int NAOFF = KSTEPS < 8 ? KSTEPS : 8;             // fragment address registers of the staggered sweep (see stagger_tile)
 };
 
@@ -581,11 +583,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	// BEFORE the one the ticket is for (atomic in flight during a whole tile), hands it over through LDS at that tile's barrier.
 	int t_cur = j_begin < j_end ? j_begin : -1, t_cend = j_end, t_step = ts, t_next_chunk = -1, t_prev = -1;
 	bool ticket_pending = false;
-	const bool dyn = MODE == 1 && QT == 2 && p.chunk_tiles > 0;
+	constexpr bool STAG = MODE == 1 && (QT == 2 || (KP == 512 && !INL));   // the bodies that take the ticket schedule and the hand-placed DMA
+	const bool dyn = STAG && KP < 512 && p.chunk_tiles > 0;
 	// two LDS words used in turn: a ticket is published at the end of one step and read at the head of the next, and nothing but program
 	// order separates that read from the NEXT publication (possible one step later when a chunk is a single tile)
 	uint32_t ticket_slot = lds_addr(smem + Cfg::TICKET_OFF);
-	if constexpr (MODE == 1 && QT == 2) {
+	if constexpr (STAG) {
 		if (dyn) {
 			if (tid == 0) {
 				const uint32_t c = atomicAdd(p.chunk_ctr + rb, 2u);   // the first chunk and the look-ahead
@@ -606,8 +609,8 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	}
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);             // (the compiler does not know tid >> 6 is wave-uniform)
 	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
-	uint32_t dma_off[(MODE == 1 && QT == 2) ? Cfg::TILE_BYTES / 4096 : 1];
-	if constexpr (MODE == 1 && QT == 2) {
+	uint32_t dma_off[STAG ? Cfg::TILE_BYTES / 4096 : 1];
+	if constexpr (STAG) {
 		tile_dma_offsets<KP>(dma_off, wave_u, lane);
 #ifdef ANNCUR_V_OLD_DMA
 		if (t_cur >= 0) tile_dma<KP>(p.Et, t_cur, smem, wave, lane);
@@ -650,13 +653,8 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #else
 #define STAGGER_DMA(NX, CUR) tile_dma_s<KP>(p.Et, (NX), lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off)
 #endif
-// (Round 3 also tried draining by occupancy -- any lane's ring at 3 entries -- instead of the planned window: +4 % sweep time on the bench
-//  matrices, same box, alternating; ANNCUR_V_ADAPT builds it again.)
-#ifdef ANNCUR_V_ADAPT
-#define STAGGER_RING_FILLING (__ballot((qcnt[0] | qcnt[1]) >= (3u << 11)) != 0ull)
-#else
-#define STAGGER_RING_FILLING false
-#endif
+// (Round 3 tried draining by occupancy as well -- a ballot "some lane's ring holds >= 3 / >= 4 entries" per step, beside or instead of the
+//  planned window: both cost 4 % of the sweep at cfg2, same box, alternating -- the check itself, not the drains.  The planned window stays.)
 #define STAGGER_STEP(CUR)                                                                                                       \
 		do {                                                                                                                    \
 			const int J = t_cur;                                                                                                \
@@ -672,7 +670,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if (nx >= 0) STAGGER_DMA(nx, CUR);                                                                                  \
 			uint32_t ticket = 0;                                                                                                \
 			if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);  /* in flight until ticket_wait() below */          \
-			if (t_prev < dense_end || --flush_in2 <= 0 || STAGGER_RING_FILLING) {                                                \
+			if (t_prev < dense_end || --flush_in2 <= 0) {                                                                       \
 				flush_in2 = p.flush_tiles;                                                                                      \
 				/* (a raw ring holds one tile: sub-tile 0 of the previous tile, sub-tile 1 of the one before) */                \
 				flush_queue<Cfg::QDEPTH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_prev);    \
@@ -700,13 +698,80 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			STAGGER_STEP(1);
 		}
 #undef STAGGER_STEP
-#undef STAGGER_DMA
-#undef STAGGER_RING_FILLING
 		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_pp);  // keep one tile's hits per queue window
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
 			filter_one<Cfg::QDEPTH>(acc1[e], e, tau1_prev, item0_prev, lq1, qcnt[1]);
 		mark_wrapped_raw<Cfg::QDEPTH>(acc1, lq1, qcnt[1]);  // (its ring was just drained: exact in every split)
+		last_item0 = item0_prev;
+	} else if constexpr (STAG && QT == 1) {
+		// ---- software-pipelined sweep for Kp = 512 (stagger1_tile) on the ticket schedule: tile loop unrolled by two (buffer parity =
+		// immediate offset); even steps accumulate into accA and filter accB, odd steps the other way round
+		f32x16 accA, accB;
+#pragma unroll
+		for (int e = 0; e < 16; ++e) { accA[e] = 0.f; accB[e] = 0.f; }
+		float tau_prev = INFINITY;   // no previous tile yet: the filter never fires
+		uint32_t item0_prev = 0, item0_pp = 0;
+		uint32_t aoff8[8];
+#pragma unroll
+		for (int s = 0; s < 8; ++s) aoff8[s] = lds_addr(smem) + (uint32_t)(r * CPR + ((2 * s + h) ^ (r & 15))) * 16u;
+		int flush_in2 = p.flush_tiles;
+		__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger1_tile() counts LDS reads
+#define STAGGER1_STEP(CUR, ACC, ACCP)                                                                                           \
+		do {                                                                                                                    \
+			const int J = t_cur;                                                                                                \
+			if (ticket_pending) {                                                                                               \
+				const uint32_t c = lds_load_u32_uniform(ticket_slot);                                                           \
+				t_next_chunk = c < (uint32_t)p.n_chunks ? p.tile_begin + (int)c * p.chunk_tiles : -1;                           \
+				ticket_pending = false;                                                                                         \
+				ticket_slot ^= 4u;                                                                                              \
+			}                                                                                                                   \
+			int nx = J + t_step;                                                                                                \
+			bool crossed = false;                                                                                               \
+			if (nx >= t_cend) { nx = t_next_chunk; crossed = dyn && nx >= 0; }                                                  \
+			if (nx >= 0) STAGGER_DMA(nx, CUR);                                                                                  \
+			uint32_t ticket = 0;                                                                                                \
+			if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);                                                     \
+			if (t_prev < dense_end || --flush_in2 <= 0) {                                                                       \
+				flush_in2 = p.flush_tiles;                                                                                      \
+				/* (a raw ring holds the tile before the previous one, filtered during the previous step) */                    \
+				flush_queue<Cfg::QDEPTH, FLUSH_BATCH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_pp); \
+			}                                                                                                                   \
+			stagger1_tile<KP, CUR>(aoff8, xb[0], ACC, ACCP, tau_prev, item0_prev, lq0, qcnt[0], J < dense_end || every_tile);   \
+			tau_prev = tau[0]; item0_pp = item0_prev; item0_prev = (uint32_t)J * TILE_I + 4 * h;                                \
+			ticket_wait(ticket);                                                                                                \
+			if (crossed) {                                                                                                      \
+				if (tid == 0) {                                                                                                 \
+					lds_store_u32(ticket_slot, ticket);                                                                         \
+					if (p.chunk_owner && ticket < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + ticket] = (uint8_t)split; \
+					__builtin_amdgcn_s_waitcnt(0xC07F);                                                                         \
+				}                                                                                                               \
+				ticket_pending = true;                                                                                          \
+				t_cend = min(nx + p.chunk_tiles, p.tile_end);                                                                   \
+			}                                                                                                                   \
+			__syncthreads();                                                                                                    \
+			t_prev = J; t_cur = nx;                                                                                             \
+		} while (0)
+		bool last_in_a = false;  // (uniform) which accumulator holds the last tile
+		while (t_cur >= 0) {
+			STAGGER1_STEP(0, accA, accB);
+			last_in_a = true;
+			if (t_cur < 0) break;
+			STAGGER1_STEP(1, accB, accA);
+			last_in_a = false;
+		}
+#undef STAGGER1_STEP
+#undef STAGGER_DMA
+		flush_queue<Cfg::QDEPTH, FLUSH_BATCH>(lq0, qcnt[0], seg0, ncand[0], (uint32_t)p.capg, (uint32_t)p.I, tau[0], item0_pp);
+		if (last_in_a) {  // drain: the last tile (its ring was just drained: the raw path is exact in every split)
+#pragma unroll
+			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accA[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
+			mark_wrapped_raw<Cfg::QDEPTH>(accA, lq0, qcnt[0]);
+		} else {
+#pragma unroll
+			for (int e = 0; e < 16; ++e) filter_one<Cfg::QDEPTH>(accB[e], e, tau_prev, item0_prev, lq0, qcnt[0]);
+			mark_wrapped_raw<Cfg::QDEPTH>(accB, lq0, qcnt[0]);
+		}
 		last_item0 = item0_prev;
 	} else if constexpr (MODE == 1 && QT == 1 && KP >= 128 && !INL) {  // (INL = the plain loop, kept for A/B in the experiments build)
 		// ---- software-pipelined sweep for Kp = 512 (stagger1_tile): tile loop unrolled by two (buffer parity = immediate offset);
@@ -1400,9 +1465,10 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	// Dynamic tile schedule (staggered 32x32x16 sweep, Kp <= 256): tickets of CHUNK_TILES tiles per query row block instead of fixed shares
 	// (score_kernel).  Workgroups per row block: enough to fill every slot (rounded UP -- a workgroup that finds no ticket left ends at
 	// once), at most 32 so that the 2 S segments of a query fit the wave-level select.
-	P.chunk = (P.QT == 2 && !mfma16) ? CHUNK_TILES : 0;
+	const bool ticketed = P.QT == 2 && !mfma16;   // the body with the ticket schedule (Kp = 512 has no LDS to spare for the ticket words: FusedCfg)
+	P.chunk = ticketed ? CHUNK_TILES : 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = (P.QT == 2 && !mfma16) ? atoi(dbg) : 0;
+	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = ticketed ? atoi(dbg) : 0;
 #endif
 	int S = P.chunk > 0 ? (slots + P.n_rb - 1) / P.n_rb : slots / P.n_rb;
 	if (P.chunk > 0 && k <= WQ_K2 && S > WAVE / 2) S = WAVE / 2;
@@ -1703,9 +1769,6 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		p.tile_step = tile_step;
-#ifdef ANNCUR_V_ADAPT
-		if (Cfg::QT == 2 && P.lg == 2 && p.flush_tiles > 1) p.flush_tiles = 8;
-#endif
 		if (chunk > 0) {
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
 			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb;

@@ -276,14 +276,20 @@ def approx_error_packed(Xp, Etp, A_exact, n_items):
 
 # ------------------------------------------------------------------ a7/a8
 @_on_device
-def rowwise_topk(A, k):
+def rowwise_topk(A, k, out=None):
 	"""Exact torch.topk(A, k, dim=1) on the device: (values f32 [Q,k], indices int32 [Q,k]),
-	sorted descending, ties -> smaller index."""
+	sorted descending, ties -> smaller index.  out: (values, indices) contiguous [Q, k] tensors to write into (row slices of a larger
+	result, when a matrix is scanned in several launches)."""
 	_dev(A)
 	A = _rowmajor(A)
 	Q, I = A.shape
-	val = torch.empty((Q, k), dtype=torch.float32, device=A.device)
-	idx = torch.empty((Q, k), dtype=torch.int32, device=A.device)
+	if out is not None:
+		val, idx = out
+		if tuple(val.shape) != (Q, k) or tuple(idx.shape) != (Q, k) or val.dtype != torch.float32 or idx.dtype != torch.int32 or not val.is_contiguous() or not idx.is_contiguous():
+			raise ValueError("rowwise_topk: out must be contiguous (float32 [Q, k], int32 [Q, k])")
+	else:
+		val = torch.empty((Q, k), dtype=torch.float32, device=A.device)
+		idx = torch.empty((Q, k), dtype=torch.int32, device=A.device)
 	check(_lib.load().anncur_rowwise_topk(_p(A), _dt(A), Q, I, _ld(A), k, _p(val), _p(idx), _stream()), "rowwise_topk")
 	return TopK(val, idx)
 

@@ -120,7 +120,7 @@ def main():
 	ap.add_argument("--no-ivf", action="store_true", help="skip the ivf_search side-line (the IVF-flat branch of build_flat_or_ivff_index at the hard-negative-mining size)")
 	ap.add_argument("--seed", type=int, default=0)
 	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
-	ap.add_argument("--scan-mode", default="side", choices=["side", "chunks", "serial"],
+	ap.add_argument("--scan-mode", default="side", choices=["side", "tail", "chunks", "serial"],
 					help="how the exact scan is scheduled against the retrieval: side = on a second stream from the start of the step, joined before the overlap "
 						 "count; chunks = anncur_eval_topk (row chunks forked beside the retrieval's latency-bound launches); serial = one stream")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
@@ -210,11 +210,35 @@ def main():
 
 	if args.no_overlap:
 		args.scan_mode = "serial"
-	side = ops.aux_stream(device) if args.scan_mode == "side" else None
+	side = ops.aux_stream(device) if args.scan_mode in ("side", "tail") else None
+	rounds_rows = int(os.environ.get("ANNCUR_BENCH_ROUND_ROWS", "4096"))
+
+	def gpu_step_tail():
+		# The exact scan runs one wave per row and keeps `rounds_rows` rows in flight; a launch costs whole rounds: a FULL round is
+		# bandwidth-bound (4096 rows of 200 KB: 145 us = 5.7 TB/s), a partial one is latency-bound (92 us however few rows).  So: the
+		# full rounds first, alone on the chip; the partial round on the second stream beside the retrieval's latency-bound head
+		# (gather, prepass, threshold: 145 us that leave HBM and most CUs idle); the MFMA-bound sweeps then run undisturbed.
+		main = torch.cuda.current_stream()
+		ev = torch.empty((Q, k), dtype=torch.float32, device=device); ei = torch.empty((Q, k), dtype=torch.int32, device=device)
+		full = (Q // rounds_rows) * rounds_rows
+		if full > 0:
+			ops.rowwise_topk(A_test[:full], k, out=(ev[:full], ei[:full]))
+		if full < Q:
+			side.wait_stream(main)
+			with torch.cuda.stream(side):
+				ops.rowwise_topk(A_test[full:], k, out=(ev[full:], ei[full:]))
+		Xq = ops.gather_cols(A_test, anc_dev)
+		if Xq.shape[1] != Kp:
+			Xq = ops.pack_bf16(Xq, Kp)
+		approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
+		main.wait_stream(side)
+		return ops.overlap_counts(ei, approx.indices, cells)
 
 	def gpu_step():
+		if args.scan_mode == "tail":
+			return gpu_step_tail()
 		main = torch.cuda.current_stream()
-		if side is not None:
+		if args.scan_mode == "side":
 			# the exact scan (HBM-bound, a8) is independent of the retrieval until the overlap count: it starts on a second stream with the
 			# step and the hardware interleaves its workgroups with the retrieval's (measured, one box, alternating: 1.097 ms per step against
 			# 1.134 on one stream; cutting the scan into row chunks beside the retrieval's latency-bound launches -- --scan-mode chunks,
@@ -225,7 +249,7 @@ def main():
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
-		if side is not None:
+		if args.scan_mode == "side":
 			approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)   # a6 + a7 fused (item rows in the index's norm order)
 			main.wait_stream(side)
 		else:

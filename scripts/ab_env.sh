@@ -8,7 +8,7 @@ for r in $(seq 1 $rounds); do
   for spec in "$@"; do
     name=$(echo "$spec" | cut -d: -f1); lib=$(echo "$spec" | cut -d: -f2); envs=$(echo "$spec" | cut -d: -f3)
     if [ "$lib" = old ]; then
-      (cd build/r2_tree && python3 bench.py --sustained-seconds 0 --cpu-sample-queries 0 --steps 40 $AB_FLAGS 2>/dev/null) > gpurun_out/abenv/${name}__$r.json
+      (cd build/r2_tree && python3 bench.py --sustained-seconds 0 --cpu-sample-queries 0 --steps 40 ${AB_FLAGS//--no-ivf/} 2>/dev/null) > gpurun_out/abenv/${name}__$r.json
     else
       L=anncur_amd/lib/libanncur_hip_$lib.so; [ "$lib" = prod ] && L=anncur_amd/lib/libanncur_hip.so
       env ANNCUR_LIB=$L X=1 $envs python3 bench.py --sustained-seconds 0 --cpu-sample-queries 0 --steps 40 $AB_FLAGS 2>/dev/null > gpurun_out/abenv/${name}__$r.json

@@ -1071,7 +1071,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 	const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg, int S, SweepStages stg, int capg,
 	const uint16_t *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ Et, int64_t I, int KP, uint32_t k,
 	float *__restrict__ out_val, int32_t *__restrict__ out_idx, uint32_t *__restrict__ n_fallback,
-	const int32_t *__restrict__ hard_list, const uint32_t *__restrict__ hard_cnt, const float *__restrict__ tau_in, int tau_stride) {
+	const int32_t *__restrict__ hard_list, const uint32_t *__restrict__ hard_cnt, const float *__restrict__ tau_in, int tau_stride,
+	const int32_t *__restrict__ remap) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const SelState s = sel_carve<KMAX>(smem);
 	float *xq = reinterpret_cast<float *>(smem + SelCfg<KMAX>::LDS_BYTES);  // [KP], repair / fallback only
@@ -1204,7 +1205,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_candidates_kernel(
 			if ((it & 15) == 15) sel_maybe_compact<KMAX>(s, k, tau, tau_key);
 		}
 	}
-	sel_finish<KMAX>(s, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	sel_finish<KMAX>(s, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k, remap);
 	}
 }
 
@@ -1264,7 +1265,8 @@ template <bool TAU_ONLY, int KW = 128>
 __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg,
 														   int capg, int64_t Q, uint32_t k, float *__restrict__ out_val,
 														   int32_t *__restrict__ out_idx, uint32_t *__restrict__ hard_cnt,
-														   int32_t *__restrict__ hard_list, float *__restrict__ tau, int tau_stride, int prefilter) {
+														   int32_t *__restrict__ hard_list, float *__restrict__ tau, int tau_stride, int prefilter,
+														   const int32_t *__restrict__ remap) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id(), wave = threadIdx.x >> 6;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -1333,7 +1335,7 @@ __global__ __launch_bounds__(256) void select_wave_kernel(const uint2 *__restric
 		SEL_STAMP(3);
 		return;
 	}
-	wsel_finish<0, 4, WqCfg<KW>::E, true>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	wsel_finish<0, 4, WqCfg<KW>::E, true>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k, remap);
 	SEL_STAMP(3);
 }
 
@@ -1556,13 +1558,13 @@ int launch_tau_refine(const uint2 *cand, const uint32_t *seg_cnt, int nseg, int 
 			constexpr int lds = 4 * WaveSelLayout<WqCfg<KW>::CAP>::BYTES;                                                         \
 			if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<true, KW>, lds)) != ANNCUR_OK) return rc;            \
 			hipLaunchKernelGGL((select_wave_kernel<true, KW>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, capg, Q, \
-							   (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, tau, tau_stride, prefilter); \
+							   (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, tau, tau_stride, prefilter, (const int32_t *)nullptr); \
 		} while (0)
 		if (k <= WSEL_K && !stream_select_small()) LAUNCH_WTAU(128);
 		else {  // streaming radix select (select_stream.hpp): 1 KB of LDS per wave
 			constexpr int lds = 4 * StreamSelLayout::BYTES;
 			hipLaunchKernelGGL((select_stream_kernel<true, 2>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, capg, Q,
-							   (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, tau, tau_stride, prefilter);
+							   (uint32_t)k, (float *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, tau, tau_stride, prefilter, (const int32_t *)nullptr);
 		}
 #undef LAUNCH_WTAU
 	} else {
@@ -1583,7 +1585,7 @@ int launch_tau_refine(const uint2 *cand, const uint32_t *seg_cnt, int nseg, int 
 // take (overflowed segment, fewer than k candidates) lands in hard_list for the workgroup-level kernel, which repairs it exactly.
 int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const uint2 *cand, const uint32_t *seg_cnt, const uint16_t *X, int64_t ldx,
 				  const uint16_t *Et, int64_t Q, int64_t I, int KP, int k, float *out_val, int32_t *out_idx, unsigned char *ws, const float *tau,
-				  int tau_stride, hipStream_t st) {
+				  int tau_stride, hipStream_t st, const int32_t *remap = nullptr) {
 	int rc;
 #define LAUNCH_SELECT(KM)                                                                                              \
 	do {                                                                                                               \
@@ -1591,7 +1593,7 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 		if ((rc = anncur_ensure_dyn_lds((const void *)select_candidates_kernel<KM>, (int)lds)) != ANNCUR_OK) return rc; \
 		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, cand, seg_cnt, nseg, \
 						   P.S, stages, P.capg, X, ldx, Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt,      \
-						   P.n_stages > 1 ? tau : (const float *)nullptr, tau_stride);                                                   \
+						   P.n_stages > 1 ? tau : (const float *)nullptr, tau_stride, remap);                                            \
 	} while (0)
 	const int32_t *hard_list = nullptr;
 	const uint32_t *hard_cnt = nullptr;
@@ -1604,13 +1606,13 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 			constexpr int lds = 4 * WaveSelLayout<WqCfg<KW>::CAP>::BYTES;                                                         \
 			if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<false, KW>, lds)) != ANNCUR_OK) return rc;           \
 			hipLaunchKernelGGL((select_wave_kernel<false, KW>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, P.capg, Q, \
-							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0); \
+							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0, remap); \
 		} while (0)
 #define LAUNCH_SSEL(EE)                                                                                                           \
 		do {                                                                                                                      \
 			constexpr int lds = 4 * StreamSelLayout::BYTES;                                                                       \
 			hipLaunchKernelGGL((select_stream_kernel<false, EE>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, P.capg, Q, \
-							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0); \
+							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0, remap); \
 		} while (0)
 		if (k <= WSEL_K) { if (stream_select_small()) LAUNCH_SSEL(2); else LAUNCH_WSEL(128); }
 		else if (k <= 256) LAUNCH_SSEL(4);
@@ -1632,7 +1634,7 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 int launch_threshold(const FusedPlan &P, const float *gmax, int64_t Q, int k, unsigned char *ws, const float *&tau, int &tau_stride, hipStream_t st) {
 	if (P.n_groups <= 4096) {  // one wave per query, keys in LDS (kth_value_wave_kernel)
 		float *t = (float *)(ws + P.off_tau);
-		const int rc = anncur_internal_kth_value(gmax, Q, P.n_groups, P.n_groups, k, t, 1, st);
+		const int rc = anncur_internal_kth_value(gmax, Q, P.n_groups, P.n_groups, k, t, 1, st, /*coarse=*/1);   // (any lower bound on the k-th best will do)
 		tau = t; tau_stride = 1;
 		return rc;
 	}
@@ -1712,7 +1714,7 @@ int co_finish(CoScan *co, hipStream_t st) {
 
 template <int KP, int QTV = FusedCfg<KP>::QT>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
-				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr) {
+				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr, const int32_t *item_ids = nullptr) {
 	using Cfg = FusedCfg<KP, QTV>;
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
@@ -1734,7 +1736,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 #endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS  // (the -DANNCUR_TIMING_EXPERIMENTS build of scripts/fused_microbench.py only: results become wrong)
 	{ const char *dbg = getenv("ANNCUR_DEBUG_TAU_BIAS"); p.tau_bias = dbg ? (float)atof(dbg) : 0.f; }
-	if (getenv("ANNCUR_DEBUG_NOSTORE")) p.capg = 0;  // every candidate is dropped at the store
+	if (getenv("ANNCUR_DEBUG_NOSTORE")) { p.capg = 0; item_ids = nullptr; }  // every candidate is dropped at the store (the select then reads slots nobody wrote: no id map through them)
 #endif
 
 	const int chunk = (P.chunk > 0 && P.lg == 2 && Cfg::QT == 2) ? P.chunk : 0;   // (the 16x16x32 sweep and the one-sub-tile bodies keep static shares)
@@ -1845,7 +1847,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		stages.n_chunks[g] = chunk > 0 ? (P.stage_end[g] - prev + chunk - 1) / chunk : 0;
 		stages.owner[g] = (const uint8_t *)(ws + P.off_owner) + (size_t)g * owner_stride;
 	}
-	if ((rc = launch_select(P, P.lg * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
+	if ((rc = launch_select(P, P.lg * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st, item_ids)) != ANNCUR_OK) return rc;
 	EV(4);
 	return ANNCUR_OK;
 }
@@ -1912,7 +1914,7 @@ FusedPlan plan_wide(int64_t Q, int64_t I, int KP, int k, bool leading = false) {
 }
 
 int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int KP, int k, float *out_val,
-				int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr) {
+				int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr, const int32_t *item_ids = nullptr) {
 	WideParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.et_rows = ceil_div64(I, TILE_I) * TILE_I; p.Q = Q; p.I = I; p.Kp = KP;
 	p.n_rb = P.n_rb; p.S = P.S;
@@ -1989,7 +1991,7 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 		stages.end[g] = P.stage_end[g] * u < n_tiles32 ? P.stage_end[g] * u : n_tiles32;
 		stages.tps[g] = P.stage_tps[g] * u;
 	}
-	if ((rc = launch_select(P, 4 * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st)) != ANNCUR_OK) return rc;
+	if ((rc = launch_select(P, 4 * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st, item_ids)) != ANNCUR_OK) return rc;
 	EV(4);
 	return ANNCUR_OK;
 }
@@ -2014,17 +2016,8 @@ extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int
 	return plan_any(Q, I, Kp, k).ok ? 1 : 0;
 }
 
-// out_idx[i] = item_ids[out_idx[i]] (rows of Et -> the caller's item ids; -1 stays -1)
-__global__ __launch_bounds__(256) void remap_ids_kernel(int32_t *__restrict__ idx, const int32_t *__restrict__ item_ids, int64_t n, int64_t n_items) {
-	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (i < n) {
-		const int32_t r = idx[i];
-		// (r < n_items always holds for a product call; the experiments build's ANNCUR_DEBUG_NOSTORE leaves the select reading candidate slots
-		//  nobody wrote, and an unchecked row there was an out-of-bounds read -- a GPU memory fault in scripts/stage_probe.py, round 3)
-		if (r >= 0) idx[i] = (int64_t)r < n_items ? item_ids[r] : -1;
-	}
-}
-
+// (item_ids: the select kernels report item_ids[row of Et] -- the map is applied where the indices are written, not by a launch of its own;
+//  a row index is always < I there: it comes out of a candidate the sweep wrote or a recomputed item)
 static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr, CoScan *co = nullptr) {
@@ -2045,18 +2038,13 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 	int rc;
 	if (co && (rc = co_plan(*co, P.n_stages + 1)) != ANNCUR_OK) return rc;   // one chunk per latency-bound launch: threshold, refinements, select
 	switch (Kp) {
-		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
-		case 128: rc = P.QT == 1 ? launch_fused<128, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co)
-								  : launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
-		case 256: rc = P.QT == 1 ? launch_fused<256, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co)
-								  : launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
-		case 512: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co); break;
-		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev, co); break;
-	}
-	if (rc == ANNCUR_OK && item_ids) {
-		const int64_t n = Q * (int64_t)k;
-		hipLaunchKernelGGL(remap_ids_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, out_idx, item_ids, n, I);
-		ANNCUR_LAUNCH_OK();
+		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
+		case 128: rc = P.QT == 1 ? launch_fused<128, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids)
+								  : launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
+		case 256: rc = P.QT == 1 ? launch_fused<256, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids)
+								  : launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
+		case 512: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
+		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
 	}
 	if (rc == ANNCUR_OK) rc = co_finish(co, st);
 	return rc;

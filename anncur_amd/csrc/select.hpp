@@ -155,7 +155,7 @@ __device__ inline void sel_sort_desc(uint64_t *buf, uint32_t n, uint32_t kp) {
 
 // After the stream: reduce to k, sort, write row q of the outputs.
 template <int KMAX>
-__device__ void sel_finish(const SelState &s, uint32_t k, float *out_val, int32_t *out_idx) {
+__device__ void sel_finish(const SelState &s, uint32_t k, float *out_val, int32_t *out_idx, const int32_t *__restrict__ remap = nullptr) {
 	__syncthreads();
 	if (s.scal[0] > k) sel_compact<KMAX>(s, k);
 	const uint32_t n = s.scal[0];
@@ -166,7 +166,7 @@ __device__ void sel_finish(const SelState &s, uint32_t k, float *out_val, int32_
 		if (j < n) {
 			const uint64_t key = s.buf[j];
 			out_val[j] = key_val(key);
-			out_idx[j] = (int32_t)key_idx(key);
+			out_idx[j] = remap ? remap[key_idx(key)] : (int32_t)key_idx(key);
 		} else {  // fewer than k selectable elements in the row
 			out_val[j] = -INFINITY;
 			out_idx[j] = -1;

@@ -97,7 +97,8 @@ template <bool TAU_ONLY, int E>
 __global__ __launch_bounds__(256) void select_stream_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ seg_cnt, int nseg,
 															 int capg, int64_t Q, uint32_t k, float *__restrict__ out_val,
 															 int32_t *__restrict__ out_idx, uint32_t *__restrict__ hard_cnt,
-															 int32_t *__restrict__ hard_list, float *__restrict__ tau, int tau_stride, int prefilter) {
+															 int32_t *__restrict__ hard_list, float *__restrict__ tau, int tau_stride, int prefilter,
+															 const int32_t *__restrict__ remap) {
 	static_assert(E * WAVE * 8 <= STREAM_KCAP * 4, "the output buffer reuses the key buffer");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(256) void select_stream_kernel(const uint2 *__restr
 			if (i < k) {
 				const bool real = i < base;
 				ov[i] = real ? f32_unsortable(sh[e]) : -INFINITY;
-				oi[i] = real ? (int32_t)(0xffffffffu - sl[e]) : -1;
+				const int32_t id = (int32_t)(0xffffffffu - sl[e]);
+				oi[i] = real ? (remap ? remap[id] : id) : -1;
 			}
 		}
 		SEL_STAMP(3);

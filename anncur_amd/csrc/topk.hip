@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 // 4096: the threshold of k = 1000 (4000 group maxima per query) no longer goes through the workgroup-level top-k (0.74 -> 0.21 ms).
 constexpr int KTH_MAX_N = 4096;
 __global__ __launch_bounds__(256) void kth_value_wave_kernel(const float *__restrict__ G, int64_t Q, int n, int64_t ldg, uint32_t k,
-															  float *__restrict__ out, int64_t out_stride, int n_pad) {
+															  float *__restrict__ out, int64_t out_stride, int n_pad, int coarse) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char kth_smem[];
 	const uint32_t lane = (uint32_t)lane_id();
 	const int wave = threadIdx.x >> 6;
@@ -364,7 +364,12 @@ __global__ __launch_bounds__(256) void kth_value_wave_kernel(const float *__rest
 	uint32_t need;
 	// (fixed sign/exponent digits: the range-adaptive digits of wsel_kth_ranged cost more here -- min / max pass and two reductions
 	//  per row -- than the histogram conflicts they avoid: 0.034 vs 0.030 ms at n = 512, 0.23 vs 0.21 ms at n = 4000, measured)
-	const uint32_t kk = wsel_kth<false, 4>(w, w.whi, (uint32_t)n, k, need, w.whi, 0u);
+	// PASSES: 4 = the exact k-th largest value; 2 = the k-th largest 16-bit key PREFIX with the low half zero -- in the sortable map that
+	// is a value <= the exact one by less than one bf16 ulp (0.8 %), i.e. still a valid lower bound, for half the histogram passes
+	// (the fused top-k's threshold: 23.6 -> 13 us at 512 keys, 91 -> 48 us at 2000; ~2 % more survivors in the first sweep stage)
+	uint32_t kk;
+	if (coarse) kk = wsel_kth<false, 2>(w, w.whi, (uint32_t)n, k, need, w.whi, 0u);
+	else kk = wsel_kth<false, 4>(w, w.whi, (uint32_t)n, k, need, w.whi, 0u);
 	if (lane == 0) out[q * out_stride] = f32_unsortable(kk);
 }
 
@@ -531,14 +536,14 @@ int kmax_class(int k) { return k <= 128 ? 128 : (k <= 512 ? 512 : 2048); }
 }  // namespace
 
 // internal (not part of the C ABI): tau[q] = k-th largest of G[q, :n], n <= 2048
-int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st) {
+int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st, int coarse) {
 	ANNCUR_REQUIRE(n >= 1 && n <= KTH_MAX_N && k >= 1 && k <= n, ANNCUR_E_INVALID, "kth_value: need 1 <= k <= n <= 4096");
 	const unsigned grid = (unsigned)ceil_div64(Q, 4);
 	const int n_pad = (n + 63) & ~63;
 	const int lds = 4 * (256 + n_pad) * 4;  // (<= 68 KB: above the 64 KB default only for n > 3840)
 	int rc;
 	if (lds > 64 * 1024 && (rc = anncur_ensure_dyn_lds((const void *)kth_value_wave_kernel, lds)) != ANNCUR_OK) return rc;
-	hipLaunchKernelGGL(kth_value_wave_kernel, dim3(grid), dim3(256), lds, st, G, Q, n, ldg, (uint32_t)k, out, out_stride, n_pad);
+	hipLaunchKernelGGL(kth_value_wave_kernel, dim3(grid), dim3(256), lds, st, G, Q, n, ldg, (uint32_t)k, out, out_stride, n_pad, coarse);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -337,7 +337,7 @@ __device__ __forceinline__ void wave_sort_desc(uint32_t (&hi)[E], uint32_t (&lo)
 // Reduce to the k best, sort them, write the output row.  Fewer than k candidates -> (-inf, -1) padding.
 // E = keys per lane of the final sort (k <= 64 E).
 template <int OUTLINED_CAP = 0, int HI_PASSES = 4, int E = 2, bool RANGED = false>
-__device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx) {
+__device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx, const int32_t *__restrict__ remap = nullptr) {
 	const int lane = lane_id();
 	if (w.cnt > k) {
 		if constexpr (OUTLINED_CAP > 0) wsel_compact_call<OUTLINED_CAP, HI_PASSES, false>(w, k);
@@ -360,7 +360,9 @@ __device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_v
 		if (i < k) {
 			const bool real = i < w.cnt;
 			out_val[i] = real ? f32_unsortable(sh[e]) : -INFINITY;
-			out_idx[i] = real ? (int32_t)(0xffffffffu - sl[e]) : -1;
+			// remap (fused top-k with an item-order hint): the selected index is a ROW of the reordered operand, reported as the caller's item id
+			const int32_t id = (int32_t)(0xffffffffu - sl[e]);
+			out_idx[i] = real ? (remap ? remap[id] : id) : -1;
 		}
 	}
 }

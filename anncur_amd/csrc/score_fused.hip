@@ -135,6 +135,9 @@ __device__ __forceinline__ void tile_dma(const uint16_t *__restrict__ Et, int ti
 	}
 }
 
+// (Round 3 also issued the next tile's pieces BETWEEN the tile's MFMAs instead of in a burst at the head of the step -- the phase stamps
+//  charge the burst with 384 of the 2855 cycles of a step -- : no gain, same box, alternating (0.4802 vs 0.4792 ms per sweep): the partner
+//  wave's MFMAs cover the burst already.)
 // The same DMA for the staggered sweep, hand-placed: hipcc kept the four per-lane source offsets as 64-bit pairs plus four VGPRs of LDS
 // destinations that it then moved to M0 through v_readfirstlane (12 VGPRs and ~20 vector instructions per tile and wave in a kernel
 // that sits at the 256-register limit).  Here: one 32-bit offset register per piece (computed once), the tile's base in SGPRs
@@ -655,6 +658,15 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #endif
 // (Round 3 tried draining by occupancy as well -- a ballot "some lane's ring holds >= 3 / >= 4 entries" per step, beside or instead of the
 //  planned window: both cost 4 % of the sweep at cfg2, same box, alternating -- the check itself, not the drains.  The planned window stays.)
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		// phase stamps (diagnostic build): shader cycles this WAVE spent per step in {ticket read + DMA issue, ring drain, the tile's MFMA / filter
+		// section, the vmcnt wait, the barrier}; summed over the loop, one record per wave (anncur_debug_sweep_phases, scripts/sweep_phases.py)
+		uint32_t ph_acc[5] = {0u, 0u, 0u, 0u, 0u};
+		uint32_t ph_t = (uint32_t)__builtin_amdgcn_s_memtime();
+#define PH(i) do { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph_acc[i] += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
 #define STAGGER_STEP(CUR)                                                                                                       \
 		do {                                                                                                                    \
 			const int J = t_cur;                                                                                                \
@@ -670,6 +682,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			if (nx >= 0) STAGGER_DMA(nx, CUR);                                                                                  \
 			uint32_t ticket = 0;                                                                                                \
 			if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);  /* in flight until ticket_wait() below */          \
+			PH(0);                                                                                                              \
 			if (t_prev < dense_end || --flush_in2 <= 0) {                                                                       \
 				flush_in2 = p.flush_tiles;                                                                                      \
 				/* (a raw ring holds one tile: sub-tile 0 of the previous tile, sub-tile 1 of the one before) */                \
@@ -677,9 +690,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 				flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_pp); \
 			}                                                                                                                   \
 			const uint32_t item0 = (uint32_t)J * TILE_I + 4 * h;                                                                \
+			PH(1);                                                                                                              \
 			stagger_tile<KP, CUR, PRED, INL>(aoff, xb, acc1, tau[0], tau1_prev, item0, item0_prev, lq0, lq1, qcnt[0], qcnt[1], J < dense_end || every_tile); \
 			tau1_prev = tau[1]; item0_pp = item0_prev; item0_prev = item0;                                                      \
+			PH(2);                                                                                                              \
 			ticket_wait(ticket);  /* vmcnt(0): the DMA of the next tile, the queue stores issued with it and the ticket have landed */ \
+			PH(3);                                                                                                              \
 			if (crossed) {                                                                                                      \
 				if (tid == 0) {                                                                                                 \
 					lds_store_u32(ticket_slot, ticket);                                                                         \
@@ -690,6 +706,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 				t_cend = min(nx + p.chunk_tiles, p.tile_end);                                                                   \
 			}                                                                                                                   \
 			__syncthreads();                                                                                                    \
+			PH(4);                                                                                                              \
 			t_prev = J; t_cur = nx;                                                                                             \
 		} while (0)
 		while (t_cur >= 0) {
@@ -698,6 +715,13 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 			STAGGER_STEP(1);
 		}
 #undef STAGGER_STEP
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (lane == 0 && d_sweep_stamps && p.debug_stamp && blockIdx.x * 4 + wave < 8192) {
+			unsigned long long *ph = d_sweep_stamps + 5 * 8192 + (size_t)(blockIdx.x * 4 + wave) * 8;
+			for (int i = 0; i < 5; ++i) ph[i] = ph_acc[i];
+		}
+#endif
+#undef PH
 		flush_queue<Cfg::QDEPTH>(lq1, qcnt[1], seg0 + seg_dt, ncand[1], (uint32_t)p.capg, (uint32_t)p.I, tau[1], item0_pp);  // keep one tile's hits per queue window
 #pragma unroll
 		for (int e = 0; e < 16; ++e)  // drain: sub-tile 1 of the last tile
@@ -1728,10 +1752,10 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
 		if (!g_stamps) {
-			ANNCUR_HIP_OK(hipMalloc((void **)&g_stamps, 5 * 8192 * sizeof(unsigned long long)));
+			ANNCUR_HIP_OK(hipMalloc((void **)&g_stamps, 13 * 8192 * sizeof(unsigned long long)));
 			ANNCUR_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(d_sweep_stamps), &g_stamps, sizeof(g_stamps)));
 		}
-		ANNCUR_HIP_OK(hipMemsetAsync(g_stamps, 0, 5 * 8192 * sizeof(unsigned long long), st));
+		ANNCUR_HIP_OK(hipMemsetAsync(g_stamps, 0, 13 * 8192 * sizeof(unsigned long long), st));
 	}
 #endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS  // (the -DANNCUR_TIMING_EXPERIMENTS build of scripts/fused_microbench.py only: results become wrong)
@@ -2251,6 +2275,15 @@ extern "C" int anncur_debug_sweep_timeline(double *out) {
 		out[2 * j] = v[j][n / 2]; out[2 * j + 1] = v[j][n - 1];
 	}
 	return ANNCUR_OK;
+}
+#endif
+
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+/* diagnostic build only: per-wave phase cycles of the stamped sweep launch (staggered Kp <= 256 body): out[8192 x 8], words 0..4 = cycles in
+ * {ticket + DMA issue, ring drain, MFMA / filter section, vmcnt wait, barrier} */
+extern "C" int anncur_debug_sweep_phases(unsigned long long *out) {
+	if (!g_stamps) return ANNCUR_E_INVALID;
+	return hipMemcpy(out, g_stamps + 5 * 8192, 8 * 8192 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? ANNCUR_OK : ANNCUR_E_HIP;
 }
 #endif
 

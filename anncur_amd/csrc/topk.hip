@@ -140,6 +140,11 @@ __global__ __launch_bounds__(SEL_THREADS) void rowwise_topk_kernel(const T *__re
 //  * the threshold used inside a block of WS_PF vectors is the one at block start: thresholds only rise, a stale one lets a
 //    superset through, and the compaction (exact composite keys) sorts that out;
 //  * the compaction is out of line (wsel_compact_call).
+// Rounds (round 3, scripts/scan_rows_probe.py): the kernel keeps 4096 rows in flight; a launch costs whole rounds of them -- a full round
+// is bandwidth-bound (4096 x 200 KB in 134-145 us), a partial one latency-bound (92 us for ONE row as for 1800: a wave alone streams
+// 2.2 GB/s) -- so 10 000 rows cost 2 + 0.65 rounds (36.4 ns per row against 32.7 at 20 000 rows).  Cutting rows into 2 or 4 shares
+// (one wave each, merged through LDS) to make the rounds finer was built and measured: WORSE everywhere (10 000 x 100 000: 0.387 -> 0.443 /
+// 0.596 ms): every share pays its own seed threshold, candidate upkeep and final sort, ~24 us per share.
 // bf16 ordering trick: y = x ^ M per 16-bit pattern with M = 0x8000 if tau >= 0 else 0xffff.  For tau >= 0 an element beats tau
 // iff it is positive and larger, i.e. iff y > tau ^ 0x8000 as UNSIGNED (negative floats get the top bit cleared); for tau < 0
 // iff y > ~tau as unsigned (positives become >= 0x8000, negatives order by falling magnitude).  NaN patterns can pass these

@@ -70,6 +70,55 @@ def check_body(name, body):
 	return findings
 
 
+def _vmcnt(ins):
+	"""vmcnt value of an s_waitcnt (None: it does not wait on vmcnt)."""
+	if not ins.lstrip().startswith("s_waitcnt"):
+		return None
+	m = re.search(r"vmcnt\((\d+)\)", ins)
+	if m:
+		return int(m.group(1))
+	m = re.search(r"s_waitcnt\s+(0x[0-9a-fA-F]+|\d+)\s", ins + " ")  # raw immediate: vmcnt = bits 0..3 and 14..15
+	if m:
+		v = int(m.group(1), 0)
+		return (v & 0xF) | (((v >> 14) & 0x3) << 4)
+	return None if ("lgkmcnt" in ins or "expcnt" in ins) else 0
+
+
+def check_vm_body(name, body):
+	"""The same walk for RETURNING global atomics (the ticket draw of the dynamic tile schedule is an inline-asm `global_atomic_add vD, ...
+	sc0` whose result is waited for a whole tile later): nothing may name vD until an s_waitcnt vmcnt(0).  (Only a full drain is taken to
+	retire it: younger VMEM operations of unknown number may sit behind it.)"""
+	from check_mfma_hazards import basic_blocks
+	findings = []
+	blocks, succ = basic_blocks(body)
+	seen, reported = set(), set()
+	work = [(0, ())]
+	while work and len(seen) < 200000:
+		k, state = work.pop()
+		if (k, state) in seen: continue
+		seen.add((k, state))
+		queue = list(state)
+		st, en = blocks[k]
+		for i in range(st, en + 1):
+			a, ins, _ = body[i]
+			op = ins.split()[0]
+			w = _vmcnt(ins)
+			if w is not None:
+				if w == 0: queue = []
+				continue
+			if queue:
+				used = regs(ins)
+				for (qa, qins, dst) in queue:
+					if dst & used and (qa, a) not in reported:
+						reported.add((qa, a))
+						findings.append(f"{name[:70]}: '{ins}' @ {a:x} touches the destination of in-flight '{qins}' @ {qa:x}")
+			if op.startswith("global_atomic") and " sc0" in ins + " ":
+				queue.append((a, ins, frozenset(regs(ins[len(op):].split(",")[0]))))
+		out = tuple(queue)
+		for t in succ[k]: work.append((t, out))
+	return findings
+
+
 def check(lib, only=None):
 	findings, n_kernels, n_reads = [], 0, 0
 	for dis in disassemble(lib):
@@ -79,6 +128,7 @@ def check(lib, only=None):
 			n_kernels += 1
 			n_reads += sum(1 for _, ins, _ in body if _is_ds_load(ins.split()[0]))
 			findings += check_body(name, body)
+			findings += check_vm_body(name, body)
 	return findings, n_kernels, n_reads
 
 

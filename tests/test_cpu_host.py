@@ -319,6 +319,20 @@ def _listing(lines, base=0x1000):
 	return body
 
 
+def test_static_check_of_returning_atomics_finds_a_planted_early_use():
+	"""The ticket draw (inline-asm returning atomic, result consumed a tile later): the walk must flag a use before the vmcnt(0) drain and
+	accept the waited form; the shipped sweep kernels contain such draws and pass."""
+	sys.path.insert(0, os.path.join(ROOT, "scripts"))
+	import check_lds_hazards
+	bad = _listing(["global_atomic_add v5, v[2:3], v6, off sc0", "v_add_u32_e32 v7, 1, v8", "ds_write_b32 v9, v5", "s_waitcnt vmcnt(0)", "s_endpgm"])
+	f = check_lds_hazards.check_vm_body("kernel", bad)
+	assert len(f) == 1 and "ds_write_b32 v9, v5" in f[0]
+	good = _listing(["global_atomic_add v5, v[2:3], v6, off sc0", "v_add_u32_e32 v7, 1, v8", "s_waitcnt vmcnt(0)", "ds_write_b32 v9, v5", "s_endpgm"])
+	assert check_lds_hazards.check_vm_body("kernel", good) == []
+	partial = _listing(["global_atomic_add v5, v[2:3], v6, off sc0", "s_waitcnt vmcnt(1)", "v_mov_b32_e32 v1, v5", "s_waitcnt vmcnt(0)", "s_endpgm"])
+	assert len(check_lds_hazards.check_vm_body("kernel", partial)) == 1          # a counted wait is not taken to retire it
+
+
 def test_static_hazard_checks_find_planted_hazards():
 	"""The two ISA walks on synthetic listings: they must report what they exist to report (and nothing on the padded / waited forms)."""
 	sys.path.insert(0, os.path.join(ROOT, "scripts"))

@@ -25,7 +25,8 @@ struct Fused16Cfg {
 	static constexpr int TILE_BYTES = TILE_I * KP * 2;
 	static constexpr int RING = 16;                  // slots of the lane's ring
 	static constexpr int QUEUE_OFF = (2 * TILE_BYTES + 32767) / 32768 * 32768;  // ring region 32 KiB aligned (slot offset is OR-ed in)
-	static constexpr int LDS_BYTES = QUEUE_OFF + RING * 256 * 8;
+	static constexpr int TICKET_OFF = QUEUE_OFF + RING * 256 * 8;    // ticket words of the dynamic tile schedule (score_kernel)
+	static constexpr int LDS_BYTES = TICKET_OFF + 16;
 	static constexpr int BQ = 256;
 };
 constexpr uint32_t SUBTILE_SHIFT = 29, ITEM_MASK = (1u << SUBTILE_SHIFT) - 1u;
@@ -41,7 +42,10 @@ __device__ __forceinline__ void filter16_one(float v, uint32_t code, float tau, 
 	}
 }
 
-// Drain the lane's ring: one store instruction per slot for the whole wave; the entry's sub-tile picks segment and counter.
+// Drain the lane's ring in batches of four slots: four LDS reads back to back, one wait, then one store instruction per slot for the
+// whole wave (the entry's sub-tile picks segment and counter).  The batch loop is a real loop (wave-uniform trip count): the drain is
+// inlined at four places of the kernel, and unrolled over the 16 slots it took the kernel to 7.9 k instructions -- past the
+// instruction cache, the bare tile loop ran 35 % slower (measured, MI355X cfg2).
 __device__ __forceinline__ void flush16(uint32_t lq, uint32_t &qcnt, uint2 *__restrict__ seg0, int64_t seg_dt, uint32_t (&ncand)[4], uint32_t capg,
 										 uint32_t n_items) {
 	uint32_t n = qcnt >> 11;
@@ -51,14 +55,27 @@ __device__ __forceinline__ void flush16(uint32_t lq, uint32_t &qcnt, uint2 *__re
 			n = 16u;
 		}
 	}
-	for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
-		if (i < n) {
-			const uint2 e = lds_load_u64(lq + i * 2048u);
-			const uint32_t qs = e.y >> SUBTILE_SHIFT, item = e.y & ITEM_MASK;
-			if (item < n_items) {
-				const uint32_t cnt = qs == 0 ? ncand[0] : (qs == 1 ? ncand[1] : (qs == 2 ? ncand[2] : ncand[3]));
-				if (cnt < capg) seg0[(int64_t)qs * seg_dt + cnt] = make_uint2(e.x, item);
-				ncand[0] += qs == 0; ncand[1] += qs == 1; ncand[2] += qs == 2; ncand[3] += qs == 3;
+#pragma nounroll
+	for (uint32_t b = 0; __ballot(b < n) != 0ull; b += 4) {
+		const uint32_t addr = lq + (b << 11);
+		unsigned long long e[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:2048\n\tds_read_b64 %2, %4 offset:4096\n\tds_read_b64 %3, %4 offset:6144\n\t"
+					 "s_waitcnt lgkmcnt(0)"
+					 : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+					 : "v"(addr)
+					 : "memory");
+#endif
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			if (b + i < n) {  // (slots past the lane's count hold stale entries)
+				const uint32_t x = (uint32_t)e[i], y = (uint32_t)(e[i] >> 32);
+				const uint32_t qs = y >> SUBTILE_SHIFT, item = y & ITEM_MASK;
+				if (item < n_items) {
+					const uint32_t cnt = qs == 0 ? ncand[0] : (qs == 1 ? ncand[1] : (qs == 2 ? ncand[2] : ncand[3]));
+					if (cnt < capg) seg0[(int64_t)qs * seg_dt + cnt] = make_uint2(x, item);
+					ncand[0] += qs == 0; ncand[1] += qs == 1; ncand[2] += qs == 2; ncand[3] += qs == 3;
+				}
 			}
 		}
 	}
@@ -123,6 +140,10 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int c16 = lane & 15, g4 = lane >> 4;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_entry)::"memory");
+#endif
 	const int wid = xcd_remap(blockIdx.x, p.n_wg);
 	const int n_rb = (int)((p.Q + C::BQ - 1) / C::BQ);
 	const int split = wid / n_rb, rb = wid - split * n_rb;
@@ -158,7 +179,32 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	const uint32_t lq = lds_addr(smem + C::QUEUE_OFF) + (uint32_t)tid * 8u;
 	if ((lds_addr(smem) & 0x7fffu) != 0u) __builtin_trap();  // filter16_one() ORs the slot offset into the address
 
-	if (j_begin < j_end) tile_dma<KP>(p.Et, j_begin, smem, wave, lane);
+	// ---- tile schedule (see score_kernel): static contiguous share, or tickets of p.chunk_tiles tiles from the row block's counter
+	int t_cur = j_begin < j_end ? j_begin : -1, t_cend = j_end, t_next_chunk = -1;
+	bool ticket_pending = false;
+	const bool dyn = p.chunk_tiles > 0;
+	uint32_t ticket_slot = lds_addr(smem + C::TICKET_OFF);
+	if (dyn) {
+		if (tid == 0) {
+			const uint32_t c = atomicAdd(p.chunk_ctr + rb, 2u);
+			if (p.chunk_owner) {
+				if (c < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c] = (uint8_t)split;
+				if (c + 1 < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c + 1] = (uint8_t)split;
+			}
+			lds_store_u32(ticket_slot, c);
+			__builtin_amdgcn_s_waitcnt(0xC07F);
+		}
+		__syncthreads();
+		const uint32_t c = lds_load_u32_uniform(ticket_slot);
+		t_cur = c < (uint32_t)p.n_chunks ? p.tile_begin + (int)c * p.chunk_tiles : -1;
+		t_cend = min(t_cur + p.chunk_tiles, p.tile_end);
+		t_next_chunk = c + 1 < (uint32_t)p.n_chunks ? p.tile_begin + (int)(c + 1) * p.chunk_tiles : -1;
+	}
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
+	uint32_t dma_off[C::TILE_BYTES / 4096];
+	tile_dma_offsets<KP>(dma_off, wave_u, lane);
+	if (t_cur >= 0) tile_dma_s<KP>(p.Et, t_cur, lds_base, wave_u, dma_off);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
 
@@ -176,29 +222,89 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		const int row = 16 * (s & 1) + c16;
 		aoff[s] = lds_addr(smem) + (uint32_t)(row * CPR + swz<CPR>(row, 4 * (s >> 1) + g4)) * 16u;
 	}
-	const int flush_period = (p.sample_leading && !p.carry && 4 * split < p.S) ? 1 : p.flush_tiles;  // (see score_kernel)
-	int flush_in = flush_period;
+	// (norm-ordered rows: the leading quarter of the first stage drains every tile -- see score_kernel)
+	const int dense_end = (p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
+	int flush_in = p.flush_tiles, t_prev = -1;
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger16_tile() counts LDS reads
 	const float tau_hi[2] = {tau[2], tau[3]};
-#define STAGGER16_STEP(CUR, J)                                                                                                  \
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	uint32_t ph_acc[5] = {0u, 0u, 0u, 0u, 0u};   // phase stamps of the diagnostic build: see score_kernel
+	uint32_t ph_t = (uint32_t)__builtin_amdgcn_s_memtime();
+	uint32_t ph_tiles = 0;
+#define PH16(i) do { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph_acc[i] += now_ - ph_t; ph_t = now_; } while (0)
+#define PH16_TILE() do { ++ph_tiles; } while (0)
+#else
+#define PH16(i) do { } while (0)
+#define PH16_TILE() do { } while (0)
+#endif
+#define STAGGER16_STEP(CUR)                                                                                                     \
 	do {                                                                                                                        \
-		if ((J) + 1 < j_end) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * C::TILE_BYTES, wave, lane);                       \
-		if (--flush_in == 0) {                                                                                                  \
-			flush_in = flush_period;                                                                                            \
+		const int J = t_cur;                                                                                                    \
+		if (ticket_pending) {                                                                                                   \
+			const uint32_t c = lds_load_u32_uniform(ticket_slot);                                                               \
+			t_next_chunk = c < (uint32_t)p.n_chunks ? p.tile_begin + (int)c * p.chunk_tiles : -1;                               \
+			ticket_pending = false;                                                                                             \
+			ticket_slot ^= 4u;                                                                                                  \
+		}                                                                                                                       \
+		int nx = J + 1;                                                                                                         \
+		bool crossed = false;                                                                                                   \
+		if (nx >= t_cend) { nx = t_next_chunk; crossed = dyn && nx >= 0; }                                                      \
+		if (nx >= 0) tile_dma_s<KP>(p.Et, nx, lds_base + ((CUR) ^ 1) * C::TILE_BYTES, wave_u, dma_off);                         \
+		uint32_t ticket = 0;                                                                                                    \
+		if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);                                                         \
+		PH16(0);                                                                                                                \
+		if (t_prev < dense_end || --flush_in <= 0) {                                                                            \
+			flush_in = p.flush_tiles;                                                                                           \
 			flush16(lq, qcnt, seg0, seg_dt, ncand, (uint32_t)p.capg, (uint32_t)p.I);                                            \
 		}                                                                                                                       \
-		const uint32_t item0 = (uint32_t)(J) * TILE_I + 4 * g4;                                                                 \
+		const uint32_t item0 = (uint32_t)J * TILE_I + 4 * g4;                                                                   \
+		PH16(1);                                                                                                                \
 		stagger16_tile<KP, CUR>(aoff, xb, accP, tau, tau_prev, item0, item0_prev, lq, qcnt);                                    \
 		tau_prev[0] = tau_hi[0]; tau_prev[1] = tau_hi[1]; item0_prev = item0;                                                   \
-		__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                     \
+		PH16(2);                                                                                                                \
+		ticket_wait(ticket);                                                                                                    \
+		PH16(3);                                                                                                                \
+		if (crossed) {                                                                                                          \
+			if (tid == 0) {                                                                                                     \
+				lds_store_u32(ticket_slot, ticket);                                                                             \
+				if (p.chunk_owner && ticket < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + ticket] = (uint8_t)split; \
+				__builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \
+			}                                                                                                                   \
+			ticket_pending = true;                                                                                              \
+			t_cend = min(nx + p.chunk_tiles, p.tile_end);                                                                       \
+		}                                                                                                                       \
 		__syncthreads();                                                                                                        \
+		PH16(4);                                                                                                                \
+		PH16_TILE();                                                                                                            \
+		t_prev = J; t_cur = nx;                                                                                                 \
 	} while (0)
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_c0), "+s"(st_r0)::"memory");
+#endif
 	ANNCUR_PAD_HERE();
-	for (int j = j_begin; j < j_end; j += 2) {
-		STAGGER16_STEP(0, j);
-		if (j + 1 < j_end) STAGGER16_STEP(1, j + 1);
+	while (t_cur >= 0) {
+		STAGGER16_STEP(0);
+		if (t_cur < 0) break;
+		STAGGER16_STEP(1);
 	}
 #undef STAGGER16_STEP
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (lane == 0 && d_sweep_stamps && p.debug_stamp && blockIdx.x * 4 + wave < 8192) {
+		unsigned long long *ph = d_sweep_stamps + 5 * 8192 + (size_t)(blockIdx.x * 4 + wave) * 8;
+		for (int i = 0; i < 5; ++i) ph[i] = ph_acc[i];
+		ph[5] = ph_tiles;
+	}
+	if (tid == 0 && d_sweep_stamps && p.debug_stamp && blockIdx.x < 8192) {
+		unsigned long long *stamps = d_sweep_stamps;
+		const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+		stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+		stamps[2 * blockIdx.x + 1] = r1 - st_r0;
+		stamps[2 * 8192 + 3 * blockIdx.x] = st_entry; stamps[2 * 8192 + 3 * blockIdx.x + 1] = st_r0; stamps[2 * 8192 + 3 * blockIdx.x + 2] = r1;
+	}
+#endif
+#undef PH16
+#undef PH16_TILE
 	flush16(lq, qcnt, seg0, seg_dt, ncand, (uint32_t)p.capg, (uint32_t)p.I);
 	// drain: sub-tiles {2,3} of the last tile
 #define F16_LAST(e)                                                                                                             \

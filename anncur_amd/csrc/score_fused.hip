@@ -1491,7 +1491,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	// Dynamic tile schedule (staggered 32x32x16 sweep, Kp <= 256): tickets of CHUNK_TILES tiles per query row block instead of fixed shares
 	// (score_kernel).  Workgroups per row block: enough to fill every slot (rounded UP -- a workgroup that finds no ticket left ends at
 	// once), at most 32 so that the 2 S segments of a query fit the wave-level select.
-	const bool ticketed = P.QT == 2 && !mfma16;   // the body with the ticket schedule (Kp = 512 has no LDS to spare for the ticket words: FusedCfg)
+	const bool ticketed = P.QT == 2;   // the bodies with the ticket schedule (32x32x16 staggered and 16x16x32; Kp = 512 has no LDS to spare for the ticket words: FusedCfg)
 	P.chunk = ticketed ? CHUNK_TILES : 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = ticketed ? atoi(dbg) : 0;
@@ -1763,7 +1763,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (getenv("ANNCUR_DEBUG_NOSTORE")) { p.capg = 0; item_ids = nullptr; }  // every candidate is dropped at the store (the select then reads slots nobody wrote: no id map through them)
 #endif
 
-	const int chunk = (P.chunk > 0 && P.lg == 2 && Cfg::QT == 2) ? P.chunk : 0;   // (the 16x16x32 sweep and the one-sub-tile bodies keep static shares)
+	const int chunk = (P.chunk > 0 && Cfg::QT == 2) ? P.chunk : 0;   // (the one-sub-tile bodies keep static shares)
 	const int owner_stride = P.n_rb * (P.n_tiles / (chunk > 0 ? chunk : P.n_tiles) + 2);
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, chunk > 0 ? P.off_gmax : 256, st));   // header (+ the stages' ticket counters)
 	EV(0);

@@ -18,13 +18,14 @@ Kp = ops.padded_k(K)
 Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), Kp)
 Xp = ops.pack_bf16(X, Kp)
 del Z, E
+FLAGS = {"mfma16": True} if os.environ.get("PH_MFMA16") else {}
 lib = _lib.load()
 lib.anncur_debug_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 2.5:
-	for _ in range(20): ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, item_ids=ids)
+	for _ in range(20): ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, item_ids=ids, **FLAGS)
 	torch.cuda.synchronize(); n += 20
-(_, _), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids)
+(_, _), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids, **FLAGS)
 ghz, us, nwg = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
 assert lib.anncur_debug_read_stamps(ctypes.byref(ghz), ctypes.byref(us), ctypes.byref(nwg)) == 0
 tf = 2.0 * Q * Kp * I / (ms[4] * 1e-3) / 1e12
@@ -44,6 +45,9 @@ if os.environ.get("ANNCUR_CLOCK_DETAIL"):
 	a = np.frombuffer(raw, dtype=np.uint64).astype(np.float64)
 	tl = a[2 * 8192:].reshape(8192, 3); ok = tl[:, 2] > 0; n = int(ok.sum())
 	dur = (tl[ok, 2] - tl[ok, 1]) / 100.0   # us
+	t0_ = tl[ok, 0].min()
+	print("entry  us after the first: p10 %.1f p50 %.1f p90 %.1f max %.1f | loop start: p50 %.1f max %.1f | loop end: p10 %.1f p50 %.1f p90 %.1f max %.1f" % (
+		*[np.percentile(tl[ok, 0] - t0_, q) / 100 for q in (10, 50, 90, 100)], *[np.percentile(tl[ok, 1] - t0_, q) / 100 for q in (50, 100)], *[np.percentile(tl[ok, 2] - t0_, q) / 100 for q in (10, 50, 90, 100)]))
 	b = np.arange(8192)[ok]
 	BQ = 256 if Kp <= 256 else 128   # queries per workgroup (two / one 32-query sub-tiles per wave)
 	n_rb = (Q + BQ - 1) // BQ; S = n // n_rb

@@ -30,7 +30,10 @@ settings = [S("default"), S("static", chunk=0), S("chunk=3", chunk=3), S("chunk=
 			S("f=.10 pred=0", stages="0.10", all_pred=0), S("f=.22 pred=0", stages="0.22", all_pred=0),
 			S("flush=1", flush_tiles=1), S("flush=4", flush_tiles=4), S("f=.25 pred=0", stages="0.25", all_pred=0), S("f=.30 pred=0", stages="0.30", all_pred=0), S("f=.18 pred=0", stages="0.18", all_pred=0),
 			S("bare", tau_bias="1e30"), S("bare pred=0", tau_bias="1e30", all_pred=0), S("bare pred=1", tau_bias="1e30", all_pred=1),
-			S("bare mfma16", {"mfma16": True}, tau_bias="1e30"), S("bare qt1", {"qt1": True}, tau_bias="1e30"), S("bare 1 stage", tau_bias="1e30", stages="1")]
+			S("bare mfma16", {"mfma16": True}, tau_bias="1e30"), S("bare qt1", {"qt1": True}, tau_bias="1e30"),
+			S("static mfma16", {"mfma16": True}, chunk=0), S("bare static mfma16", {"mfma16": True}, chunk=0, tau_bias="1e30"), S("mfma16 chunk=8", {"mfma16": True}, chunk=8),
+			S("bare mfma16 chunk=64", {"mfma16": True}, chunk=64, tau_bias="1e30"), S("bare mfma16 chunk=1", {"mfma16": True}, chunk=1, tau_bias="1e30"),
+			S("bare static contig", chunk=0, contig=1, tau_bias="1e30"), S("bare chunk=64", chunk=64, tau_bias="1e30"), S("bare 1 stage", tau_bias="1e30", stages="1")]
 if os.environ.get("STAGE_PROBE_ONLY"):
 	keep = os.environ["STAGE_PROBE_ONLY"].split(";")
 	settings = [s for s in settings if s[0] in keep]

@@ -17,13 +17,14 @@ Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), 256)
 Xp = ops.pack_bf16(X, 256)
 lib = _lib.load()
 lib.anncur_debug_sweep_phases.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-plan = ops.fused_plan(Q, I, 256, k, leading_sample=True)
+FLAGS = {"mfma16": True} if os.environ.get("PH_MFMA16") else {}
+plan = ops.fused_plan(Q, I, 256, k, leading_sample=True, **FLAGS)
 print("plan", plan)
 for stage in range(plan["n_stages"]):
 	os.environ["ANNCUR_DEBUG_STAMP_STAGE"] = str(stage)
-	for _ in range(30): ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, item_ids=ids)
+	for _ in range(30): ops.score_topk_fused(Xp, Etp, I, k, leading_sample=True, item_ids=ids, **FLAGS)
 	torch.cuda.synchronize()
-	(_, _), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids)
+	(_, _), ms = ops.score_topk_fused_timed(Xp, Etp, I, k, leading_sample=True, item_ids=ids, **FLAGS)
 	raw = (ctypes.c_ulonglong * (8 * 8192))()
 	assert lib.anncur_debug_sweep_phases(raw) == 0
 	a = np.frombuffer(raw, dtype=np.uint64).astype(np.float64).reshape(8192, 8)[:, :5]

@@ -16,6 +16,7 @@ F32, BF16, F64 = 0, 1, 2
 TOPK_LEADING_SAMPLE = 1
 TOPK_MFMA16 = 2
 TOPK_QT1 = 4
+TOPK_MFMA32 = 8
 MAX_TOPK = 2048
 
 _p32 = POINTER(c_int32)

@@ -10,9 +10,15 @@
 // sharing the step's A fragment) while the filter of sub-tiles {2,3} of the PREVIOUS tile is issued in their shadow; steps
 // K..2K-1 do sub-tiles {2,3} beside the filter of {0,1}.  K = Kp / 16 steps per half, step s = (k-step s >> 1, item half s & 1).
 //
-// Candidates: a lane now serves four queries with one item group g = lane >> 4, so it owns four segments (query, g, split) --
-// 4 S per query -- and ONE LDS ring of 16 slots shared by its four sub-tiles (pooling the four streams makes a wrap rarer than
-// four rings of 4): the sub-tile travels in bits 29..30 of the ring entry's item word (I < 2^29).
+// Candidates: a WAVE-level queue instead of per-lane rings.  A lane serves four queries with one item group, so a per-lane ring pools
+// four streams and its drain has to sort every entry into one of four segments (22 vector instructions per slot, for the fullest of
+// the 64 rings: the drain was 22 % of a first-stage tile in the phase stamps, most lanes idle).  Here the lanes that pass a compare
+// append their survivors to ONE queue per wave in LDS (rank among the hitting lanes by mbcnt, wave-uniform fill pointer in an SGPR);
+// an entry carries its query in the item word (bits 26..31: query sub-tile and lane & 15; I < 2^26).  The drain is dense -- 64 entries
+// per pass, one entry per lane: the entry's query draws its slot from the wave's 64 per-query counters in LDS (ds_add_rtn) and the entry
+// goes to the segment of (query, item split): ONE segment per (query, split), S per query.  The queue cannot overflow: a push that
+// leaves fewer than 64 free entries drains on the spot (cold path inside the tile function), and a step drains at its head when
+// the queue holds DRAIN_AT entries or more.
 #pragma once
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -23,70 +29,67 @@ struct Fused16Cfg {
 	static constexpr int K = KP / 16;                // stagger steps per half = (k-step, item half) pairs
 	static constexpr int CPR = KP / 8;
 	static constexpr int TILE_BYTES = TILE_I * KP * 2;
-	static constexpr int RING = 16;                  // slots of the lane's ring
-	static constexpr int QUEUE_OFF = (2 * TILE_BYTES + 32767) / 32768 * 32768;  // ring region 32 KiB aligned (slot offset is OR-ed in)
-	static constexpr int TICKET_OFF = QUEUE_OFF + RING * 256 * 8;    // ticket words of the dynamic tile schedule (score_kernel)
+	static constexpr int QCAP = 1024;                // entries of a wave's queue
+	static constexpr int DRAIN_AT = 192;             // a step drains at its head from this fill on (three full passes)
+	static constexpr int QUEUE_OFF = 2 * TILE_BYTES;
+	static constexpr int CNT_OFF = QUEUE_OFF + 4 * QCAP * 8;        // 256 per-query candidate counts of this item split
+	static constexpr int TICKET_OFF = CNT_OFF + 256 * 4;            // ticket words of the dynamic tile schedule (score_kernel)
 	static constexpr int LDS_BYTES = TICKET_OFF + 16;
 	static constexpr int BQ = 256;
 };
-constexpr uint32_t SUBTILE_SHIFT = 29, ITEM_MASK = (1u << SUBTILE_SHIFT) - 1u;
+constexpr uint32_t WQ_ITEM_BITS = 26, WQ_ITEM_MASK = (1u << WQ_ITEM_BITS) - 1u;
 
-// one accumulator element against the lane's threshold of its sub-tile; code = item row within the tile's lane group | sub-tile << 29
-// (a compile-time constant after unrolling)
-__device__ __forceinline__ void filter16_one(float v, uint32_t code, float tau, uint32_t item0, uint32_t lq, uint32_t &qcnt) {
-	if (__builtin_expect(__ballot(v >= tau) != 0ull, 0)) {
-		if (v >= tau) {
-			lds_store_2x32((qcnt & (uint32_t)(15u << 11)) | lq, __float_as_uint(v), item0 + code);
-			qcnt += 2048u;
-		}
-	}
-}
+// wave-uniform state of the candidate path (scalars)
+struct WaveQueue {
+	uint32_t base, limit;      // LDS byte address of the queue, of the fill from which a step of the tile function drains first
+	uint32_t cnt;              // LDS byte address of the wave's 64 per-query counts
+	uint2 *seg;                // segment of the wave's first query for this item split
+	int64_t q_stride;          // entries between the segments of consecutive queries (segments per query x capg)
+	uint32_t capg, n_items;
+	int lane;
+};
 
-// Drain the lane's ring in batches of four slots: four LDS reads back to back, one wait, then one store instruction per slot for the
-// whole wave (the entry's sub-tile picks segment and counter).  The batch loop is a real loop (wave-uniform trip count): the drain is
-// inlined at four places of the kernel, and unrolled over the 16 slots it took the kernel to 7.9 k instructions -- past the
-// instruction cache, the bare tile loop ran 35 % slower (measured, MI355X cfg2).
-__device__ __forceinline__ void flush16(uint32_t lq, uint32_t &qcnt, uint2 *__restrict__ seg0, int64_t seg_dt, uint32_t (&ncand)[4], uint32_t capg,
-										 uint32_t n_items) {
-	uint32_t n = qcnt >> 11;
-	if (__builtin_expect(__ballot(n > 16u) != 0ull, 0)) {
-		if (n > 16u) {  // the ring wrapped between two flushes: poison the lane's four counts -> those queries are repaired exactly
-			ncand[0] = ncand[1] = ncand[2] = ncand[3] = 0x80000000u;
-			n = 16u;
-		}
-	}
+// Drain: entry i of the queue -> lane i & 63 of pass i >> 6.
+__device__ __forceinline__ void wq_drain(const WaveQueue &w, uint32_t &fill) {
+	const uint32_t n = (fill - w.base) >> 3;  // (uniform)
 #pragma nounroll
-	for (uint32_t b = 0; __ballot(b < n) != 0ull; b += 4) {
-		const uint32_t addr = lq + (b << 11);
-		unsigned long long e[4];
+	for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+		const uint32_t i = i0 + (uint32_t)w.lane;
+		if (i < n) {
+			const uint2 e = lds_load_u64(w.base + i * 8u);
+			const uint32_t item = e.y & WQ_ITEM_MASK, ql = e.y >> WQ_ITEM_BITS;
+			if (item < w.n_items) {  // (the matrix' last tile may be partial)
+				uint32_t pos = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-		asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:2048\n\tds_read_b64 %2, %4 offset:4096\n\tds_read_b64 %3, %4 offset:6144\n\t"
-					 "s_waitcnt lgkmcnt(0)"
-					 : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
-					 : "v"(addr)
-					 : "memory");
+				const uint32_t one = 1u;
+				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(w.cnt + ql * 4u), "v"(one) : "memory");
 #endif
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			if (b + i < n) {  // (slots past the lane's count hold stale entries)
-				const uint32_t x = (uint32_t)e[i], y = (uint32_t)(e[i] >> 32);
-				const uint32_t qs = y >> SUBTILE_SHIFT, item = y & ITEM_MASK;
-				if (item < n_items) {
-					const uint32_t cnt = qs == 0 ? ncand[0] : (qs == 1 ? ncand[1] : (qs == 2 ? ncand[2] : ncand[3]));
-					if (cnt < capg) seg0[(int64_t)qs * seg_dt + cnt] = make_uint2(x, item);
-					ncand[0] += qs == 0; ncand[1] += qs == 1; ncand[2] += qs == 2; ncand[3] += qs == 3;
-				}
+				if (pos < w.capg) w.seg[(int64_t)ql * w.q_stride + pos] = make_uint2(e.x, item);
 			}
 		}
 	}
-	qcnt = 0;
+	fill = w.base;
+}
+
+// one accumulator element against the lane's threshold of its sub-tile; code = item row within the tile's lane group | sub-tile << 30
+// (a compile-time constant after unrolling); item0c = first item of the lane's group | (lane & 15) << 26
+__device__ __forceinline__ void filter16_one(float v, uint32_t code, float tau, uint32_t item0c, const WaveQueue &w, uint32_t &fill) {
+	const bool hit = v >= tau;
+	const unsigned long long m = __ballot(hit);
+	if (__builtin_expect(m != 0ull, 0)) {
+		if (hit) {
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+			lds_store_2x32(fill + rank * 8u, __float_as_uint(v), item0c + code);
+		}
+		fill += 8u * (uint32_t)__builtin_popcountll(m);
+	}
 }
 
 // One 32-item tile.  accP = sub-tiles {2,3} of the previous tile (filtered here, then replaced by this tile's).
 template <int KP, int CUR>
 __device__ __forceinline__ void stagger16_tile(const uint32_t (&aoff)[Fused16Cfg<KP>::K], const bf16x8 (&xb)[4][Fused16Cfg<KP>::KS32], f32x4 (&accP)[2][2],
-												const float (&tau)[4], const float (&tau_prev)[2], uint32_t item0, uint32_t item0_prev, uint32_t lq,
-												uint32_t &qcnt) {
+												const float (&tau)[4], const float (&tau_prev)[2], uint32_t item0, uint32_t item0_prev, const WaveQueue &w,
+												uint32_t &fill) {
 	using C = Fused16Cfg<KP>;
 	constexpr int K = C::K, AR = 5, DIST = 3, OFF = CUR * C::TILE_BYTES;
 	constexpr int EPS = 16 / K > 0 ? 16 / K : 1;  // filter elements per step (Kp = 64: 4, 128: 2, 256: 1)
@@ -102,8 +105,8 @@ __device__ __forceinline__ void stagger16_tile(const uint32_t (&aoff)[Fused16Cfg
 	// element e of a finished half: item half e >> 3, query of the pair (e >> 2) & 1, register e & 3
 #define F16_ELEM(ACC, e, QS0, TAU, ITEM0)                                                                                       \
 	filter16_one(ACC[(e) >> 3][((e) >> 2) & 1][(e) & 3],                                                                        \
-				 (uint32_t)((((e) >> 3) * 16 + ((e) & 3)) | ((uint32_t)((QS0) + (((e) >> 2) & 1)) << SUBTILE_SHIFT)),          \
-				 TAU[((e) >> 2) & 1], ITEM0, lq, qcnt)
+				 (uint32_t)((((e) >> 3) * 16 + ((e) & 3)) | ((uint32_t)((QS0) + (((e) >> 2) & 1)) << (WQ_ITEM_BITS + 4))),     \
+				 TAU[((e) >> 2) & 1], ITEM0, w, fill)
 #pragma unroll
 	for (int g = 0; g < 2 * K; ++g) {
 		const int nxt = g + DIST;
@@ -111,6 +114,9 @@ __device__ __forceinline__ void stagger16_tile(const uint32_t (&aoff)[Fused16Cfg
 #if defined(__HIP_DEVICE_COMPILE__)
 		if (g >= 1) asm volatile("" ::"v"(ring[(g - 1) % AR]));
 #endif
+		// (uniform, cold) every 8 pushes: the queue must take the next 8 + EPS (64 entries each at most) -- checked a few times per tile, not
+		// per push (two scalar instructions per step cost the bare loop 10 %; per push the 48 inlined drains ran the kernel out of SGPRs)
+		if (g > 0 && (g * EPS) % 8 == 0 && __builtin_expect(fill > w.limit, 0)) wq_drain(w, fill);
 		const int after = 2 * K - 1 - g;
 		lds_wait_frag(ring[g % AR], after < DIST ? after : DIST);
 		const bf16x8 a = __builtin_bit_cast(bf16x8, ring[g % AR]);
@@ -166,18 +172,25 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	__builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see score_kernel
 
 	const int j_begin = p.tile_begin + split * p.tiles_per_split, j_end = min(j_begin + p.tiles_per_split, p.tile_end);
-	const int nseg = 4 * p.S, sg = g4 * p.S + split;
 	float tau[4];
-	uint32_t ncand[4];
 #pragma unroll
-	for (int t = 0; t < 4; ++t) {
-		tau[t] = qv[t] < p.Q ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
-		ncand[t] = (p.carry && qv[t] < p.Q) ? p.seg_cnt[qv[t] * nseg + sg] : 0u;
+	for (int t = 0; t < 4; ++t) tau[t] = qv[t] < p.Q ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
+	// candidate path: the wave's queue, its 64 per-query counts (lane l <-> local query l = 16 * sub-tile + (lane & 15) of the wave)
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
+	const int64_t q_wave0 = (int64_t)rb * C::BQ + wave_u * 64;  // (uniform) the wave's first query
+	WaveQueue w;
+	w.base = lds_base + (uint32_t)(C::QUEUE_OFF + wave_u * C::QCAP * 8);
+	w.limit = w.base + (uint32_t)(C::QCAP - 64 * (8 + 2 * (16 / K > 0 ? 16 / K : 1))) * 8u;  // see stagger16_tile: 8 + 2 EPS pushes between two checks
+	w.cnt = lds_base + (uint32_t)(C::CNT_OFF + wave_u * 256);
+	w.q_stride = (int64_t)p.nseg * p.capg;
+	w.seg = p.cand + (q_wave0 * p.nseg + p.seg_off + split) * (int64_t)p.capg;
+	w.capg = (uint32_t)p.capg; w.n_items = (uint32_t)p.I; w.lane = lane;
+	uint32_t fill = w.base;
+	{
+		const int64_t q = q_wave0 + lane;
+		lds_store_u32(w.cnt + (uint32_t)lane * 4u, (p.carry && q < p.Q) ? p.seg_cnt[q * p.nseg + p.seg_off + split] : 0u);
 	}
-	uint2 *seg0 = p.cand + (qv[0] * nseg + sg) * (int64_t)p.capg;  // sub-tile t: + t * seg_dt
-	const int64_t seg_dt = (int64_t)16 * nseg * p.capg;
-	const uint32_t lq = lds_addr(smem + C::QUEUE_OFF) + (uint32_t)tid * 8u;
-	if ((lds_addr(smem) & 0x7fffu) != 0u) __builtin_trap();  // filter16_one() ORs the slot offset into the address
 
 	// ---- tile schedule (see score_kernel): static contiguous share, or tickets of p.chunk_tiles tiles from the row block's counter
 	int t_cur = j_begin < j_end ? j_begin : -1, t_cend = j_end, t_next_chunk = -1;
@@ -200,8 +213,6 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		t_cend = min(t_cur + p.chunk_tiles, p.tile_end);
 		t_next_chunk = c + 1 < (uint32_t)p.n_chunks ? p.tile_begin + (int)(c + 1) * p.chunk_tiles : -1;
 	}
-	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
 	uint32_t dma_off[C::TILE_BYTES / 4096];
 	tile_dma_offsets<KP>(dma_off, wave_u, lane);
 	if (t_cur >= 0) tile_dma_s<KP>(p.Et, t_cur, lds_base, wave_u, dma_off);
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 #pragma unroll
 		for (int q = 0; q < 2; ++q) accP[ih][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 	float tau_prev[2] = {INFINITY, INFINITY};  // no previous tile yet: the filter of accP never fires
-	uint32_t item0_prev = 0, qcnt = 0;
+	uint32_t item0_prev = 0;
 	// A fragment of step s = (k-step s >> 1, item half s & 1): row 16 (s & 1) + (lane & 15), 16-byte chunk 4 (s >> 1) + (lane >> 4)
 	uint32_t aoff[K];
 #pragma unroll
@@ -222,9 +233,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		const int row = 16 * (s & 1) + c16;
 		aoff[s] = lds_addr(smem) + (uint32_t)(row * CPR + swz<CPR>(row, 4 * (s >> 1) + g4)) * 16u;
 	}
-	// (norm-ordered rows: the leading quarter of the first stage drains every tile -- see score_kernel)
-	const int dense_end = (p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
-	int flush_in = p.flush_tiles, t_prev = -1;
+	const uint32_t lane_code = (uint32_t)c16 << WQ_ITEM_BITS;
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger16_tile() counts LDS reads
 	const float tau_hi[2] = {tau[2], tau[3]};
 #ifdef ANNCUR_TIMING_EXPERIMENTS
@@ -253,13 +262,10 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		uint32_t ticket = 0;                                                                                                    \
 		if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);                                                         \
 		PH16(0);                                                                                                                \
-		if (t_prev < dense_end || --flush_in <= 0) {                                                                            \
-			flush_in = p.flush_tiles;                                                                                           \
-			flush16(lq, qcnt, seg0, seg_dt, ncand, (uint32_t)p.capg, (uint32_t)p.I);                                            \
-		}                                                                                                                       \
-		const uint32_t item0 = (uint32_t)J * TILE_I + 4 * g4;                                                                   \
+		if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                               \
+		const uint32_t item0 = ((uint32_t)J * TILE_I + 4 * g4) | lane_code;                                                     \
 		PH16(1);                                                                                                                \
-		stagger16_tile<KP, CUR>(aoff, xb, accP, tau, tau_prev, item0, item0_prev, lq, qcnt);                                    \
+		stagger16_tile<KP, CUR>(aoff, xb, accP, tau, tau_prev, item0, item0_prev, w, fill);                                        \
 		tau_prev[0] = tau_hi[0]; tau_prev[1] = tau_hi[1]; item0_prev = item0;                                                   \
 		PH16(2);                                                                                                                \
 		ticket_wait(ticket);                                                                                                    \
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		__syncthreads();                                                                                                        \
 		PH16(4);                                                                                                                \
 		PH16_TILE();                                                                                                            \
-		t_prev = J; t_cur = nx;                                                                                                 \
+		t_cur = nx;                                                                                                             \
 	} while (0)
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -305,18 +311,23 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 #endif
 #undef PH16
 #undef PH16_TILE
-	flush16(lq, qcnt, seg0, seg_dt, ncand, (uint32_t)p.capg, (uint32_t)p.I);
-	// drain: sub-tiles {2,3} of the last tile
+	// drain: sub-tiles {2,3} of the last tile (16 pushes: at most the whole queue)
+	wq_drain(w, fill);
 #define F16_LAST(e)                                                                                                             \
 	filter16_one(accP[(e) >> 3][((e) >> 2) & 1][(e) & 3],                                                                       \
-				 (uint32_t)((((e) >> 3) * 16 + ((e) & 3)) | ((uint32_t)(2 + (((e) >> 2) & 1)) << SUBTILE_SHIFT)),              \
-				 tau_prev[((e) >> 2) & 1], item0_prev, lq, qcnt)
+				 (uint32_t)((((e) >> 3) * 16 + ((e) & 3)) | ((uint32_t)(2 + (((e) >> 2) & 1)) << (WQ_ITEM_BITS + 4))),         \
+				 tau_prev[((e) >> 2) & 1], item0_prev, w, fill)
 	F16_LAST(0); F16_LAST(1); F16_LAST(2); F16_LAST(3); F16_LAST(4); F16_LAST(5); F16_LAST(6); F16_LAST(7);
 	F16_LAST(8); F16_LAST(9); F16_LAST(10); F16_LAST(11); F16_LAST(12); F16_LAST(13); F16_LAST(14); F16_LAST(15);
 #undef F16_LAST
 #undef F16_ELEM
-	flush16(lq, qcnt, seg0, seg_dt, ncand, (uint32_t)p.capg, (uint32_t)p.I);
-#pragma unroll
-	for (int t = 0; t < 4; ++t)
-		if (qv[t] < p.Q) p.seg_cnt[qv[t] * nseg + sg] = ncand[t];
+	wq_drain(w, fill);
+	{
+		const int64_t q = q_wave0 + lane;
+		uint32_t c = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c) : "v"(w.cnt + (uint32_t)lane * 4u) : "memory");
+#endif
+		if (q < p.Q) p.seg_cnt[q * p.nseg + p.seg_off + split] = c;
+	}
 }

@@ -96,6 +96,8 @@ struct FusedParams {
 	float *gmax; int n_groups;        // prepass output [Q x n_groups]
 	const float *tau; int tau_stride; // threshold per query: tau[q * tau_stride]
 	uint2 *cand; uint32_t *seg_cnt; int capg;
+	int nseg, seg_off;                // candidate segments per query; first segment of the launched body within them (mixed-body plans)
+	int zero_off;                     // >= 0: the launch also zeroes seg_cnt[q * nseg + zero_off + split] (segments a later stage's body carries on from)
 	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	int debug_stamp;                  // timing experiments only: this launch writes the in-kernel clock stamps
@@ -565,12 +567,14 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #pragma unroll
 	for (int t = 0; t < QT; ++t) {
 		tau[t] = (MODE == 1 && qv[t] < p.Q) ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
-		ncand[t] = (MODE == 1 && p.carry && qv[t] < p.Q) ? p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] : 0u;
+		ncand[t] = (MODE == 1 && p.carry && qv[t] < p.Q) ? p.seg_cnt[qv[t] * p.nseg + p.seg_off + h * p.S + split] : 0u;
 		qcnt[t] = 0;
 	}
 	// candidate segment of (query, lane half, split); sub-tile t adds a wave-uniform stride
-	uint2 *seg0 = p.cand + ((qv[0] * 2 + h) * (int64_t)p.S + split) * (int64_t)p.capg;
-	const int64_t seg_dt = (int64_t)32 * 2 * p.S * p.capg;
+	uint2 *seg0 = p.cand + (qv[0] * p.nseg + p.seg_off + h * p.S + split) * (int64_t)p.capg;
+	const int64_t seg_dt = (int64_t)32 * p.nseg * p.capg;
+	if (MODE == 1 && p.zero_off >= 0 && tid < Cfg::BQ && (int64_t)rb * Cfg::BQ + tid < p.Q)  // (a later stage's body starts from these counts)
+		p.seg_cnt[((int64_t)rb * Cfg::BQ + tid) * p.nseg + p.zero_off + split] = 0u;
 	const uint32_t lq0 = lds_addr(smem + Cfg::QUEUE_OFF) + (uint32_t)tid * 8u;  // slot i of sub-tile t at byte lq0 + (t*QDEPTH + i)*2048
 	static_assert(Cfg::QUEUE_OFF % (Cfg::QDEPTH * 2048) == 0 && Cfg::QDEPTH * 2048 == 16384, "ring must be 16 KiB aligned");
 	if (MODE == 1 && (lds_addr(smem) & 0x3fffu) != 0u) __builtin_trap();  // filter_one() ORs the slot offset into the address
@@ -930,7 +934,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #pragma unroll
 		for (int t = 0; t < QT; ++t) {
 			flush_queue<Cfg::QDEPTH, FLUSH_BATCH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I, tau[t], last_item0);
-			if (qv[t] < p.Q) p.seg_cnt[(qv[t] * 2 + h) * (int64_t)p.S + split] = ncand[t];
+			if (qv[t] < p.Q) p.seg_cnt[qv[t] * p.nseg + p.seg_off + h * p.S + split] = ncand[t];
 		}
 	}
 }
@@ -1374,8 +1378,11 @@ struct FusedPlan {
 	bool ok;
 	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
 	int n_stages, stage_end[3], stage_tps[3], stage_flush[3], stage_pred[3];
+	bool stage_body16[3];   // the stage runs score16_kernel
 	int leading;
-	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves) or 4 (16x16x32 sweep: lane groups)
+	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue), 3 (mixed)
+	bool body16;  // every sweep stage runs score16_kernel (ANNCUR_TOPK_MFMA16)
+	bool mixed;   // the first stage runs the 32x32x16 body (2 S ring segments per query), the later ones score16_kernel (S more segments)
 	int chunk;  // dynamic tile schedule of the sweep stages: tiles per ticket (0: static shares)
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, off_ctr, off_owner, total;
 };
@@ -1463,7 +1470,7 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	}
 }
 
-FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false) {
+FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false, bool mfma32 = false) {
 	FusedPlan P{};
 	P.ok = false;
 	P.leading = leading ? 1 : 0;
@@ -1500,11 +1507,8 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	if (P.chunk > 0 && k <= WQ_K2 && S > WAVE / 2) S = WAVE / 2;
 	if (S < 1) S = 1;
 	if (S > 255) S = P.chunk > 0 ? 255 : (S > 256 ? 256 : S);   // (the owner map holds a split in a byte, 255 = none)
-	// ANNCUR_TOPK_MFMA16 with few query rows: its four segments per split must fit the wave-level select (4 S <= 64), so the item
-	// axis is split at most 16 ways -- the flag is honoured for every shape (fewer workgroups than slots when Q < ~8000: an A/B
-	// variant, not the default)
-	const bool want16 = mfma16 && KP <= 256 && I < (int64_t)(1 << 29);
-	if (want16 && k <= WQ_K2 && S > WAVE / 4) S = WAVE / 4;
+	// ANNCUR_TOPK_MFMA16: the 16x16x32 sweep (score16.hpp); its queue entries carry the query beside the item: I < 2^26
+	const bool want16 = mfma16 && KP <= 256 && I < (int64_t)(1 << 26);
 	if (S > P.n_tiles) S = P.n_tiles;
 	P.tiles_per_split = (P.n_tiles + S - 1) / S;
 	P.S = (P.n_tiles + P.tiles_per_split - 1) / P.tiles_per_split;
@@ -1513,19 +1517,26 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	if (S0 > P.n_st) S0 = P.n_st;
 	P.st_per_split = (P.n_st + S0 - 1) / S0;
 	P.S0 = (P.n_st + P.st_per_split - 1) / P.st_per_split;
-	// sweep variant: the 16x16x32 kernel (score16.hpp, ANNCUR_TOPK_MFMA16) where its four segments per split still fit the
-	// wave-level select; the default is the 32x32x16 kernel (measured on MI355X at cfg2 size: the 16x16 loop is 5.8 % faster
-	// without survivors, 1208 vs 1142 TFLOP/s, and level with them, 0.576-0.589 vs 0.574-0.579 ms: its flush serves four queries per lane)
-	P.lg = (want16 && (k > WQ_K2 || 4 * P.S <= WAVE)) ? 4 : 2;
+	// candidate segments per (query, item split): two (lane halves) in the 32x32x16 sweep, ONE in the 16x16x32 sweep (wave-level queue).
+	// Default for k <= 128 where the select takes 3 S segments: MIXED -- first stage on the 32x32x16 body (exec-mask filter, per-lane rings:
+	// the better of the two against the loose prepass threshold, 0.195 vs 0.205 ms at cfg2), later stages on the 16x16x32 body (the chip
+	// holds a higher clock on that shape and few compares hit: 0.249 vs 0.276 ms; MI355X, same box, alternating).  The bodies write
+	// disjoint segments of the same query: [0, 2 S) and [2 S, 3 S).
+	P.body16 = want16;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_MFMA16") && KP <= 256 && I < (int64_t)(1 << 29) && (k > WQ_K2 || 4 * P.S <= WAVE)) P.lg = 4;
+	if (getenv("ANNCUR_DEBUG_MFMA16") && KP <= 256 && I < (int64_t)(1 << 26) && P.QT == 2) P.body16 = true;
 #endif
+	P.mixed = !P.body16 && !mfma32 && !mfma16 && P.QT == 2 && P.chunk > 0 && KP <= 256 && I < (int64_t)(1 << 26) && k <= WSEL_K && 3 * P.S <= WAVE;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (getenv("ANNCUR_DEBUG_NO_MIXED")) P.mixed = false;
+#endif
+	P.lg = P.body16 ? 1 : (P.mixed ? 3 : 2);
 	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over lg S lane segments
 	// (segment capacity -- hence the workspace size -- is planned for the strided sample whatever the hint; with item rows ordered
 	//  by descending norm the leading sample's threshold lets ~40 % fewer elements through: measured on the synthetic protocol)
 	const double exp_hits_cap = 1.3 * k * ((double)P.n_tiles / P.n_st);
 	const double exp_hits = (leading ? 0.65 : 1.0) * exp_hits_cap;
-	const double per_seg = exp_hits_cap / ((double)P.lg * P.S);
+	const double per_seg = exp_hits_cap / ((double)(P.mixed ? 2 : P.lg) * P.S);   // (mixed: the first stage's ring segments take most of them)
 	int capg = next_pow2((int)(4.0 * per_seg) + 32);
 	if (capg < 64) capg = 64;
 	if (capg > 16384) capg = 16384;
@@ -1538,6 +1549,11 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	int ft = (int)(0.35 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
 	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
+	if (P.mixed && P.n_stages < 2) {  // a single stage: nothing for the second body to do
+		P.mixed = false; P.lg = 2;
+		plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
+	}
+	for (int g = 0; g < 3; ++g) P.stage_body16[g] = P.body16 || (P.mixed && g > 0);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_ctr = off;    off = align256(off + (size_t)P.n_rb * 3 * 4);   // ticket counters [stage][row block]: zeroed with the header, one memset
@@ -1749,6 +1765,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	p.tau_bias = 0.f;
 	p.chunk_tiles = 0; p.n_chunks = 0; p.chunk_ctr = nullptr; p.chunk_owner = nullptr;
+	p.nseg = P.lg * P.S; p.seg_off = 0; p.zero_off = -1;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
 		if (!g_stamps) {
@@ -1787,7 +1804,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	// the survivors crowd into the leading tiles, all the workgroups of a stage run at once, and with contiguous ranges the stage took
 	// as long as its FIRST split (cfg2: the first stage, 22 % of the tiles, 0.236 ms against 0.306 ms for the other 78 %).
 	// (score16_kernel keeps contiguous ranges)
-	const int tile_step = (P.lg == 2 && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
+	const int tile_step = (!P.body16 && !P.mixed && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
 	p.n_wg = P.n_rb * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
@@ -1795,6 +1812,10 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		p.tile_step = tile_step;
+		if (P.mixed) {  // disjoint segments per body; the first stage zeroes the counts the second body starts from
+			p.seg_off = P.stage_body16[stg] ? 2 * P.S : 0;
+			p.zero_off = stg == 0 ? 2 * P.S : -1;
+		}
 		if (chunk > 0) {
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
 			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb;
@@ -1814,8 +1835,8 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			launched = true;
 		}
 #endif
-		if constexpr (KP <= 256 && QTV == 2) {  // 16x16x32 sweep (score16.hpp): four lane groups -> 4 S segments per query
-			if (!launched && P.lg == 4) {
+		if constexpr (KP <= 256 && QTV == 2) {  // 16x16x32 sweep (score16.hpp): one segment per (query, item split)
+			if (!launched && P.stage_body16[stg]) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score16_kernel<KP>, Fused16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((score16_kernel<KP>), dim3(p.n_wg), dim3(256), Fused16Cfg<KP>::LDS_BYTES, st, p);
 				launched = true;
@@ -2021,14 +2042,17 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 }
 #undef EV
 
-FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false) {
-	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1);
+FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, int flags = 0) {
+	const bool leading = (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, mfma16 = (flags & ANNCUR_TOPK_MFMA16) != 0, qt1 = (flags & ANNCUR_TOPK_QT1) != 0;
+	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1, (flags & ANNCUR_TOPK_MFMA32) != 0);
 }
+constexpr int TOPK_FLAGS = ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1 | ANNCUR_TOPK_MFMA32;
 
 }  // namespace
 
 extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
-	const FusedPlan P = plan_any(Q, I, Kp, k), P16 = plan_any(Q, I, Kp, k, false, true), P1 = plan_any(Q, I, Kp, k, false, false, true);  // (whatever flags the call will carry)
+	const FusedPlan P = plan_any(Q, I, Kp, k), P16 = plan_any(Q, I, Kp, k, ANNCUR_TOPK_MFMA16), P1 = plan_any(Q, I, Kp, k, ANNCUR_TOPK_QT1);  // (whatever flags the call will carry;
+	// ANNCUR_TOPK_MFMA32 never needs more than the default)
 	if (!P.ok) return 0;
 	size_t t = P.total;
 	if (P16.ok && P16.total > t) t = P16.total;
@@ -2045,8 +2069,8 @@ extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int
 static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr, CoScan *co = nullptr) {
-	ANNCUR_REQUIRE((flags & ~(ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1)) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
-	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0, (flags & ANNCUR_TOPK_QT1) != 0);
+	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
+	const FusedPlan P = plan_any(Q, I, Kp, k, flags);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
 				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512} or a multiple of 128 up to %d, "
 				   "1<=k<=%d, I large enough for a sampled threshold); use anncur_gemm + anncur_rowwise_topk",
@@ -2113,7 +2137,7 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 	constexpr int NEV = 11;  // 0..4 stage boundaries, 5..10 begin/end of up to three sweep launches
 	hipEvent_t ev[NEV];
 	for (int i = 0; i < NEV; ++i) ANNCUR_HIP_OK(hipEventCreate(&ev[i]));
-	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0, (flags & ANNCUR_TOPK_QT1) != 0);
+	const FusedPlan P = plan_any(Q, I, Kp, k, flags);
 	int rc = score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, ev, flags, item_ids);
 	if (rc == ANNCUR_OK) {
 		hipError_t e = hipEventSynchronize(ev[4]);
@@ -2143,17 +2167,18 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 }
 
 /* the same for the flags of anncur_score_topk_ex: out[0 .. n_out) = {sample tiles, item tiles, S, segment capacity, group, segments per
- * query and item split (2: 32x32x16 sweep, 4: 16x16x32 sweep / wide kernel), 32-query sub-tiles per wave, sweep stages, stage_end[3],
- * stage uses the exec-mask filter[3], ring drain period[3]} -- what a test needs to see that a variant flag was honoured */
+ * query and item split (2: 32x32x16 sweep, 1: 16x16x32 sweep, 3: mixed, 4: wide kernel), 32-query sub-tiles per wave, sweep stages,
+ * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32), ring drain period[3]} --
+ * what a test needs to see that a variant flag was honoured */
 extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
-	ANNCUR_REQUIRE((flags & ~(ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1)) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
-	const FusedPlan P = plan_any(Q, I, Kp, k, (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, (flags & ANNCUR_TOPK_MFMA16) != 0, (flags & ANNCUR_TOPK_QT1) != 0);
+	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
+	const FusedPlan P = plan_any(Q, I, Kp, k, flags);
 	ANNCUR_REQUIRE(P.ok && out && n_out >= 0, ANNCUR_E_UNSUPPORTED, "score_topk_plan_ex: unsupported shape");
 	const bool wide = wide_kp(Kp);
 	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
 	for (int g = 0; g < 3; ++g) {
 		const bool on = g < P.n_stages;
-		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? P.stage_pred[g] : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
+		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.stage_body16[g] ? 2 : P.stage_pred[g]) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
 	}
 	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
 	return ANNCUR_OK;

@@ -377,19 +377,20 @@ def _item_ids_arg(item_ids, I, device):
 	return item_ids
 
 
-def _topk_flags(leading_sample=False, mfma16=False, qt1=False):
+def _topk_flags(leading_sample=False, mfma16=False, qt1=False, mfma32=False):
 	"""The flags word of anncur_score_topk_ex / _timed / _plan_ex."""
-	return ((_lib.TOPK_LEADING_SAMPLE if leading_sample else 0) | (_lib.TOPK_MFMA16 if mfma16 else 0) | (_lib.TOPK_QT1 if qt1 else 0))
+	return ((_lib.TOPK_LEADING_SAMPLE if leading_sample else 0) | (_lib.TOPK_MFMA16 if mfma16 else 0) | (_lib.TOPK_QT1 if qt1 else 0)
+			| (_lib.TOPK_MFMA32 if mfma32 else 0))
 
 
 @_on_device
-def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False):
+def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False):
 	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16).
 	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time).
 	leading_sample / item_ids: the index builder's hints of anncur_score_topk_ex (rows of Etp ordered by descending norm, and the
 	map from rows back to item ids); the result is the exact top-k either way.
-	mfma16 / qt1: the sweep variants ANNCUR_TOPK_MFMA16 / ANNCUR_TOPK_QT1 (fused_plan(..., mfma16=, qt1=) tells whether the shape
-	takes them: "lg" == 4 / "QT" == 1)."""
+	mfma16 / mfma32 / qt1: the sweep variants ANNCUR_TOPK_MFMA16 / _MFMA32 / _QT1 (fused_plan(..., mfma16=, ...) tells whether the shape
+	takes them: "lg" == 1 / "lg" == 2 / "QT" == 1; the default for Kp <= 256, k <= 128 is the mixed plan, "lg" == 3)."""
 	_dev(Xp, Etp)
 	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16:
 		raise TypeError("score_topk_fused takes bf16 operands")
@@ -409,7 +410,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 		val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
 		idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 		for q0 in range(0, Q, qc):   # (a chunk of 512 queries is accepted whatever its workspace size)
-			part = score_topk_fused(Xp[q0:q0 + qc], Etp, I, k, leading_sample=leading_sample, item_ids=item_ids, mfma16=mfma16, qt1=qt1)
+			part = score_topk_fused(Xp[q0:q0 + qc], Etp, I, k, leading_sample=leading_sample, item_ids=item_ids, mfma16=mfma16, qt1=qt1, mfma32=mfma32)
 			val[q0:q0 + qc], idx[q0:q0 + qc] = part.values, part.indices
 		return TopK(val, idx)
 	if workspace is None:
@@ -422,7 +423,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 	ids = _item_ids_arg(item_ids, I, Xp.device)
 	check(lib.anncur_score_topk_ex(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
-								   _topk_flags(leading_sample, mfma16, qt1), _p(ids) if ids is not None else None, _stream()), "score_topk")
+								   _topk_flags(leading_sample, mfma16, qt1, mfma32), _p(ids) if ids is not None else None, _stream()), "score_topk")
 	if return_fallbacks:
 		return TopK(val, idx), ws[:4].view(torch.int32)
 	return TopK(val, idx)
@@ -440,7 +441,7 @@ def aux_stream(device):
 
 
 @_on_device
-def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False):
+def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False, mfma32=False):
 	"""The per-query evaluation loop's two top-k's in one call (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:97-106):
 	(exact = rowwise_topk(A, k), approx = score_topk_fused(Xp, Etp, I, k_retvr)), the exact scan's row chunks co-scheduled with the
 	retrieval's latency-bound launches on a second stream (anncur_eval_topk).  serial=True: the same two results, one after the other."""
@@ -472,12 +473,12 @@ def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, i
 		aux = aux or aux_stream(A.device)
 		aux_p = ctypes.c_void_p(aux.cuda_stream)
 	check(lib.anncur_eval_topk(_p(A), _dt(A), _ld(A), k, _p(ev), _p(ei), _p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k_retvr, _p(av), _p(ai), _p(ws), nbytes,
-							   _topk_flags(leading_sample, mfma16, qt1), _p(ids) if ids is not None else None, _stream(), aux_p), "eval_topk")
+							   _topk_flags(leading_sample, mfma16, qt1, mfma32), _p(ids) if ids is not None else None, _stream(), aux_p), "eval_topk")
 	return TopK(ev, ei), TopK(av, ai)
 
 
 @_on_device
-def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False):
+def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False):
 	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches, sweep launch 1, 2, 3]) in
 	ms, from HIP events on the launch stream."""
 	_dev(Xp, Etp)
@@ -492,16 +493,18 @@ def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, m
 	ms = (ctypes.c_float * 9)()
 	ids = _item_ids_arg(item_ids, I, Xp.device)
 	check(lib.anncur_score_topk_timed(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
-									  _topk_flags(leading_sample, mfma16, qt1), _p(ids) if ids is not None else None, _stream(), ms),
+									  _topk_flags(leading_sample, mfma16, qt1, mfma32), _p(ids) if ids is not None else None, _stream(), ms),
 		  "score_topk_timed")
 	return TopK(val, idx), [float(x) for x in ms]
 
 
-def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False):
-	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 sweep, 4 = the
-	16x16x32 sweep (mfma16 honoured) or the wide kernel; "QT": 32-query sub-tiles per wave (1 = qt1 honoured, or Kp = 512)."""
+def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False):
+	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 body in every
+	sweep stage, 1 = the 16x16x32 body in every stage (mfma16 honoured), 3 = mixed (first stage 32x32x16, later stages 16x16x32: the default
+	for Kp <= 256, k <= 128), 4 = the wide kernel (Kp > 512); "QT": 32-query sub-tiles per wave (1 = qt1 honoured, or Kp = 512);
+	"stage_pred": body of each sweep stage -- 0 / 1 = 32x32x16 with the ballot / exec-mask filter, 2 = 16x16x32."""
 	out = (ctypes.c_int32 * 17)()
-	check(_lib.load().anncur_score_topk_plan_ex(Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1), out, 17), "score_topk_plan_ex")
+	check(_lib.load().anncur_score_topk_plan_ex(Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32), out, 17), "score_topk_plan_ex")
 	v = [int(x) for x in out]
 	plan = dict(zip(("n_sample_tiles", "n_tiles", "splits", "segment_capacity", "group", "lg", "QT", "n_stages"), v[:8]))
 	n = plan["n_stages"]

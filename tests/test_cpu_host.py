@@ -53,17 +53,22 @@ def test_sweep_variant_flags_reach_the_plan():
 	"""ops.score_topk_fused accepted mfma16= / qt1= and dropped them.  The plan query takes the same flags word the launch
 	does (ops._topk_flags), so a dropped flag shows here without a GPU."""
 	from anncur_amd import _lib, ops
-	assert ops._topk_flags() == 0 and ops._topk_flags(True, True, True) == (_lib.TOPK_LEADING_SAMPLE | _lib.TOPK_MFMA16 | _lib.TOPK_QT1)
+	assert ops._topk_flags() == 0 and ops._topk_flags(True, True, True, True) == (_lib.TOPK_LEADING_SAMPLE | _lib.TOPK_MFMA16 | _lib.TOPK_QT1 | _lib.TOPK_MFMA32)
 	base = ops.fused_plan(10000, 100000, 256, 100)
-	assert (base["lg"], base["QT"]) == (2, 2) and base["n_stages"] == len(base["stage_end"]) >= 1 and base["stage_end"][-1] == base["n_tiles"]
-	assert ops.fused_plan(10000, 100000, 256, 100, mfma16=True)["lg"] == 4
-	assert ops.fused_plan(300, 40000, 64, 10, mfma16=True)["lg"] == 4 and ops.fused_plan(300, 40000, 64, 10, mfma16=True)["splits"] <= 16
+	assert (base["lg"], base["QT"]) == (3, 2) and base["n_stages"] == len(base["stage_end"]) == 2 and base["stage_end"][-1] == base["n_tiles"]
+	assert base["stage_pred"][0] in (0, 1) and base["stage_pred"][1] == 2       # mixed plan: 32x32x16 first, then 16x16x32
+	m32 = ops.fused_plan(10000, 100000, 256, 100, mfma32=True)
+	assert m32["lg"] == 2 and all(b in (0, 1) for b in m32["stage_pred"])
+	assert ops.fused_plan(10000, 100000, 256, 500)["lg"] == 2                   # k > 128: 32x32x16 throughout
+	assert all(b == 2 for b in ops.fused_plan(10000, 100000, 256, 100, mfma16=True)["stage_pred"])
+	assert ops.fused_plan(10000, 100000, 256, 100, mfma16=True)["lg"] == 1
+	assert ops.fused_plan(300, 40000, 64, 10, mfma16=True)["lg"] == 1
 	assert ops.fused_plan(10000, 100000, 256, 100, qt1=True)["QT"] == 1 and ops.fused_plan(10000, 100000, 128, 100, qt1=True)["QT"] == 1
 	assert ops.fused_plan(10000, 100000, 64, 100, qt1=True)["QT"] == 2       # Kp = 64 has no QT = 1 body
 	assert ops.fused_plan(6250, 1000000, 512, 100, mfma16=True, qt1=True)["lg"] == 2   # Kp = 512: one body whatever the flags
 	import inspect
 	src = inspect.getsource(ops.score_topk_fused.__wrapped__) + inspect.getsource(ops.score_topk_fused_timed.__wrapped__)
-	assert src.count("_topk_flags(leading_sample, mfma16, qt1)") == 2 and "mfma16=mfma16, qt1=qt1" in src
+	assert src.count("_topk_flags(leading_sample, mfma16, qt1, mfma32)") == 2 and "mfma16=mfma16, qt1=qt1, mfma32=mfma32" in src
 
 
 def test_product_never_imports_the_oracle():

@@ -73,7 +73,7 @@ def test_rowwise_topk_random(ops, Q, I, kfrac, bf16, kind, off, seed):
 
 @settings(max_examples=(_N // 4) or 25, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(Q=st.integers(1, 300), I=st.integers(2500, 90000), K=st.integers(8, 512), k=st.integers(1, 200), rank=st.integers(2, 48),
-	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), variant=st.sampled_from(["", "", "mfma16", "qt1"]))
+	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), variant=st.sampled_from(["", "", "mfma16", "qt1", "mfma32"]))
 def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	g = torch.Generator().manual_seed(seed)
 	X = torch.randn(Q, K, generator=g).bfloat16()
@@ -82,10 +82,11 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	if not ops.fused_supported(Q, I, Kp, k):
 		return
 	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
-	plan = ops.fused_plan(Q, I, Kp, k, mfma16=variant == "mfma16", qt1=variant == "qt1")
-	if Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128)
-		assert plan["lg"] == (4 if variant == "mfma16" else 2) and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
-	v, i = ops.score_topk_fused(Xp, Etp, I, k, mfma16=variant == "mfma16", qt1=variant == "qt1")   # (sweep variants: same answer)
+	kw = dict(mfma16=variant == "mfma16", qt1=variant == "qt1", mfma32=variant == "mfma32")
+	plan = ops.fused_plan(Q, I, Kp, k, **kw)
+	if Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = mixed where it fits)
+		assert plan["lg"] in {"mfma16": (1,), "mfma32": (2,), "qt1": (2,), "": (2, 3)}[variant] and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
+	v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)   # (sweep variants: same answer)
 	S = X.double() @ E.double()
 	rv, ri = torch.topk(S, k, dim=1)
 	scale = float(S.abs().max()) + 1e-30

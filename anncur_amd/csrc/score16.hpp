@@ -184,12 +184,12 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	w.limit = w.base + (uint32_t)(C::QCAP - 64 * (8 + 2 * (16 / K > 0 ? 16 / K : 1))) * 8u;  // see stagger16_tile: 8 + 2 EPS pushes between two checks
 	w.cnt = lds_base + (uint32_t)(C::CNT_OFF + wave_u * 256);
 	w.q_stride = (int64_t)p.nseg * p.capg;
-	w.seg = p.cand + (q_wave0 * p.nseg + p.seg_off + split) * (int64_t)p.capg;
+	w.seg = p.cand + (q_wave0 * p.nseg + split) * (int64_t)p.capg;
 	w.capg = (uint32_t)p.capg; w.n_items = (uint32_t)p.I; w.lane = lane;
 	uint32_t fill = w.base;
 	{
 		const int64_t q = q_wave0 + lane;
-		lds_store_u32(w.cnt + (uint32_t)lane * 4u, (p.carry && q < p.Q) ? p.seg_cnt[q * p.nseg + p.seg_off + split] : 0u);
+		lds_store_u32(w.cnt + (uint32_t)lane * 4u, (p.carry && q < p.Q) ? p.seg_cnt[q * p.nseg + split] : 0u);
 	}
 
 	// ---- tile schedule (see score_kernel): static contiguous share, or tickets of p.chunk_tiles tiles from the row block's counter
@@ -328,6 +328,6 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 		asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c) : "v"(w.cnt + (uint32_t)lane * 4u) : "memory");
 #endif
-		if (q < p.Q) p.seg_cnt[q * p.nseg + p.seg_off + split] = c;
+		if (q < p.Q) p.seg_cnt[q * p.nseg + split] = c;
 	}
 }

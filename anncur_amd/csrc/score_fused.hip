@@ -96,8 +96,7 @@ struct FusedParams {
 	float *gmax; int n_groups;        // prepass output [Q x n_groups]
 	const float *tau; int tau_stride; // threshold per query: tau[q * tau_stride]
 	uint2 *cand; uint32_t *seg_cnt; int capg;
-	int nseg, seg_off;                // candidate segments per query; first segment of the launched body within them (mixed-body plans)
-	int zero_off;                     // >= 0: the launch also zeroes seg_cnt[q * nseg + zero_off + split] (segments a later stage's body carries on from)
+	int nseg;                         // candidate segments per query (2 S: 32x32x16 body, lane halves; S: 16x16x32 body)
 	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	int debug_stamp;                  // timing experiments only: this launch writes the in-kernel clock stamps
@@ -567,14 +566,12 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #pragma unroll
 	for (int t = 0; t < QT; ++t) {
 		tau[t] = (MODE == 1 && qv[t] < p.Q) ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
-		ncand[t] = (MODE == 1 && p.carry && qv[t] < p.Q) ? p.seg_cnt[qv[t] * p.nseg + p.seg_off + h * p.S + split] : 0u;
+		ncand[t] = (MODE == 1 && p.carry && qv[t] < p.Q) ? p.seg_cnt[qv[t] * p.nseg + h * p.S + split] : 0u;
 		qcnt[t] = 0;
 	}
 	// candidate segment of (query, lane half, split); sub-tile t adds a wave-uniform stride
-	uint2 *seg0 = p.cand + (qv[0] * p.nseg + p.seg_off + h * p.S + split) * (int64_t)p.capg;
+	uint2 *seg0 = p.cand + (qv[0] * p.nseg + h * p.S + split) * (int64_t)p.capg;
 	const int64_t seg_dt = (int64_t)32 * p.nseg * p.capg;
-	if (MODE == 1 && p.zero_off >= 0 && tid < Cfg::BQ && (int64_t)rb * Cfg::BQ + tid < p.Q)  // (a later stage's body starts from these counts)
-		p.seg_cnt[((int64_t)rb * Cfg::BQ + tid) * p.nseg + p.zero_off + split] = 0u;
 	const uint32_t lq0 = lds_addr(smem + Cfg::QUEUE_OFF) + (uint32_t)tid * 8u;  // slot i of sub-tile t at byte lq0 + (t*QDEPTH + i)*2048
 	static_assert(Cfg::QUEUE_OFF % (Cfg::QDEPTH * 2048) == 0 && Cfg::QDEPTH * 2048 == 16384, "ring must be 16 KiB aligned");
 	if (MODE == 1 && (lds_addr(smem) & 0x3fffu) != 0u) __builtin_trap();  // filter_one() ORs the slot offset into the address
@@ -934,7 +931,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #pragma unroll
 		for (int t = 0; t < QT; ++t) {
 			flush_queue<Cfg::QDEPTH, FLUSH_BATCH>(lq0 + t * Cfg::QDEPTH * 2048, qcnt[t], seg0 + t * seg_dt, ncand[t], (uint32_t)p.capg, (uint32_t)p.I, tau[t], last_item0);
-			if (qv[t] < p.Q) p.seg_cnt[qv[t] * p.nseg + p.seg_off + h * p.S + split] = ncand[t];
+			if (qv[t] < p.Q) p.seg_cnt[qv[t] * p.nseg + h * p.S + split] = ncand[t];
 		}
 	}
 }
@@ -1378,11 +1375,9 @@ struct FusedPlan {
 	bool ok;
 	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
 	int n_stages, stage_end[3], stage_tps[3], stage_flush[3], stage_pred[3];
-	bool stage_body16[3];   // the stage runs score16_kernel
 	int leading;
-	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue), 3 (mixed)
-	bool body16;  // every sweep stage runs score16_kernel (ANNCUR_TOPK_MFMA16)
-	bool mixed;   // the first stage runs the 32x32x16 body (2 S ring segments per query), the later ones score16_kernel (S more segments)
+	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
+	bool body16;  // the sweep stages run score16_kernel
 	int chunk;  // dynamic tile schedule of the sweep stages: tiles per ticket (0: static shares)
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, off_ctr, off_owner, total;
 };
@@ -1424,9 +1419,11 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	// (dense rings, exec-mask filter) and every candidate it collects is read again by the refinement.  Measured at cfg2 size on MI355X
 	// (round 3, one box, alternating): k = 100 -- the model's 0.35 stays (0.245: + 2 % sweep time on the bench matrices, level on random
 	// operands); k = 500 -- the model's 0.35: 1.18 ms per call, 0.30 1.12, 0.22 1.11, 0.15 1.15 -> above k = 128 a two-stage plan
-	// takes 0.6 of the model's first fraction.
+	// takes 0.6 of the model's first fraction.  The 16x16x32 body (k <= 128) gains more from a tight threshold than it loses to a
+	// loose one (higher clock on sparse tiles, costlier pushes on dense ones): cfg2 sweep launches 0.458 ms at 0.35, 0.455 at 0.30,
+	// 0.453 at 0.26, 0.450 at 0.22, 0.453 at 0.18, 0.461 at 0.14 -> 0.63 of the model's fraction.
 	if (P.n_stages == 2) {
-		double shrink = k <= WSEL_K ? 1.0 : 0.6;
+		double shrink = P.body16 ? 0.63 : (k <= WSEL_K ? 1.0 : 0.6);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		if (const char *dbg = getenv("ANNCUR_DEBUG_F1_SHRINK")) shrink = atof(dbg);
 #endif
@@ -1507,8 +1504,12 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	if (P.chunk > 0 && k <= WQ_K2 && S > WAVE / 2) S = WAVE / 2;
 	if (S < 1) S = 1;
 	if (S > 255) S = P.chunk > 0 ? 255 : (S > 256 ? 256 : S);   // (the owner map holds a split in a byte, 255 = none)
-	// ANNCUR_TOPK_MFMA16: the 16x16x32 sweep (score16.hpp); its queue entries carry the query beside the item: I < 2^26
-	const bool want16 = mfma16 && KP <= 256 && I < (int64_t)(1 << 26);
+	// Body of the sweep stages (Kp <= 256, two sub-tiles per wave): 16x16x32 MFMAs with one candidate queue per wave (score16.hpp; its queue
+	// entries carry the query beside the item: I < 2^26) for k <= 128, 32x32x16 with per-lane rings above (at k = 500 half of the leading
+	// tiles' elements pass the first threshold: the rings' raw-tile hand-over is built for that).  ANNCUR_TOPK_MFMA16 / _MFMA32 force one.
+	// Measured at cfg2, MI355X, same box, alternating (round 3): sweep launches 0.457 ms (16x16x32) vs 0.479 (32x32x16) at equal stage
+	// split, 0.450 with the split below; a mixed plan (first stage 32x32x16, later stages 16x16x32) was level with 16x16x32 throughout.
+	const bool can16 = KP <= 256 && P.QT == 2 && I < (int64_t)(1 << 26);
 	if (S > P.n_tiles) S = P.n_tiles;
 	P.tiles_per_split = (P.n_tiles + S - 1) / S;
 	P.S = (P.n_tiles + P.tiles_per_split - 1) / P.tiles_per_split;
@@ -1517,26 +1518,18 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	if (S0 > P.n_st) S0 = P.n_st;
 	P.st_per_split = (P.n_st + S0 - 1) / S0;
 	P.S0 = (P.n_st + P.st_per_split - 1) / P.st_per_split;
-	// candidate segments per (query, item split): two (lane halves) in the 32x32x16 sweep, ONE in the 16x16x32 sweep (wave-level queue).
-	// Default for k <= 128 where the select takes 3 S segments: MIXED -- first stage on the 32x32x16 body (exec-mask filter, per-lane rings:
-	// the better of the two against the loose prepass threshold, 0.195 vs 0.205 ms at cfg2), later stages on the 16x16x32 body (the chip
-	// holds a higher clock on that shape and few compares hit: 0.249 vs 0.276 ms; MI355X, same box, alternating).  The bodies write
-	// disjoint segments of the same query: [0, 2 S) and [2 S, 3 S).
-	P.body16 = want16;
+	// candidate segments per (query, item split): two (lane halves) in the 32x32x16 sweep, ONE in the 16x16x32 sweep (wave-level queue)
+	P.body16 = can16 && !mfma32 && (mfma16 || k <= WSEL_K);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_MFMA16") && KP <= 256 && I < (int64_t)(1 << 26) && P.QT == 2) P.body16 = true;
+	if (getenv("ANNCUR_DEBUG_MFMA16")) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
 #endif
-	P.mixed = !P.body16 && !mfma32 && !mfma16 && P.QT == 2 && P.chunk > 0 && KP <= 256 && I < (int64_t)(1 << 26) && k <= WSEL_K && 3 * P.S <= WAVE;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_NO_MIXED")) P.mixed = false;
-#endif
-	P.lg = P.body16 ? 1 : (P.mixed ? 3 : 2);
+	P.lg = P.body16 ? 1 : 2;
 	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over lg S lane segments
 	// (segment capacity -- hence the workspace size -- is planned for the strided sample whatever the hint; with item rows ordered
 	//  by descending norm the leading sample's threshold lets ~40 % fewer elements through: measured on the synthetic protocol)
 	const double exp_hits_cap = 1.3 * k * ((double)P.n_tiles / P.n_st);
 	const double exp_hits = (leading ? 0.65 : 1.0) * exp_hits_cap;
-	const double per_seg = exp_hits_cap / ((double)(P.mixed ? 2 : P.lg) * P.S);   // (mixed: the first stage's ring segments take most of them)
+	const double per_seg = exp_hits_cap / ((double)P.lg * P.S);
 	int capg = next_pow2((int)(4.0 * per_seg) + 32);
 	if (capg < 64) capg = 64;
 	if (capg > 16384) capg = 16384;
@@ -1549,11 +1542,6 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	int ft = (int)(0.35 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
 	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
-	if (P.mixed && P.n_stages < 2) {  // a single stage: nothing for the second body to do
-		P.mixed = false; P.lg = 2;
-		plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
-	}
-	for (int g = 0; g < 3; ++g) P.stage_body16[g] = P.body16 || (P.mixed && g > 0);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_ctr = off;    off = align256(off + (size_t)P.n_rb * 3 * 4);   // ticket counters [stage][row block]: zeroed with the header, one memset
@@ -1765,7 +1753,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	p.tau_bias = 0.f;
 	p.chunk_tiles = 0; p.n_chunks = 0; p.chunk_ctr = nullptr; p.chunk_owner = nullptr;
-	p.nseg = P.lg * P.S; p.seg_off = 0; p.zero_off = -1;
+	p.nseg = P.lg * P.S;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
 		if (!g_stamps) {
@@ -1804,7 +1792,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	// the survivors crowd into the leading tiles, all the workgroups of a stage run at once, and with contiguous ranges the stage took
 	// as long as its FIRST split (cfg2: the first stage, 22 % of the tiles, 0.236 ms against 0.306 ms for the other 78 %).
 	// (score16_kernel keeps contiguous ranges)
-	const int tile_step = (!P.body16 && !P.mixed && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
+	const int tile_step = (!P.body16 && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
 	p.n_wg = P.n_rb * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
@@ -1812,10 +1800,6 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		p.tile_step = tile_step;
-		if (P.mixed) {  // disjoint segments per body; the first stage zeroes the counts the second body starts from
-			p.seg_off = P.stage_body16[stg] ? 2 * P.S : 0;
-			p.zero_off = stg == 0 ? 2 * P.S : -1;
-		}
 		if (chunk > 0) {
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
 			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb;
@@ -1836,7 +1820,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		}
 #endif
 		if constexpr (KP <= 256 && QTV == 2) {  // 16x16x32 sweep (score16.hpp): one segment per (query, item split)
-			if (!launched && P.stage_body16[stg]) {
+			if (!launched && P.body16) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score16_kernel<KP>, Fused16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((score16_kernel<KP>), dim3(p.n_wg), dim3(256), Fused16Cfg<KP>::LDS_BYTES, st, p);
 				launched = true;
@@ -2051,12 +2035,13 @@ constexpr int TOPK_FLAGS = ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANN
 }  // namespace
 
 extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
-	const FusedPlan P = plan_any(Q, I, Kp, k), P16 = plan_any(Q, I, Kp, k, ANNCUR_TOPK_MFMA16), P1 = plan_any(Q, I, Kp, k, ANNCUR_TOPK_QT1);  // (whatever flags the call will carry;
-	// ANNCUR_TOPK_MFMA32 never needs more than the default)
+	const FusedPlan P = plan_any(Q, I, Kp, k);
 	if (!P.ok) return 0;
 	size_t t = P.total;
-	if (P16.ok && P16.total > t) t = P16.total;
-	if (P1.ok && P1.total > t) t = P1.total;
+	for (int flags : {ANNCUR_TOPK_MFMA16, ANNCUR_TOPK_MFMA32, ANNCUR_TOPK_QT1}) {  // (whatever variant flag the call will carry)
+		const FusedPlan V = plan_any(Q, I, Kp, k, flags);
+		if (V.ok && V.total > t) t = V.total;
+	}
 	return t;
 }
 
@@ -2167,7 +2152,7 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 }
 
 /* the same for the flags of anncur_score_topk_ex: out[0 .. n_out) = {sample tiles, item tiles, S, segment capacity, group, segments per
- * query and item split (2: 32x32x16 sweep, 1: 16x16x32 sweep, 3: mixed, 4: wide kernel), 32-query sub-tiles per wave, sweep stages,
+ * query and item split (2: 32x32x16 sweep, 1: 16x16x32 sweep, 4: wide kernel), 32-query sub-tiles per wave, sweep stages,
  * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32), ring drain period[3]} --
  * what a test needs to see that a variant flag was honoured */
 extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
@@ -2178,7 +2163,7 @@ extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32
 	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
 	for (int g = 0; g < 3; ++g) {
 		const bool on = g < P.n_stages;
-		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.stage_body16[g] ? 2 : P.stage_pred[g]) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
+		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.body16 ? 2 : P.stage_pred[g]) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
 	}
 	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
 	return ANNCUR_OK;

@@ -390,7 +390,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 	leading_sample / item_ids: the index builder's hints of anncur_score_topk_ex (rows of Etp ordered by descending norm, and the
 	map from rows back to item ids); the result is the exact top-k either way.
 	mfma16 / mfma32 / qt1: the sweep variants ANNCUR_TOPK_MFMA16 / _MFMA32 / _QT1 (fused_plan(..., mfma16=, ...) tells whether the shape
-	takes them: "lg" == 1 / "lg" == 2 / "QT" == 1; the default for Kp <= 256, k <= 128 is the mixed plan, "lg" == 3)."""
+	takes them: "lg" == 1 / "lg" == 2 / "QT" == 1; the default for Kp <= 256 is the 16x16x32 body up to k = 128, 32x32x16 above)."""
 	_dev(Xp, Etp)
 	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16:
 		raise TypeError("score_topk_fused takes bf16 operands")
@@ -499,9 +499,9 @@ def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, m
 
 
 def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False):
-	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 body in every
-	sweep stage, 1 = the 16x16x32 body in every stage (mfma16 honoured), 3 = mixed (first stage 32x32x16, later stages 16x16x32: the default
-	for Kp <= 256, k <= 128), 4 = the wide kernel (Kp > 512); "QT": 32-query sub-tiles per wave (1 = qt1 honoured, or Kp = 512);
+	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 body (per-lane
+	rings; the default above k = 128, and for Kp = 512), 1 = the 16x16x32 body (one queue per wave; the default for Kp <= 256, k <= 128),
+	4 = the wide kernel (Kp > 512); "QT": 32-query sub-tiles per wave (1 = qt1 honoured, or Kp = 512);
 	"stage_pred": body of each sweep stage -- 0 / 1 = 32x32x16 with the ballot / exec-mask filter, 2 = 16x16x32."""
 	out = (ctypes.c_int32 * 17)()
 	check(_lib.load().anncur_score_topk_plan_ex(Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32), out, 17), "score_topk_plan_ex")

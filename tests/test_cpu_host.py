@@ -55,8 +55,8 @@ def test_sweep_variant_flags_reach_the_plan():
 	from anncur_amd import _lib, ops
 	assert ops._topk_flags() == 0 and ops._topk_flags(True, True, True, True) == (_lib.TOPK_LEADING_SAMPLE | _lib.TOPK_MFMA16 | _lib.TOPK_QT1 | _lib.TOPK_MFMA32)
 	base = ops.fused_plan(10000, 100000, 256, 100)
-	assert (base["lg"], base["QT"]) == (3, 2) and base["n_stages"] == len(base["stage_end"]) == 2 and base["stage_end"][-1] == base["n_tiles"]
-	assert base["stage_pred"][0] in (0, 1) and base["stage_pred"][1] == 2       # mixed plan: 32x32x16 first, then 16x16x32
+	assert (base["lg"], base["QT"]) == (1, 2) and base["n_stages"] == len(base["stage_end"]) == 2 and base["stage_end"][-1] == base["n_tiles"]
+	assert all(b == 2 for b in base["stage_pred"])                              # k <= 128: the 16x16x32 body in every stage
 	m32 = ops.fused_plan(10000, 100000, 256, 100, mfma32=True)
 	assert m32["lg"] == 2 and all(b in (0, 1) for b in m32["stage_pred"])
 	assert ops.fused_plan(10000, 100000, 256, 500)["lg"] == 2                   # k > 128: 32x32x16 throughout

@@ -186,7 +186,7 @@ def test_fused_mfma16_sweep_gives_the_same_topk(ops, Q, I, K, k):
 	assert ops.fused_plan(Q, I, Kp, k, mfma16=True)["lg"] == 1
 	assert ops.fused_plan(Q, I, Kp, k, qt1=True)["QT"] == (1 if Kp >= 128 else 2)
 	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma32=True)
-	# the default plan (mixed bodies where the shape takes them: first stage 32x32x16, later stages 16x16x32) -- same answer
+	# the default plan (the 16x16x32 body for k <= 128, the 32x32x16 body above) -- same answer
 	(vd, idd), nfbd = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
 	torch.cuda.synchronize()
 	assert nfbd.item() == 0
@@ -239,7 +239,7 @@ def test_fused_regression_dense_first_stage_found_by_fuzzing(ops):
 	rv, ri = torch.topk(S, k, dim=1)
 	for kw in ({}, {"mfma32": True}, {"mfma16": True}, {"qt1": True}):
 		plan = ops.fused_plan(Q, I, Kp, k, **kw)
-		assert (plan["lg"], plan["QT"]) in {(): ((2, 2), (3, 2)), ("mfma32",): ((2, 2),), ("mfma16",): ((1, 2),), ("qt1",): ((2, 1),)}[tuple(kw)], (kw, plan)
+		assert (plan["lg"], plan["QT"]) in {(): ((1, 2),), ("mfma32",): ((2, 2),), ("mfma16",): ((1, 2),), ("qt1",): ((2, 1),)}[tuple(kw)], (kw, plan)
 		v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)
 		assert (v.cpu().double() - rv).abs().max() <= 1e-4 * float(S.abs().max())
 		assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(i.cpu(), ri)), kw
@@ -294,23 +294,25 @@ def test_fused_local_overflow_is_repaired_exactly(ops):
 	assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(got[::37], ri[::37]))
 
 
-def test_fused_local_overflow_under_the_dynamic_tile_schedule(ops):
-	"""The default sweep draws its tiles as tickets (chunks of 4 tiles per query row block): which workgroup sweeps which tiles is decided
-	at run time, and the repair path finds a split's tiles in the chunk-owner map the sweep leaves behind.  Forced here: the first 256
-	items (the first two chunks, which ONE workgroup of every row block draws together at its start) score far above the rest for every
-	query -- 128 survivors per lane half against a segment capacity of 64 (and rings that wrap): that workgroup's segments overflow,
-	its chunks are recomputed from the owner map, the result is exact."""
+@pytest.mark.parametrize("body", ["mfma32", "default"])
+def test_fused_local_overflow_under_the_dynamic_tile_schedule(ops, body):
+	"""The sweep draws its tiles as tickets (chunks of 4 tiles per query row block): which workgroup sweeps which tiles is decided at run
+	time, and the repair path finds a split's tiles in the chunk-owner map the sweep leaves behind.  Forced here: the first 256 items
+	(the first two chunks, which ONE workgroup of every row block draws together at its start) score far above the rest for every
+	query -- 256 survivors per query in that workgroup's segments (32x32x16 body: 128 per lane half against a capacity of 64, and rings
+	that wrap; 16x16x32 body, the default at this k: 256 against its one segment per split): the segments overflow, the workgroup's
+	chunks are recomputed from the owner map, the result is exact."""
 	Q, I, K, k = 3000, 80000, 128, 10
-	plan = ops.fused_plan(Q, I, 128, k)
-	assert plan["QT"] == 2 and plan["lg"] in (2, 3) and plan["segment_capacity"] == 64   # (mixed or not: the first stage is the 32x32x16 body)
-	assert plan["stage_pred"][0] in (0, 1)
+	kw = {"mfma32": True} if body == "mfma32" else {}
+	plan = ops.fused_plan(Q, I, 128, k, **kw)
+	assert plan["QT"] == 2 and plan["lg"] == (2 if body == "mfma32" else 1) and plan["segment_capacity"] * plan["lg"] < 256
 	g = _g(777)
 	X = (1.0 + 0.1 * torch.randn(Q, K, generator=g)).bfloat16()
 	E = 0.05 * torch.randn(K, I, generator=g)
 	E[:, :256] += 0.5
 	E = E.bfloat16()
 	Xp = ops.pack_bf16(X.cuda(), 128); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 128, row_multiple=32)
-	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, **kw)
 	torch.cuda.synchronize()
 	assert nfb.item() > 0                                      # the local repair ran
 	S = X.double() @ E.double()
@@ -320,7 +322,7 @@ def test_fused_local_overflow_under_the_dynamic_tile_schedule(ops):
 	assert (got < 256).all()
 	assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(got[::37], ri[::37]))
 	# and again: the owner map of the previous call must not leak into this one (another assignment, same answer)
-	(v2, i2), _ = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	(v2, i2), _ = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, **kw)
 	assert torch.equal(v2, v) and torch.equal(torch.sort(i2, 1).values, torch.sort(i, 1).values)
 
 

@@ -84,8 +84,8 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
 	kw = dict(mfma16=variant == "mfma16", qt1=variant == "qt1", mfma32=variant == "mfma32")
 	plan = ops.fused_plan(Q, I, Kp, k, **kw)
-	if Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = mixed where it fits)
-		assert plan["lg"] in {"mfma16": (1,), "mfma32": (2,), "qt1": (2,), "": (2, 3)}[variant] and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
+	if Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = 16x16x32 up to k = 128)
+		assert plan["lg"] in {"mfma16": (1,), "mfma32": (2,), "qt1": (2,), "": (1, 2)}[variant] and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
 	v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)   # (sweep variants: same answer)
 	S = X.double() @ E.double()
 	rv, ri = torch.topk(S, k, dim=1)

@@ -70,6 +70,28 @@ int anncur_event_pool(hipEvent_t **out, int n) {
 	return ANNCUR_OK;
 }
 
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+// Where a workgroup runs: {XCC_ID, HW_ID} (diagnostic build: which CUs a stream's CU mask leaves -- scripts/cumask_map.py)
+namespace {
+__global__ void where_kernel(uint32_t *out) {
+	if (threadIdx.x == 0) {
+		uint32_t xcc = 0, hw = 0;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hw));
+		out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw;
+	}
+	// a little work so that the workgroups of a launch spread over every CU the queue may use
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+	while (__builtin_amdgcn_s_memrealtime() - t0 < 2000) { }   // 20 us
+}
+}
+extern "C" int anncur_debug_where(uint32_t *out, int n_wg, void *stream) {
+	ANNCUR_REQUIRE(out && n_wg > 0, ANNCUR_E_INVALID, "debug_where: bad arguments");
+	hipLaunchKernelGGL(where_kernel, dim3(n_wg), dim3(64), 0, (hipStream_t)stream, out);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+#endif
+
 extern "C" int anncur_version(void) { return 1000 * 0 + 3; }
 
 extern "C" const char *anncur_last_error(void) { return g_err; }

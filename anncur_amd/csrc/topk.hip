@@ -225,7 +225,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
 																 uint32_t trig, float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int lane = lane_id(), wave = threadIdx.x >> 6;
+	// (the wave index through readfirstlane: the compiler then knows the row pointer is wave-uniform and keeps the stream's base address
+	//  in scalar registers -- without it every load of the stream carried 64-bit per-lane address arithmetic)
+	const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
 	if (q >= Q) return;
 	WaveSel w = wsel_init<WS_CAP>(smem + wave * WaveSelLayout<WS_CAP>::BYTES);
@@ -300,15 +302,15 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		__builtin_amdgcn_wave_barrier();                                                                                        \
 		if (w.cnt > trig) wsel_compact_call<WS_CAP, HP, true>(w, k, tie_limit);                                                 \
 	}
-#define SCAN_STEP(d)                                                                                                            \
+#define SCAN_STEP(d, FULL)                                                                                                      \
 	{                                                                                                                           \
 		const u32x4 cur = pf[d];                                                                                                \
-		const int64_t iv = (s0 + (d)) * WAVE + lane;                                                                            \
 		const u32x4 y = sp.xform(cur);                                                                                          \
 		bool pass = sp.any(y);                                                                                                  \
-		if (full) {                                                                                                             \
-			pf[d] = __builtin_nontemporal_load(vp + iv + (int64_t)WS_PF * WAVE);                                                \
+		if (FULL) {  /* the block and its prefetch lie inside the row: wave-uniform base + lane, nothing to clamp */            \
+			pf[d] = __builtin_nontemporal_load(blk + ((d) + WS_PF) * WAVE + lane);                                              \
 		} else {  /* the last blocks: prefetches clamped, steps past the row masked (never branched around) */                  \
+			const int64_t iv = (s0 + (d)) * WAVE + lane;                                                                        \
 			const int64_t ivn = iv + (int64_t)WS_PF * WAVE;                                                                     \
 			pf[d] = vp[ivn < nvec ? ivn : vlast];                                                                               \
 			pass = pass && iv < nvec;                                                                                           \
@@ -320,16 +322,27 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 			if (pass) {                                                                                                         \
 				const uint32_t pos = scnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u)); \
 				stage_vec[pos] = cur;                                                                                           \
-				stage_idx[pos] = (uint32_t)(head + iv * VEC);                                                                   \
+				stage_idx[pos] = (uint32_t)(head + ((s0 + (d)) * WAVE + lane) * VEC);                                           \
 			}                                                                                                                   \
 			scnt += np;                                                                                                         \
 		}                                                                                                                       \
 	}
 	static_assert(WS_PF == 8, "the block spells out eight steps");
-	for (int64_t s0 = 0; s0 < nsteps; s0 += WS_PF) {
+	// Two loops (round 3): the blocks whose prefetches lie inside the row -- all but the last one or two -- carry no per-lane index
+	// arithmetic and no clamp (the one-loop version spent ~130 instructions per 16-byte step, most of them 64-bit address and mask
+	// work for a case that arises in the last block only; that did not matter with 256 CUs on the stream, HBM-bound either way, but it
+	// caps what a PART of the chip can stream: 31 GB/s per CU -- see bench.py --scan-mode partition).
+	int64_t s0 = 0;
+	for (; (s0 + 2 * WS_PF) * WAVE <= nvec; s0 += WS_PF) {
 		sp.set(w.tau);  // frozen for the block
-		const bool full = (s0 + 2 * WS_PF) * WAVE <= nvec;  // (wave-uniform) the block and its prefetch lie inside the row
-		SCAN_STEP(0) SCAN_STEP(1) SCAN_STEP(2) SCAN_STEP(3) SCAN_STEP(4) SCAN_STEP(5) SCAN_STEP(6) SCAN_STEP(7)
+		const u32x4 *blk = vp + s0 * WAVE;  // (uniform)
+		SCAN_STEP(0, true) SCAN_STEP(1, true) SCAN_STEP(2, true) SCAN_STEP(3, true) SCAN_STEP(4, true) SCAN_STEP(5, true) SCAN_STEP(6, true) SCAN_STEP(7, true)
+	}
+	for (; s0 < nsteps; s0 += WS_PF) {
+		sp.set(w.tau);
+		const u32x4 *blk = vp;  // (unused)
+		(void)blk;
+		SCAN_STEP(0, false) SCAN_STEP(1, false) SCAN_STEP(2, false) SCAN_STEP(3, false) SCAN_STEP(4, false) SCAN_STEP(5, false) SCAN_STEP(6, false) SCAN_STEP(7, false)
 	}
 	if (scnt > 0u) SCAN_DRAIN()
 #undef SCAN_STEP

@@ -440,6 +440,40 @@ def aux_stream(device):
 	return _aux_streams[key]
 
 
+_cu_streams = {}
+
+
+def cu_partition_streams(device, n_scan):
+	"""Two streams that split the chip's compute units: (retrieval stream on the CUs the scan leaves, scan stream on `n_scan` CUs), by
+	hipExtStreamCreateWithCUMask.  On MI355X the first n bits of the mask stand for n / 8 CUs on each of the 8 XCDs, in steps of 32
+	bits (scripts/cumask_map.py; sparse masks are ignored by the driver), so n_scan is rounded down to a multiple of 32.  For an
+	HBM-bound kernel (the exact scan) beside an MFMA-bound one (the fused retrieval) whose workgroups fill the register file: sharing a
+	CU means time-slicing it, a partition lets both run for the whole step.  Created once per (device, n_scan); fails loudly if the
+	runtime lacks the call."""
+	device = torch.device(device)
+	idx = device.index if device.index is not None else torch.cuda.current_device()
+	n_cu = torch.cuda.get_device_properties(idx).multi_processor_count
+	n_scan = (int(n_scan) // 32) * 32
+	if not (0 < n_scan < n_cu):
+		raise ValueError(f"cu_partition_streams: n_scan={n_scan} must leave CUs on both sides of {n_cu}")
+	key = (idx, n_scan)
+	if key not in _cu_streams:
+		hip = ctypes.CDLL("libamdhip64.so")
+		fn = hip.hipExtStreamCreateWithCUMask
+		fn.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+		words = (n_cu + 31) // 32
+		def make(lo, hi):
+			mask = (ctypes.c_uint32 * words)(*[sum(1 << b for b in range(32) if lo <= 32 * w + b < hi) for w in range(words)])
+			h = ctypes.c_void_p()
+			with torch.cuda.device(idx):
+				rc = fn(ctypes.byref(h), words, mask)
+			if rc != 0 or not h.value:
+				raise _lib.AnncurHipError(f"hipExtStreamCreateWithCUMask failed (code {rc})")
+			return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
+		_cu_streams[key] = (make(n_scan, n_cu), make(0, n_scan))
+	return _cu_streams[key]
+
+
 @_on_device
 def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False, mfma32=False):
 	"""The per-query evaluation loop's two top-k's in one call (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:97-106):

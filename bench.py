@@ -120,9 +120,12 @@ def main():
 	ap.add_argument("--no-ivf", action="store_true", help="skip the ivf_search side-line (the IVF-flat branch of build_flat_or_ivff_index at the hard-negative-mining size)")
 	ap.add_argument("--seed", type=int, default=0)
 	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
-	ap.add_argument("--scan-mode", default="side", choices=["side", "tail", "chunks", "serial"],
-					help="how the exact scan is scheduled against the retrieval: side = on a second stream from the start of the step, joined before the overlap "
-						 "count; chunks = anncur_eval_topk (row chunks forked beside the retrieval's latency-bound launches); serial = one stream")
+	ap.add_argument("--scan-cus", type=int, default=96, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD)")
+	ap.add_argument("--scan-mode", default=None, choices=["side", "partition", "tail", "chunks", "serial"],
+					help="how the exact scan is scheduled against the retrieval: partition = on a stream whose CU mask leaves it --scan-cus CUs, beside the "
+						 "retrieval on all of them (default where the retrieval's sweep draws its tiles dynamically: Kp <= 256); side = on a second stream "
+						 "from the start of the step, joined before the overlap count (default otherwise); chunks = anncur_eval_topk (row chunks forked "
+						 "beside the retrieval's latency-bound launches); serial = one stream")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,79 +213,149 @@ def main():
 
 	if args.no_overlap:
 		args.scan_mode = "serial"
-	side = ops.aux_stream(device) if args.scan_mode in ("side", "tail") else None
+	if args.scan_mode is None:
+		# Measured on MI355X, one box (round 3): cfg2 (Kp = 256) 0.939 ms per step with the partition, 1.007 with "side"; the cfg4 per-GPU
+		# shape (Kp = 512: static tile shares, and a scan a third of the step) 9.00 vs 7.42 -- a workgroup that shares its CU with the scan
+		# for the whole launch holds a static share back, the dynamic schedule just hands it fewer tiles.
+		args.scan_mode = "partition" if Kp <= 256 else "side"
 	rounds_rows = int(os.environ.get("ANNCUR_BENCH_ROUND_ROWS", "4096"))
 
-	def gpu_step_tail():
-		# The exact scan runs one wave per row and keeps `rounds_rows` rows in flight; a launch costs whole rounds: a FULL round is
-		# bandwidth-bound (4096 rows of 200 KB: 145 us = 5.7 TB/s), a partial one is latency-bound (92 us however few rows).  So: the
-		# full rounds first, alone on the chip; the partial round on the second stream beside the retrieval's latency-bound head
-		# (gather, prepass, threshold: 145 us that leave HBM and most CUs idle); the MFMA-bound sweeps then run undisturbed.
-		main = torch.cuda.current_stream()
-		ev = torch.empty((Q, k), dtype=torch.float32, device=device); ei = torch.empty((Q, k), dtype=torch.int32, device=device)
-		full = (Q // rounds_rows) * rounds_rows
-		if full > 0:
-			ops.rowwise_topk(A_test[:full], k, out=(ev[:full], ei[:full]))
-		if full < Q:
-			side.wait_stream(main)
-			with torch.cuda.stream(side):
-				ops.rowwise_topk(A_test[full:], k, out=(ev[full:], ei[full:]))
-		Xq = ops.gather_cols(A_test, anc_dev)
-		if Xq.shape[1] != Kp:
-			Xq = ops.pack_bf16(Xq, Kp)
-		approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
-		main.wait_stream(side)
-		return ops.overlap_counts(ei, approx.indices, cells)
-
-	def gpu_step():
-		if args.scan_mode == "tail":
-			return gpu_step_tail()
-		main = torch.cuda.current_stream()
-		if args.scan_mode == "side":
-			# the exact scan (HBM-bound, a8) is independent of the retrieval until the overlap count: it starts on a second stream with the
-			# step and the hardware interleaves its workgroups with the retrieval's (measured, one box, alternating: 1.097 ms per step against
-			# 1.134 on one stream; cutting the scan into row chunks beside the retrieval's latency-bound launches -- --scan-mode chunks,
-			# anncur_eval_topk -- lost to both at this size: a chunk of one round of rows streams at 3.7 TB/s, the whole scan at 5.6)
-			side.wait_stream(main)
-			with torch.cuda.stream(side):
-				exact = ops.rowwise_topk(A_test, k)
+	def retrieve():
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
-		if args.scan_mode == "side":
-			approx = ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)   # a6 + a7 fused (item rows in the index's norm order)
+		return ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)   # a6 + a7 fused (item rows in the index's norm order)
+
+	def make_launcher(mode):
+		"""launch(slot) for one way of placing the exact scan (a8's HBM-bound half) beside the MFMA-bound retrieval:
+		  side      the scan starts on a second stream with the step, the hardware interleaves its workgroups with the retrieval's;
+		  partition the chip's CUs are split between the two (streams with CU masks, ops.cu_partition_streams): the scan streams on
+		            --scan-cus CUs while the retrieval's dynamic tile schedule runs on the rest -- no time-slicing of a CU between a
+		            register-filling MFMA kernel and a latency-bound stream;
+		  tail / chunks / serial   earlier schedules, kept for A/B."""
+		side = ops.aux_stream(device) if mode in ("side", "tail") else None
+
+		def gpu_step_tail():
+			# The exact scan runs one wave per row and keeps `rounds_rows` rows in flight; a launch costs whole rounds: a FULL round is
+			# bandwidth-bound (4096 rows of 200 KB: 145 us = 5.7 TB/s), a partial one is latency-bound (92 us however few rows).  So: the
+			# full rounds first, alone on the chip; the partial round on the second stream beside the retrieval's latency-bound head
+			# (gather, prepass, threshold: 145 us that leave HBM and most CUs idle); the MFMA-bound sweeps then run undisturbed.
+			main = torch.cuda.current_stream()
+			ev = torch.empty((Q, k), dtype=torch.float32, device=device); ei = torch.empty((Q, k), dtype=torch.int32, device=device)
+			full = (Q // rounds_rows) * rounds_rows
+			if full > 0:
+				ops.rowwise_topk(A_test[:full], k, out=(ev[:full], ei[:full]))
+			if full < Q:
+				side.wait_stream(main)
+				with torch.cuda.stream(side):
+					ops.rowwise_topk(A_test[full:], k, out=(ev[full:], ei[full:]))
+			approx = retrieve()
 			main.wait_stream(side)
-		else:
-			exact, approx = ops.eval_topk(A_test, k, Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, serial=args.scan_mode == "serial")
-		return ops.overlap_counts(exact.indices, approx.indices, cells)   # a8 rerank (closed form) + a10
+			return ops.overlap_counts(ei, approx.indices, cells)
 
-	# The ten launches of a step are captured once into a HIP graph and replayed: per-dispatch latency on a busy host
-	# otherwise dominates (the kernels of a step total ~1.6 ms).  --no-graph keeps the eager launches.
-	# The counts reach the host through a copy kernel that writes into mapped pinned memory (inside the graph): a step is ONE
-	# graph replay, with no copy-engine hop whose cross-queue dependency a busy host would have to resolve.
-	graphs = None
-	if not args.no_graph:
-		ops.copy_to_mapped_host(gpu_step(), pinned[0]); torch.cuda.synchronize()   # workspace / code objects loaded outside capture
-		try:
-			graphs = []
-			for slot in range(2):
-				g = torch.cuda.CUDAGraph()
-				# thread_local: other threads of the process (the RCCL watchdog of a multi-rank run) may touch the runtime meanwhile
-				with torch.cuda.graph(g, capture_error_mode="thread_local"):
-					ops.copy_to_mapped_host(gpu_step(), pinned[slot])
-				graphs.append(g)
-		except Exception as exc:  # never lose the measurement to a capture problem: fall back to eager launches
-			print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
-			graphs = None
-			torch.cuda.synchronize()
+		def gpu_step():
+			if mode == "tail":
+				return gpu_step_tail()
+			main = torch.cuda.current_stream()
+			if mode == "side":
+				# the exact scan (HBM-bound, a8) is independent of the retrieval until the overlap count: it starts on a second stream with the
+				# step and the hardware interleaves its workgroups with the retrieval's (measured, one box, alternating: 1.097 ms per step against
+				# 1.134 on one stream; cutting the scan into row chunks beside the retrieval's latency-bound launches -- --scan-mode chunks,
+				# anncur_eval_topk -- lost to both at this size: a chunk of one round of rows streams at 3.7 TB/s, the whole scan at 5.6)
+				side.wait_stream(main)
+				with torch.cuda.stream(side):
+					exact = ops.rowwise_topk(A_test, k)
+				approx = retrieve()
+				main.wait_stream(side)
+			else:
+				Xq = ops.gather_cols(A_test, anc_dev)
+				if Xq.shape[1] != Kp:
+					Xq = ops.pack_bf16(Xq, Kp)
+				exact, approx = ops.eval_topk(A_test, k, Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, serial=mode == "serial")
+			return ops.overlap_counts(exact.indices, approx.indices, cells)   # a8 rerank (closed form) + a10
 
-	def launch(slot):
-		if graphs is not None:
-			graphs[slot].replay()
-		else:
-			ops.copy_to_mapped_host(gpu_step(), pinned[slot])
-		events[slot].record()
-		return slot
+		if mode == "partition":
+			# The scan on a stream whose CU mask leaves it --scan-cus CUs (ops.cu_partition_streams), issued FIRST; the retrieval on the
+			# unmasked stream: its workgroups take the other CUs outright and share the scan's (the dynamic tile schedule gives the slower
+			# workgroups fewer tiles).  Three pieces, each a HIP graph of its own replayed ON its stream (a forked branch inside one graph
+			# would run on a stream of the runtime's choosing, without the mask): scan | gather + retrieval | overlap counts + copy to the
+			# mapped host buffer.  The scan of step i+1 may start while step i's retrieval runs: it waits only for the overlap count that
+			# last read its result buffers (two steps back).
+			# (neither piece on the default stream: hipExtStreamCreateWithCUMask makes a BLOCKING stream, which the NULL stream synchronises
+			#  with implicitly -- with the retrieval there the two ran strictly one after the other: 1.41 ms per step)
+			_, s_st = ops.cu_partition_streams(device, args.scan_cus)
+			main = torch.cuda.Stream(device=device)
+			main.wait_stream(torch.cuda.current_stream()); s_st.wait_stream(torch.cuda.current_stream())
+			state = [{} for _ in range(2)]
+			tail_done = [torch.cuda.Event() for _ in range(2)]
+			def piece_scan(slot): state[slot]["exact"] = ops.rowwise_topk(A_test, k)
+			def piece_retr(slot): state[slot]["approx"] = retrieve()
+			def piece_tail(slot): ops.copy_to_mapped_host(ops.overlap_counts(state[slot]["exact"].indices, state[slot]["approx"].indices, cells), pinned[slot])
+			pieces = ((piece_scan, s_st), (piece_retr, main), (piece_tail, main))
+			for fn, st in pieces:   # workspaces / code objects loaded outside capture
+				with torch.cuda.stream(st): fn(0)
+				torch.cuda.synchronize()
+			pgraphs = None
+			if not args.no_graph:
+				try:
+					pgraphs = []
+					for slot in range(2):
+						gs = []
+						for fn, st in pieces:
+							g = torch.cuda.CUDAGraph()
+							with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+								fn(slot)
+							gs.append(g)
+						pgraphs.append(gs)
+				except Exception as exc:
+					print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
+					pgraphs = None
+					torch.cuda.synchronize()
+			for e in tail_done: e.record(main)
+			def launch_partition(slot):
+				s_st.wait_event(tail_done[slot])
+				for j, (fn, st) in enumerate(pieces):
+					if j == 2:
+						main.wait_stream(s_st)
+					with torch.cuda.stream(st):
+						if pgraphs is not None: pgraphs[slot][j].replay()
+						else: fn(slot)
+				tail_done[slot].record(main)
+				events[slot].record(main)
+				return slot
+			return launch_partition, pgraphs is not None
+
+		# The ten launches of a step are captured once into a HIP graph and replayed: per-dispatch latency on a busy host
+		# otherwise dominates (the kernels of a step total ~1.6 ms).  --no-graph keeps the eager launches.
+		# The counts reach the host through a copy kernel that writes into mapped pinned memory (inside the graph): a step is ONE
+		# graph replay, with no copy-engine hop whose cross-queue dependency a busy host would have to resolve.
+		graphs = None
+		if not args.no_graph:
+			ops.copy_to_mapped_host(gpu_step(), pinned[0]); torch.cuda.synchronize()   # workspace / code objects loaded outside capture
+			try:
+				graphs = []
+				for slot in range(2):
+					g = torch.cuda.CUDAGraph()
+					# thread_local: other threads of the process (the RCCL watchdog of a multi-rank run) may touch the runtime meanwhile
+					with torch.cuda.graph(g, capture_error_mode="thread_local"):
+						ops.copy_to_mapped_host(gpu_step(), pinned[slot])
+					graphs.append(g)
+			except Exception as exc:  # never lose the measurement to a capture problem: fall back to eager launches
+				print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
+				graphs = None
+				torch.cuda.synchronize()
+
+		def launch_one(slot):
+			if graphs is not None:
+				graphs[slot].replay()
+			else:
+				ops.copy_to_mapped_host(gpu_step(), pinned[slot])
+			events[slot].record()
+			return slot
+		return launch_one, graphs is not None
+
+	launchers = {args.scan_mode: make_launcher(args.scan_mode)}
+	launch, graphed = None, False
 
 	def finish(slot):
 		t_a = time.perf_counter()
@@ -315,6 +388,8 @@ def main():
 			torch.distributed.barrier()
 		torch.cuda.synchronize()
 
+	launch, graphed = launchers[args.scan_mode]
+	scan_mode_used = args.scan_mode
 	res = run_steps(args.warmup)
 	barrier()
 	t0 = time.perf_counter()
@@ -459,7 +534,8 @@ def main():
 			"index_build_what": "gather anchor columns + U = pinv(W) + E = U.R + bf16 packs; pinv 'auto' = fp64 Newton-Schulz on the GPU (host LAPACK only for ill-conditioned blocks); numpy = the reference's host call",
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
 			"fused_plan": plan_now,
-			"launch_mode": "eager" if graphs is None else "hipGraph replay (the step's launches captured once per result slot)",
+			"launch_mode": "eager" if not graphed else "hipGraph replay (the step's launches captured once per result slot)",
+			"scan_mode": {"used": scan_mode_used, "scan_cus": args.scan_cus if scan_mode_used == "partition" else None},
 			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
 			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),
 		}

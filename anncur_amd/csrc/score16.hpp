@@ -30,7 +30,13 @@ struct Fused16Cfg {
 	static constexpr int CPR = KP / 8;
 	static constexpr int TILE_BYTES = TILE_I * KP * 2;
 	static constexpr int QCAP = 1024;                // entries of a wave's queue
-	static constexpr int DRAIN_AT = 192;             // a step drains at its head from this fill on (three full passes)
+#if defined(ANNCUR_V_DRAIN128)
+	static constexpr int DRAIN_AT = 128;
+#elif defined(ANNCUR_V_DRAIN320)
+	static constexpr int DRAIN_AT = 320;
+#else
+	static constexpr int DRAIN_AT = 192;             // a step drains at its head from this fill on (three full passes; 128 / 320 measured: see DESIGN 4.1)
+#endif
 	static constexpr int QUEUE_OFF = 2 * TILE_BYTES;
 	static constexpr int CNT_OFF = QUEUE_OFF + 4 * QCAP * 8;        // 256 per-query candidate counts of this item split
 	static constexpr int TICKET_OFF = CNT_OFF + 256 * 4;            // ticket words of the dynamic tile schedule (score_kernel)

@@ -937,6 +937,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 }
 
 #include "score16.hpp"
+#include "score_q1.hpp"
 
 // ------------------------------------------------------------------ a11: approximation error on the same MFMA loop
 // err_sq[q] += sum_i (S_hat[q,i] - A[q,i])^2, norm_sq[q] += sum_i A[q,i]^2 over this workgroup's item tiles; S_hat is never
@@ -1378,6 +1379,7 @@ struct FusedPlan {
 	int leading;
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
 	bool body16;  // the sweep stages run score16_kernel
+	bool bodyq1;  // the sweep stages run scoreq1_kernel (Kp = 512)
 	int chunk;  // dynamic tile schedule of the sweep stages: tiles per ticket (0: static shares)
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, off_ctr, off_owner, total;
 };
@@ -1495,7 +1497,13 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	// Dynamic tile schedule (staggered 32x32x16 sweep, Kp <= 256): tickets of CHUNK_TILES tiles per query row block instead of fixed shares
 	// (score_kernel).  Workgroups per row block: enough to fill every slot (rounded UP -- a workgroup that finds no ticket left ends at
 	// once), at most 32 so that the 2 S segments of a query fit the wave-level select.
-	const bool ticketed = P.QT == 2;   // the bodies with the ticket schedule (32x32x16 staggered and 16x16x32; Kp = 512 has no LDS to spare for the ticket words: FusedCfg)
+	// Kp = 512: the body with the wave-level queue (score_q1.hpp: queue + counters + ticket words fit the 16 KB the rings took) unless
+	// ANNCUR_TOPK_MFMA32 asks for the per-lane-ring body (static shares: no LDS left for its ticket words) or I >= 2^26
+	P.bodyq1 = KP == 512 && !mfma32 && I < (int64_t)(1 << 26);
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (getenv("ANNCUR_DEBUG_NO_Q1")) P.bodyq1 = false;
+#endif
+	const bool ticketed = P.QT == 2 || P.bodyq1;   // the bodies with the ticket schedule
 	P.chunk = ticketed ? CHUNK_TILES : 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = ticketed ? atoi(dbg) : 0;
@@ -1523,7 +1531,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_MFMA16")) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
 #endif
-	P.lg = P.body16 ? 1 : 2;
+	P.lg = (P.body16 || P.bodyq1) ? 1 : 2;
 	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over lg S lane segments
 	// (segment capacity -- hence the workspace size -- is planned for the strided sample whatever the hint; with item rows ordered
 	//  by descending norm the leading sample's threshold lets ~40 % fewer elements through: measured on the synthetic protocol)
@@ -1768,7 +1776,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (getenv("ANNCUR_DEBUG_NOSTORE")) { p.capg = 0; item_ids = nullptr; }  // every candidate is dropped at the store (the select then reads slots nobody wrote: no id map through them)
 #endif
 
-	const int chunk = (P.chunk > 0 && Cfg::QT == 2) ? P.chunk : 0;   // (the one-sub-tile bodies keep static shares)
+	const int chunk = (P.chunk > 0 && (Cfg::QT == 2 || P.bodyq1)) ? P.chunk : 0;   // (the one-sub-tile bodies with per-lane rings keep static shares)
 	const int owner_stride = P.n_rb * (P.n_tiles / (chunk > 0 ? chunk : P.n_tiles) + 2);
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, chunk > 0 ? P.off_gmax : 256, st));   // header (+ the stages' ticket counters)
 	EV(0);
@@ -1792,7 +1800,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	// the survivors crowd into the leading tiles, all the workgroups of a stage run at once, and with contiguous ranges the stage took
 	// as long as its FIRST split (cfg2: the first stage, 22 % of the tiles, 0.236 ms against 0.306 ms for the other 78 %).
 	// (score16_kernel keeps contiguous ranges)
-	const int tile_step = (!P.body16 && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
+	const int tile_step = (!P.body16 && !P.bodyq1 && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
 	p.n_wg = P.n_rb * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
@@ -1819,6 +1827,13 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			launched = true;
 		}
 #endif
+		if constexpr (KP == 512) {  // Kp = 512 with the wave-level queue and tickets (score_q1.hpp)
+			if (!launched && P.bodyq1) {
+				if ((rc = anncur_ensure_dyn_lds((const void *)scoreq1_kernel<KP>, FusedQ1Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((scoreq1_kernel<KP>), dim3(p.n_wg), dim3(256), FusedQ1Cfg<KP>::LDS_BYTES, st, p);
+				launched = true;
+			}
+		}
 		if constexpr (KP <= 256 && QTV == 2) {  // 16x16x32 sweep (score16.hpp): one segment per (query, item split)
 			if (!launched && P.body16) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score16_kernel<KP>, Fused16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
@@ -2153,7 +2168,8 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 
 /* the same for the flags of anncur_score_topk_ex: out[0 .. n_out) = {sample tiles, item tiles, S, segment capacity, group, segments per
  * query and item split (2: 32x32x16 sweep, 1: 16x16x32 sweep, 4: wide kernel), 32-query sub-tiles per wave, sweep stages,
- * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32), ring drain period[3]} --
+ * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32, 3: Kp = 512 with the
+ * wave-level queue), ring drain period[3]} --
  * what a test needs to see that a variant flag was honoured */
 extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
 	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
@@ -2163,7 +2179,7 @@ extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32
 	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
 	for (int g = 0; g < 3; ++g) {
 		const bool on = g < P.n_stages;
-		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.body16 ? 2 : P.stage_pred[g]) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
+		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.body16 ? 2 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g])) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
 	}
 	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
 	return ANNCUR_OK;

@@ -10,8 +10,8 @@ if [[ $part == *A* ]]; then
 echo "== bench cfg2"; python3 bench.py > $out/bench_cfg2_n1.json 2> $out/bench_cfg2.err
 echo "== bench cfg4 per gpu"; python3 bench.py --config cfg4_per_gpu --no-ivf > $out/bench_cfg4_per_gpu_n1.json 2> $out/bench_cfg4.err
 echo "== bench 2 ranks gloo"; python3 bench.py --gpus 2 --backend gloo --share-gpu --steps 5 --warmup 2 --sustained-seconds 0 > $out/bench_cfg4_2ranks_gloo_one_gpu_rehearsal.json 2> $out/bench_2r.err
-echo "== profile cfg2"; bash scripts/profile_round.sh r03 cfg2 > $out/profile_cfg2.log 2>&1
-echo "== profile cfg4"; bash scripts/profile_round.sh r03 cfg4_per_gpu > $out/profile_cfg4.log 2>&1
+echo "== profile cfg2"; bash scripts/profile_round.sh r03_cfg2 cfg2 > $out/profile_cfg2.log 2>&1
+echo "== profile cfg4"; bash scripts/profile_round.sh r03_cfg4 cfg4_per_gpu > $out/profile_cfg4.log 2>&1
 fi
 if [[ $part == *B* ]]; then
 echo "== variant kernels under rocprof"

@@ -204,6 +204,42 @@ def test_fused_mfma16_sweep_gives_the_same_topk(ops, Q, I, K, k):
 	assert (torch.sort(i1, 1).values == torch.sort(i, 1).values).float().mean() > 0.9995
 
 
+@pytest.mark.parametrize("Q,I,K,k", [(257, 70000, 512, 100), (1000, 60007, 400, 10), (130, 131072, 512, 500)])
+def test_fused_kp512_queue_body_equals_the_ring_body(ops, Q, I, K, k):
+	"""Kp = 512 has one MFMA shape and two candidate paths: one queue per wave with the dynamic tile schedule (score_q1.hpp, the default)
+	and per-lane rings with static shares (ANNCUR_TOPK_MFMA32).  Same MFMAs in the same order: values bit for bit, sets identical."""
+	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
+	assert Xp.shape[1] == 512
+	pq, pr = ops.fused_plan(Q, I, 512, k), ops.fused_plan(Q, I, 512, k, mfma32=True)
+	assert pq["lg"] == 1 and all(b == 3 for b in pq["stage_pred"]) and pr["lg"] == 2 and all(b in (0, 1) for b in pr["stage_pred"])
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	(vr, ir), nfbr = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma32=True)
+	torch.cuda.synchronize()
+	assert nfb.item() == 0 and nfbr.item() == 0
+	assert torch.equal(v, vr)
+	assert (torch.sort(i, 1).values == torch.sort(ir, 1).values).float().mean() > 0.9995
+
+
+def test_fused_kp512_dense_block_drains_inside_the_tile_function(ops):
+	# a contiguous block of items far above the rest: nearly every compare of those tiles passes, the wave queues (448 entries) drain
+	# inside the tile function; segments may overflow -> exact repair through the chunk-owner map
+	Q, I, K, k = 300, 60000, 512, 100
+	g = _g(512512)
+	X = torch.randn(Q, K, generator=g).abs().bfloat16()
+	E = (0.01 * torch.randn(K, I, generator=g))
+	E[:, 20000:24000] += 1.0
+	E = E.bfloat16()
+	Xp = ops.pack_bf16(X.cuda(), 512); Etp = ops.pack_bf16(E.t().contiguous().cuda(), 512, row_multiple=32)
+	assert ops.fused_plan(Q, I, 512, k)["lg"] == 1
+	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	torch.cuda.synchronize()
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	torch.testing.assert_close(v.cpu().double(), rv, rtol=1e-4, atol=1e-4)
+	torch.testing.assert_close(torch.gather(S, 1, i.cpu().long()), v.cpu().double(), rtol=1e-4, atol=1e-4)
+	assert all(len(set(r.tolist())) == k for r in i.cpu())
+
+
 def test_fused_mfma16_dense_block_and_segment_overflow_stay_exact(ops):
 	# a contiguous block of items far above the rest: the wave queues drain inside the tile function, segments may overflow -> exact repair
 	Q, I, K, k = 300, 80000, 128, 100

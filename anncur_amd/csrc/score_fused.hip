@@ -97,6 +97,7 @@ struct FusedParams {
 	const float *tau; int tau_stride; // threshold per query: tau[q * tau_stride]
 	uint2 *cand; uint32_t *seg_cnt; int capg;
 	int nseg;                         // candidate segments per query (2 S: 32x32x16 body, lane halves; S: 16x16x32 body)
+	int rb_major;                     // work id -> (row block, split): 1 = row-block-major (dynamic tile schedule), 0 = split-major
 	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	int debug_stamp;                  // timing experiments only: this launch writes the in-kernel clock stamps
@@ -523,8 +524,10 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 #endif
 	const int wid = xcd_remap(blockIdx.x, p.n_wg);
 	const int nsplit = (MODE == 0) ? p.S0 : p.S;  // MODE 2 = MODE 1 without the filter (debug timing)
-	const int split = wid / (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ) ;
-	const int rb = wid - split * (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ);
+	const int n_rb_ = (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ);
+	const bool rbm = MODE == 1 && p.rb_major;   // (uniform) tickets: row-block-major work ids, see score16.hpp
+	const int split = rbm ? wid % p.S : wid / n_rb_;
+	const int rb = rbm ? wid / p.S : wid - split * n_rb_;
 	(void)nsplit;
 
 	// ---- this wave's queries: B operand fragments, resident for the whole kernel
@@ -1809,6 +1812,12 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
 		p.tile_step = tile_step;
 		if (chunk > 0) {
+			// (row-block-major work ids -- the workgroups of a row block on ONE XCD -- were measured for the ticket schedule, round 3, one box:
+			//  cfg4 shape sweep 5.13 -> 6.28 ms and L2-miss traffic 9.0 -> 13.0 GB per launch, cfg2 0.451 -> 0.480 ms: split-major stays)
+			p.rb_major = 0;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+			if (const char *dbg = getenv("ANNCUR_DEBUG_RB_MAJOR")) p.rb_major = atoi(dbg);
+#endif
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
 			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb;
 			p.chunk_owner = (uint8_t *)(ws + P.off_owner) + (size_t)stg * owner_stride;

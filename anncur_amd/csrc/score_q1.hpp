@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void scoreq1_kernel(const FusedParams p) {
 	const int r = lane & 31, h = lane >> 5;
 	const int wid = xcd_remap(blockIdx.x, p.n_wg);
 	const int n_rb = (int)((p.Q + C::BQ - 1) / C::BQ);
-	const int split = wid / n_rb, rb = wid - split * n_rb;
+	// work id -> (row block, split): split-major (p.rb_major = 1, row-block-major, is an experiments knob: measured worse, see launch_fused)
+	const int split = p.rb_major ? wid % p.S : wid / n_rb, rb = p.rb_major ? wid / p.S : wid - split * n_rb;
 
 	// ---- this lane's query: B operand fragments, resident for the whole kernel (as score_kernel, QT = 1)
 	bf16x8 xb[KSTEPS];

@@ -13,9 +13,9 @@ SHAPES = {"cfg2": dict(Q=10000, I=100000, Kp=256, k=100), "cfg4_per_gpu": dict(Q
 shape = SHAPES[cfg]
 kp = shape["Kp"]
 qt = 2 if kp <= 256 else 1
-# the sweep runs as up to three bodies (32x32x16 with the ballot / exec-mask filter, 16x16x32 -- chosen per stage by the plan): all of them
+# the sweep runs as one of four bodies (32x32x16 with the ballot / exec-mask filter, 16x16x32, Kp = 512 with the wave queue -- chosen by the plan): all of them
 # are "the sweep kernel" of the roofline, whose per-launch figures average over the launches of a step
-sweep_variants = [f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 1, 16, true, false, {qt}>", f"score16_kernel<{kp}>"]
+sweep_variants = [f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 1, 16, true, false, {qt}>", f"score16_kernel<{kp}>", f"scoreq1_kernel<{kp}>"]
 sweep, prepass = f"score_kernel<{kp}, sweep>", f"score_kernel<{kp}, 0, 16, false, false, {qt}>"
 names = sweep_variants + [prepass, f"score_kernel<{kp}, 1, 16, false, false, 1>", "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false", "select_wave_kernel<true", "select_stream_kernel<false",
 		 "select_stream_kernel<true", "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel", "gemm_f64_kernel"]

@@ -964,6 +964,150 @@ template <> struct ExactQuad<float> {
 	__device__ __forceinline__ float get(int c) const { return w[c]; }
 };
 
+// The tile's MFMA chains with the A fragments through the counted-wait register ring of the sweep (three k-steps ahead, inline-asm
+// ds_read_b128, s_waitcnt lgkmcnt(n)): round 2's loop read two k-steps, waited lgkmcnt(0), issued four MFMAs -- eight exposed LDS
+// round trips per tile (0.24 of peak).  Both sub-tiles share the fragment.
+template <int KP, int CUR>
+__device__ __forceinline__ void error_mfma_tile(const uint32_t (&aoff)[FusedCfg<KP>::NAOFF], const bf16x8 (&xb)[FusedCfg<KP>::QT][FusedCfg<KP>::KSTEPS],
+												 f32x16 (&acc)[FusedCfg<KP>::QT]) {
+	using Cfg = FusedCfg<KP>;
+	constexpr int K = Cfg::KSTEPS, NA = Cfg::NAOFF, QT = Cfg::QT, AR = 5, DIST = 3, OFF = CUR * Cfg::TILE_BYTES;
+	static_assert(K > DIST, "at least four k-steps");
+	u32x4 ring[AR];
+#define ER_READ(slot, s) lds_read_frag_at(ring[slot], aoff[(s) % NA], OFF + ((s) / NA) * 256)
+	ER_READ(0, 0); ER_READ(1, 1); ER_READ(2, 2);
+#pragma unroll
+	for (int t = 0; t < QT; ++t)
+#pragma unroll
+		for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+	for (int g = 0; g < K; ++g) {
+		const int nxt = g + DIST;
+		if (nxt < K) ER_READ(nxt % AR, nxt);
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (g >= 1) asm volatile("" ::"v"(ring[(g - 1) % AR]));
+#endif
+		const int after = K - 1 - g;
+		lds_wait_frag(ring[g % AR], after < DIST ? after : DIST);
+		const bf16x8 a = __builtin_bit_cast(bf16x8, ring[g % AR]);
+#pragma unroll
+		for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[t][g], acc[t], 0, 0, 0);
+	}
+#undef ER_READ
+#pragma unroll
+	for (int t = 0; t < QT; ++t) mfma_chain_done(acc[t]);
+}
+
+// a11 with the exact matrix staged through LDS (bf16 exact matrix, rows 16-byte aligned: lda % 8 == 0).  error_kernel reads the exact
+// values with the accumulator's orientation -- lane = query -- i.e. 8 bytes per lane from 32 different rows per load instruction:
+// 2.5 TB/s of exact matrix at cfg2 size whatever the MFMA loop does (round 3: the counted-wait fragment ring alone moved 0.84 -> 0.81 ms;
+// the time did not scale with Kp either: 0.60 ms at Kp = 128).  Here the workgroup's tile of the exact matrix -- BQ rows x 64 bytes --
+// comes in by the same direct-to-LDS loads as the item tile (16 bytes per lane, four lanes per row, 16 rows per instruction), double
+// buffered, one tile ahead; the lanes then read their four quads per sub-tile from LDS (ds_read_b64; the 16-byte chunk of a row is
+// XOR-swizzled with (row >> 2) & 3 on the DMA's source address: two-way bank conflicts instead of eight-way).
+template <int KP>
+__global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, const uint16_t *__restrict__ Aex, int64_t lda,
+															float *__restrict__ err_sq, float *__restrict__ norm_sq) {
+	using Cfg = FusedCfg<KP>;
+	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
+	constexpr int ATILE = Cfg::BQ * 64, PA = ATILE / 4096, AOFF = 2 * Cfg::TILE_BYTES;   // exact tile bytes, DMA pieces per wave, LDS offset
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int r = lane & 31, h = lane >> 5;
+	const int wid = xcd_remap(blockIdx.x, p.n_wg);
+	const int n_rb = (int)((p.Q + Cfg::BQ - 1) / Cfg::BQ);
+	const int split = wid / n_rb, rb = wid - split * n_rb;
+
+	bf16x8 xb[QT][KSTEPS];
+	int64_t qv[QT];
+	uint32_t aread[QT], asw[QT];  // LDS byte address of this lane's row of the exact tile (+ 8 h) in buffer 0; the row's chunk swizzle
+#pragma unroll
+	for (int t = 0; t < QT; ++t) {
+		const int row = wave * 32 * QT + 32 * t + r;
+		qv[t] = (int64_t)rb * Cfg::BQ + row;
+		const bool ok = qv[t] < p.Q;
+		aread[t] = lds_addr(smem) + (uint32_t)(AOFF + row * 64 + 8 * h);
+		asw[t] = (uint32_t)((row >> 2) & 3) << 4;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(p.X + (ok ? qv[t] : 0) * p.ldx) + h;
+#pragma unroll
+		for (int s = 0; s < KSTEPS; ++s) {
+			const u32x4 zero = {0u, 0u, 0u, 0u};
+			const u32x4 w = ok ? src[2 * s] : zero;
+			xb[t][s] = __builtin_bit_cast(bf16x8, w);
+		}
+	}
+	// exact-tile DMA: piece i of this wave fills LDS chunks (wave * PA + i) * 64 + lane: row = chunk >> 2, position = chunk & 3
+	const uint16_t *asrc[PA];
+#pragma unroll
+	for (int i = 0; i < PA; ++i) {
+		const int ch = (wave * PA + i) * 64 + lane, row = ch >> 2, pos = ch & 3;
+		int64_t q = (int64_t)rb * Cfg::BQ + row;
+		if (q >= p.Q) q = p.Q - 1;  // rows past Q re-read the last row (their sums are dropped)
+		asrc[i] = Aex + q * lda + 8 * (pos ^ ((row >> 2) & 3));
+	}
+	auto adma = [&](int j, int buf) {
+#pragma unroll
+		for (int i = 0; i < PA; ++i)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc[i] + (int64_t)j * TILE_I),
+											 (__attribute__((address_space(3))) void *)(smem + AOFF + buf * ATILE + (wave * PA + i) * 1024), 16, 0, 0);
+	};
+	__builtin_amdgcn_s_waitcnt(0x0F70);  // see score_kernel: keeps vmcnt(0) out of the tile loop
+
+	const int j_begin = split * p.tiles_per_split, j_end = min(j_begin + p.tiles_per_split, p.n_tiles);
+	float se[QT], sn[QT];
+#pragma unroll
+	for (int t = 0; t < QT; ++t) { se[t] = 0.f; sn[t] = 0.f; }
+	if (j_begin < j_end) {
+		tile_dma<KP>(p.Et, j_begin, smem, wave, lane);
+		adma(j_begin, 0);
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);
+	__syncthreads();
+	uint32_t aoff[Cfg::NAOFF];
+#pragma unroll
+	for (int s = 0; s < Cfg::NAOFF; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
+	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): error_mfma_tile() counts LDS reads
+#define ERRL_STEP(CUR, J)                                                                                                       \
+	do {                                                                                                                        \
+		if ((J) + 1 < j_end) {                                                                                                  \
+			tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                                      \
+			adma((J) + 1, (CUR) ^ 1);                                                                                           \
+		}                                                                                                                       \
+		f32x16 acc[QT];                                                                                                         \
+		error_mfma_tile<KP, CUR>(aoff, xb, acc);                                                                                \
+		ExactQuad<uint16_t> ex[QT][4];  /* items 32 j + 8 g + 4 h + {0..3}, g = 0..3, of the lane's query */                   \
+		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
+			_Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                       \
+				asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ex[t][g].w) : "v"(aread[t] + (((uint32_t)g << 4) ^ asw[t])), "n"((CUR) * ATILE)); \
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                      \
+		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
+			_Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));                                  \
+		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
+			_Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                    \
+				const float x = ex[t][e >> 2].get(e & 3);                                                                       \
+				const float d = acc[t][e] - x;                                                                                  \
+				se[t] = fmaf(d, d, se[t]);                                                                                      \
+				sn[t] = fmaf(x, x, sn[t]);                                                                                      \
+			}                                                                                                                   \
+		/* this wave's parts of the next item tile and exact tile have landed; the barrier orders LDS only */                   \
+		__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                     \
+		asm volatile("" ::: "memory");                                                                                          \
+		__builtin_amdgcn_s_barrier();                                                                                           \
+		asm volatile("" ::: "memory");                                                                                          \
+	} while (0)
+	for (int j = j_begin; j < j_end; j += 2) {
+		ERRL_STEP(0, j);
+		if (j + 1 < j_end) ERRL_STEP(1, j + 1);
+	}
+#undef ERRL_STEP
+#pragma unroll
+	for (int t = 0; t < QT; ++t)
+		if (qv[t] < p.Q) {
+			atomicAdd(&err_sq[qv[t]], se[t]);
+			atomicAdd(&norm_sq[qv[t]], sn[t]);
+		}
+}
+
 // Full 32-item tiles only (p.n_tiles = I / 32): the host adds the last I % 32 columns with the strided kernel of gemm.hip.
 template <int KP, typename TA>
 __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, const TA *__restrict__ Aex, int64_t lda,
@@ -1009,69 +1153,49 @@ __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, cons
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
-	for (int j = j_begin; j < j_end; ++j) {
-		const int cur = (j - j_begin) & 1;
-		const bool more = j + 1 < j_end;
-		if (more) tile_dma<KP>(p.Et, j + 1, smem + (cur ^ 1) * Cfg::TILE_BYTES, wave, lane);
-		f32x16 acc[QT];
+	uint32_t aoff[Cfg::NAOFF];   // LDS byte address of this lane's A fragment of k-step s (< NAOFF) in tile buffer 0 (see stagger_tile)
 #pragma unroll
-		for (int t = 0; t < QT; ++t)
-#pragma unroll
-			for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-		const u32x4 *tb = reinterpret_cast<const u32x4 *>(smem + cur * Cfg::TILE_BYTES);
-#pragma unroll
-		for (int s = 0; s < KSTEPS; ++s) {
-			// (Kp = 512: a scheduling fence every 8 k-steps -- left alone hipcc hoisted so many fragment reads that error_kernel<512, float>
-			//  spilled ten registers)
-			if (KSTEPS > 16 && s > 0 && (s & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-			const u32x4 w = tb[r * CPR + swz<CPR>(r, 2 * s + h)];
-			const bf16x8 a = __builtin_bit_cast(bf16x8, w);
-#pragma unroll
-			for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[t][s], acc[t], 0, 0, 0);
-		}
-#if defined(__HIP_DEVICE_COMPILE__)
-		// the exact values are consumed HERE, behind the MFMA chain: hipcc otherwise hoists their unpacking to the top of the
-		// iteration and waits vmcnt(0) there -- for them and for the tile DMA it has just issued.  (It still waits vmcnt(0)
-		// here, DMA included, because the loads sit behind `if (more)`; counted waits would need asm loads: not done.)
-#pragma unroll
-		for (int t = 0; t < QT; ++t)
-#pragma unroll
-			for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));
-#endif
-#pragma unroll
-		for (int t = 0; t < QT; ++t)
-#pragma unroll
-			for (int e = 0; e < 16; ++e) {
-				const float x = ex[t][e >> 2].get(e & 3);
-				const float d = acc[t][e] - x;
-				se[t] = fmaf(d, d, se[t]);
-				sn[t] = fmaf(x, x, sn[t]);
-			}
-		// the next tile's exact values are requested now and consumed after the next MFMA chain; the wait below covers the
-		// tile DMA only (loads return in order: the QT*4 quads issued after it may still be in flight)
-		if (more) {
-#if defined(__HIP_DEVICE_COMPILE__)
-			// the quads must be issued AFTER the tile DMA (the counted wait below relies on it) and after the sums above have
-			// consumed the previous ones: otherwise hipcc sinks the sums below the loads, renames the loads' destinations and
-			// waits for them at the end of the iteration to copy them back
-			if (QT == 2) asm volatile("" : "+v"(se[0]), "+v"(sn[0]), "+v"(se[QT - 1]), "+v"(sn[QT - 1])::"memory");
-			else asm volatile("" : "+v"(se[0]), "+v"(sn[0])::"memory");
-#endif
-#pragma unroll
-			for (int t = 0; t < QT; ++t)
-#pragma unroll
-				for (int g = 0; g < 4; ++g) ex[t][g].load(rowp[t] + (int64_t)(j + 1) * TILE_I + 8 * g);
-			__builtin_amdgcn_s_waitcnt(QT == 2 ? 0x0F78 : 0x0F74);  // vmcnt(8) / vmcnt(4)
-		}
-		// raw barrier: __syncthreads() carries a release fence for which hipcc waits vmcnt(0), i.e. for the quads just issued.
-		// What the barrier orders here is LDS only: this wave's fragment reads are complete (their MFMAs have issued), its part
-		// of the DMA has landed (counted wait above).
-#if defined(__HIP_DEVICE_COMPILE__)
-		asm volatile("" ::: "memory");
-		__builtin_amdgcn_s_barrier();
-		asm volatile("" ::: "memory");
-#endif
+	for (int s = 0; s < Cfg::NAOFF; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
+	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): error_mfma_tile() counts LDS reads
+#define ERR_STEP(CUR, J)                                                                                                        \
+	do {                                                                                                                        \
+		const bool more = (J) + 1 < j_end;                                                                                      \
+		if (more) tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                                \
+		f32x16 acc[QT];                                                                                                         \
+		error_mfma_tile<KP, CUR>(aoff, xb, acc);                                                                                \
+		/* the exact values are consumed HERE, behind the MFMA chain: hipcc otherwise hoists their unpacking to the top of the */ \
+		/* iteration and waits vmcnt(0) there -- for them and for the tile DMA it has just issued */                            \
+		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
+			_Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));                                  \
+		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
+			_Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                    \
+				const float x = ex[t][e >> 2].get(e & 3);                                                                       \
+				const float d = acc[t][e] - x;                                                                                  \
+				se[t] = fmaf(d, d, se[t]);                                                                                      \
+				sn[t] = fmaf(x, x, sn[t]);                                                                                      \
+			}                                                                                                                   \
+		/* the next tile's exact values are requested now and consumed after the next MFMA chain; the wait below covers the */  \
+		/* tile DMA only (loads return in order: the QT*4 quads issued after it may still be in flight) */                      \
+		if (more) {                                                                                                             \
+			/* the quads must be issued AFTER the tile DMA (the counted wait relies on it) and after the sums above have */      \
+			/* consumed the previous ones: otherwise hipcc sinks the sums below the loads and renames the destinations */       \
+			if (QT == 2) asm volatile("" : "+v"(se[0]), "+v"(sn[0]), "+v"(se[QT - 1]), "+v"(sn[QT - 1])::"memory");             \
+			else asm volatile("" : "+v"(se[0]), "+v"(sn[0])::"memory");                                                         \
+			_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                      \
+				_Pragma("unroll") for (int g = 0; g < 4; ++g) ex[t][g].load(rowp[t] + (int64_t)((J) + 1) * TILE_I + 8 * g);     \
+			__builtin_amdgcn_s_waitcnt(QT == 2 ? 0x0F78 : 0x0F74);  /* vmcnt(8) / vmcnt(4) */                                   \
+		}                                                                                                                       \
+		/* raw barrier: __syncthreads() carries a release fence for which hipcc waits vmcnt(0), i.e. for the quads just issued. */ \
+		/* What the barrier orders here is LDS only: this wave's fragment reads are complete, its part of the DMA has landed. */ \
+		asm volatile("" ::: "memory");                                                                                          \
+		__builtin_amdgcn_s_barrier();                                                                                           \
+		asm volatile("" ::: "memory");                                                                                          \
+	} while (0)
+	for (int j = j_begin; j < j_end; j += 2) {
+		ERR_STEP(0, j);
+		if (j + 1 < j_end) ERR_STEP(1, j + 1);
 	}
+#undef ERR_STEP
 #pragma unroll
 	for (int t = 0; t < QT; ++t)
 		if (qv[t] < p.Q) {
@@ -2239,7 +2363,23 @@ extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void
 			default: LAUNCH_ERR(512, TA); break;                                                                              \
 		}                                                                                                                     \
 	} while (0)
-	if (a_dtype == ANNCUR_F32) LAUNCH_ERR_K(float); else LAUNCH_ERR_K(uint16_t);
+	// bf16 exact matrix with 16-byte aligned rows: the kernel that stages the exact tile through LDS
+	const bool lds_exact = a_dtype == ANNCUR_BF16 && (lda % 8) == 0 && ((uintptr_t)A % 16) == 0;
+	if (lds_exact) {
+#define LAUNCH_ERRL(KPV)                                                                                                      \
+		do {                                                                                                                  \
+			const int lds_ = 2 * FusedCfg<KPV>::TILE_BYTES + 2 * FusedCfg<KPV>::BQ * 64;                                      \
+			{ const int rc_ = anncur_ensure_dyn_lds((const void *)error_lds_kernel<KPV>, lds_); if (rc_ != ANNCUR_OK) return rc_; } \
+			hipLaunchKernelGGL((error_lds_kernel<KPV>), dim3(p.n_wg), dim3(256), lds_, st, p, (const uint16_t *)A, lda, err_sq, norm_sq); \
+		} while (0)
+		switch (Kp) {
+			case 64: LAUNCH_ERRL(64); break;
+			case 128: LAUNCH_ERRL(128); break;
+			case 256: LAUNCH_ERRL(256); break;
+			default: LAUNCH_ERRL(512); break;
+		}
+#undef LAUNCH_ERRL
+	} else if (a_dtype == ANNCUR_F32) LAUNCH_ERR_K(float); else LAUNCH_ERR_K(uint16_t);
 #undef LAUNCH_ERR_K
 #undef LAUNCH_ERR
 	ANNCUR_LAUNCH_OK();

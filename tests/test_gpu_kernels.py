@@ -499,15 +499,18 @@ def test_rowwise_topk_threshold_crossing_zero_nan_and_sorted_rows(ops, dtype):
 		assert torch.equal(i.cpu().long(), order)
 
 
-@pytest.mark.parametrize("Q,I,K,adt", [(300, 4096, 64, torch.bfloat16), (257, 10031, 128, torch.bfloat16), (130, 7000, 256, torch.bfloat16),
-									   (70, 5023, 500, torch.bfloat16), (129, 6400, 256, torch.float32), (40, 40, 64, torch.bfloat16), (33, 20, 128, torch.float32)])
-def test_approx_error_packed_matches_strided_and_fp64(ops, Q, I, K, adt):
+@pytest.mark.parametrize("Q,I,K,adt,pad", [(300, 4096, 64, torch.bfloat16, 8), (257, 10031, 128, torch.bfloat16, 8), (130, 7000, 256, torch.bfloat16, 8),
+										   (70, 5023, 500, torch.bfloat16, 8), (129, 6400, 256, torch.float32, 8), (40, 40, 64, torch.bfloat16, 8),
+										   (33, 20, 128, torch.float32, 8), (257, 10031, 128, torch.bfloat16, 4), (600, 9000, 256, torch.bfloat16, 4),
+										   (1000, 33000, 256, torch.bfloat16, 8), (300, 20000, 512, torch.bfloat16, 8)])
+def test_approx_error_packed_matches_strided_and_fp64(ops, Q, I, K, adt, pad):
 	"""a11 on the sweep's MFMA loop (full 32-item tiles + the strided kernel for the last I % 32 columns) against the strided fp32
-	GEMM reduction on the same bf16 operands and against fp64 on the CPU."""
+	GEMM reduction on the same bf16 operands and against fp64 on the CPU.  bf16 exact matrix with a row pitch that is a multiple of 8
+	(pad = 8): the exact tile goes through LDS (error_lds_kernel); pitch = 4 mod 8 (pad = 4) and fp32: per-lane loads (error_kernel)."""
 	g = _g(Q + I + K)
 	X = torch.randn(Q, K, generator=g).bfloat16()
 	E = (torch.randn(K, I, generator=g) / K ** 0.5).bfloat16()
-	ld = (I + 3) // 4 * 4 + 8                                      # padded rows (row pitch a multiple of 4)
+	ld = (I + 7) // 8 * 8 + pad                                    # padded rows (row pitch a multiple of 4; of 8 iff pad = 8)
 	Abuf = torch.zeros(Q, ld, dtype=adt)
 	Abuf[:, :I] = (X.float() @ E.float() + 0.3 * torch.randn(Q, I, generator=g)).to(adt)
 	A = Abuf.cuda()[:, :I]

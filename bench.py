@@ -354,7 +354,15 @@ def main():
 			return slot
 		return launch_one, graphs is not None
 
-	launchers = {args.scan_mode: make_launcher(args.scan_mode)}
+	try:
+		launchers = {args.scan_mode: make_launcher(args.scan_mode)}
+	except Exception as exc:   # measurement plumbing only: a runtime without CU-masked streams falls back to the second-stream placement
+		if args.scan_mode != "partition":
+			raise
+		print(f"[bench] --scan-mode partition unavailable ({type(exc).__name__}: {exc}); using --scan-mode side", file=sys.stderr)
+		torch.cuda.synchronize()
+		args.scan_mode = "side"
+		launchers = {"side": make_launcher("side")}
 	launch, graphed = None, False
 
 	def finish(slot):

@@ -941,6 +941,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 
 #include "score16.hpp"
 #include "score_q1.hpp"
+#include "score_q16.hpp"
 
 // ------------------------------------------------------------------ a11: approximation error on the same MFMA loop
 // err_sq[q] += sum_i (S_hat[q,i] - A[q,i])^2, norm_sq[q] += sum_i A[q,i]^2 over this workgroup's item tiles; S_hat is never
@@ -1507,6 +1508,7 @@ struct FusedPlan {
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
 	bool body16;  // the sweep stages run score16_kernel
 	bool bodyq1;  // the sweep stages run scoreq1_kernel (Kp = 512)
+	bool bodyq16; // ... scoreq16_kernel: the same body on 16x16x32 MFMAs
 	int chunk;  // dynamic tile schedule of the sweep stages: tiles per ticket (0: static shares)
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, off_ctr, off_owner, total;
 };
@@ -1629,6 +1631,10 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.bodyq1 = KP == 512 && !mfma32 && I < (int64_t)(1 << 26);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_NO_Q1")) P.bodyq1 = false;
+#endif
+	P.bodyq16 = P.bodyq1;   // (16x16x32 MFMAs: cfg4 per-GPU shape, one box, alternating: sweep launches 5.21 -> 5.02 ms, step 7.19 -> 7.00; scoreq1_kernel stays for A/B)
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_Q16")) P.bodyq16 = P.bodyq1 && atoi(dbg) != 0;
 #endif
 	const bool ticketed = P.QT == 2 || P.bodyq1;   // the bodies with the ticket schedule
 	P.chunk = ticketed ? CHUNK_TILES : 0;
@@ -1961,6 +1967,11 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		}
 #endif
 		if constexpr (KP == 512) {  // Kp = 512 with the wave-level queue and tickets (score_q1.hpp)
+			if (!launched && P.bodyq16) {
+				if ((rc = anncur_ensure_dyn_lds((const void *)scoreq16_kernel<KP>, FusedQ1Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((scoreq16_kernel<KP>), dim3(p.n_wg), dim3(256), FusedQ1Cfg<KP>::LDS_BYTES, st, p);
+				launched = true;
+			}
 			if (!launched && P.bodyq1) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)scoreq1_kernel<KP>, FusedQ1Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((scoreq1_kernel<KP>), dim3(p.n_wg), dim3(256), FusedQ1Cfg<KP>::LDS_BYTES, st, p);
@@ -2301,8 +2312,8 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 
 /* the same for the flags of anncur_score_topk_ex: out[0 .. n_out) = {sample tiles, item tiles, S, segment capacity, group, segments per
  * query and item split (2: 32x32x16 sweep, 1: 16x16x32 sweep, 4: wide kernel), 32-query sub-tiles per wave, sweep stages,
- * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32, 3: Kp = 512 with the
- * wave-level queue), ring drain period[3]} --
+ * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32, 3 / 4: Kp = 512 with the
+ * wave-level queue on 32x32x16 / 16x16x32 MFMAs), ring drain period[3]} --
  * what a test needs to see that a variant flag was honoured */
 extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
 	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
@@ -2312,7 +2323,7 @@ extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32
 	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
 	for (int g = 0; g < 3; ++g) {
 		const bool on = g < P.n_stages;
-		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.body16 ? 2 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g])) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
+		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.body16 ? 2 : (!wide && P.bodyq16 ? 4 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g]))) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
 	}
 	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
 	return ANNCUR_OK;

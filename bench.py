@@ -523,7 +523,7 @@ def main():
 					   "parallelism": f"row-sharded x{world}, index replicated (one RCCL all-gather of anchor rows at build time)"},
 			"recall": recall,
 			"roofline": {"bound": "mfma", "kernel": "sweep stages (fused S_hat GEMM + threshold filter): " + " + ".join(
-							 ({2: f"score16_kernel<{Kp}>", 3: f"scoreq1_kernel<{Kp}>"}.get(b, f"score_kernel<{Kp},sweep>")) for b in plan_now["stage_pred"]),
+							 ({2: f"score16_kernel<{Kp}>", 3: f"scoreq1_kernel<{Kp}>", 4: f"scoreq16_kernel<{Kp}>"}.get(b, f"score_kernel<{Kp},sweep>")) for b in plan_now["stage_pred"]),
 						 "achieved": sweep_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": sweep_tflops / PEAK_BF16_TFLOPS,
 						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(sweep_ms), "launches_per_step": n_sweep},
 			"roofline_scan": {"bound": "hbm", "kernel": "rowwise_topk_wave_kernel<bf16> (exact top-k scan, one wave per row)",

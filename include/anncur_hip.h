@@ -163,7 +163,8 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
  *    candidate queue per wave (I < 2^26; the chip holds a higher clock on that shape).  Same products and fp32 sums: the result is the
  *    same bit for bit up to the order of exact score ties.  Default: the 16x16x32 body for k <= 128, the 32x32x16 body above.
  *  ANNCUR_TOPK_MFMA16 / ANNCUR_TOPK_MFMA32: force the 16x16x32 / the 32x32x16 body (A/B variants).  Kp = 512 has one MFMA shape and two
- *    candidate paths: one queue per wave with the dynamic tile schedule (default, I < 2^26), per-lane rings (ANNCUR_TOPK_MFMA32). */
+ *    candidate paths: one queue per wave with the dynamic tile schedule on 16x16x32 MFMAs (default, I < 2^26), per-lane rings with
+ *    static shares on 32x32x16 MFMAs (ANNCUR_TOPK_MFMA32). */
 #define ANNCUR_TOPK_MFMA16 2
 /*  ANNCUR_TOPK_QT1 (Kp = 128 / 256): one 32-query sub-tile per wave and three workgroups per CU, with the cross-tile software
  *    pipeline of the Kp = 512 sweep, instead of two sub-tiles staggered inside a wave at two workgroups per CU (A/B variant). */
@@ -203,8 +204,8 @@ int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t 
 /* The plan a call with `flags` (ANNCUR_TOPK_*) would run: out[0 .. n_out), n_out <= 17 = {sample tiles, item tiles, item splits S,
  * segment capacity, group size, candidate segments per (query, item split) -- 2: 32x32x16 sweep, 1: 16x16x32 sweep, 4: wide
  * kernel --, 32-query sub-tiles per wave, number of sweep stages, stage_end[3] (tiles), body per stage[3] (0: 32x32x16 with the ballot
- * filter, 1: 32x32x16 with the exec-mask filter, 2: 16x16x32, 3: the Kp = 512 body with the wave-level queue), ring drain period per
- * stage[3]}.  Lets a caller (and the parity tests) see that a variant flag was honoured for the shape. */
+ * filter, 1: 32x32x16 with the exec-mask filter, 2: 16x16x32, 3 / 4: the Kp = 512 body with the wave-level queue on 32x32x16 / 16x16x32 MFMAs), ring
+ * drain period per stage[3]}.  Lets a caller (and the parity tests) see that a variant flag was honoured for the shape. */
 int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out);
 
 /* a8: exact re-rank of the approximately retrieved items + a10 overlap counts --------

@@ -65,8 +65,8 @@ def test_sweep_variant_flags_reach_the_plan():
 	assert ops.fused_plan(300, 40000, 64, 10, mfma16=True)["lg"] == 1
 	assert ops.fused_plan(10000, 100000, 256, 100, qt1=True)["QT"] == 1 and ops.fused_plan(10000, 100000, 128, 100, qt1=True)["QT"] == 1
 	assert ops.fused_plan(10000, 100000, 64, 100, qt1=True)["QT"] == 2       # Kp = 64 has no QT = 1 body
-	p512 = ops.fused_plan(6250, 1000000, 512, 100, mfma16=True, qt1=True)            # Kp = 512: one MFMA shape whatever those flags;
-	assert p512["lg"] == 1 and p512["QT"] == 1 and all(b == 3 for b in p512["stage_pred"])   # default = the wave-level queue + tickets
+	p512 = ops.fused_plan(6250, 1000000, 512, 100)                                    # Kp = 512: default = the wave-level queue + tickets
+	assert p512["lg"] == 1 and p512["QT"] == 1 and all(b == 4 for b in p512["stage_pred"])            # ... on 16x16x32 MFMAs
 	assert ops.fused_plan(6250, 1000000, 512, 100, mfma32=True)["lg"] == 2           # the per-lane-ring body on request
 	assert ops.fused_plan(64, (1 << 26) + 64, 64, 10)["lg"] == 2                      # queue entries carry the query beside the item: I < 2^26
 	import inspect

@@ -206,17 +206,18 @@ def test_fused_mfma16_sweep_gives_the_same_topk(ops, Q, I, K, k):
 
 @pytest.mark.parametrize("Q,I,K,k", [(257, 70000, 512, 100), (1000, 60007, 400, 10), (130, 131072, 512, 500)])
 def test_fused_kp512_queue_body_equals_the_ring_body(ops, Q, I, K, k):
-	"""Kp = 512 has one MFMA shape and two candidate paths: one queue per wave with the dynamic tile schedule (score_q1.hpp, the default)
-	and per-lane rings with static shares (ANNCUR_TOPK_MFMA32).  Same MFMAs in the same order: values bit for bit, sets identical."""
+	"""Kp = 512 has two candidate paths: one queue per wave with the dynamic tile schedule (score_q16.hpp: 16x16x32 MFMAs, the default;
+	score_q1.hpp: the same on 32x32x16 MFMAs, experiments build) and per-lane rings with static shares on 32x32x16 MFMAs
+	(ANNCUR_TOPK_MFMA32).  Same products, fp32 sums that may associate differently between the MFMA shapes: values to 1e-6, sets identical."""
 	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
 	assert Xp.shape[1] == 512
 	pq, pr = ops.fused_plan(Q, I, 512, k), ops.fused_plan(Q, I, 512, k, mfma32=True)
-	assert pq["lg"] == 1 and all(b == 3 for b in pq["stage_pred"]) and pr["lg"] == 2 and all(b in (0, 1) for b in pr["stage_pred"])
+	assert pq["lg"] == 1 and all(b == 4 for b in pq["stage_pred"]) and pr["lg"] == 2 and all(b in (0, 1) for b in pr["stage_pred"])
 	(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
 	(vr, ir), nfbr = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma32=True)
 	torch.cuda.synchronize()
 	assert nfb.item() == 0 and nfbr.item() == 0
-	assert torch.equal(v, vr)
+	torch.testing.assert_close(v, vr, rtol=1e-6, atol=1e-6)
 	assert (torch.sort(i, 1).values == torch.sort(ir, 1).values).float().mean() > 0.9995
 
 

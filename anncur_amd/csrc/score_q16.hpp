@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256, 2) void scoreq16_kernel(const FusedParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int c16 = lane & 15, g4 = lane >> 4;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();   // (diagnostic build: scripts/inkernel_clock.py)
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_entry)::"memory");
+#endif
 	const int wid = xcd_remap(blockIdx.x, p.n_wg);
 	const int n_rb = (int)((p.Q + C::BQ - 1) / C::BQ);
 	const int split = p.rb_major ? wid % p.S : wid / n_rb, rb = p.rb_major ? wid / p.S : wid - split * n_rb;
@@ -167,6 +171,10 @@ __global__ __launch_bounds__(256, 2) void scoreq16_kernel(const FusedParams p) {
 		__syncthreads();                                                                                                        \
 		t_cur = nx;                                                                                                             \
 	} while (0)
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_c0), "+s"(st_r0)::"memory");
+#endif
 	ANNCUR_PAD_HERE();
 	bool last_in_a = false;  // (uniform) which accumulator set holds the last tile
 	while (t_cur >= 0) {
@@ -177,6 +185,15 @@ __global__ __launch_bounds__(256, 2) void scoreq16_kernel(const FusedParams p) {
 		last_in_a = false;
 	}
 #undef Q16_STEP
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (tid == 0 && d_sweep_stamps && p.debug_stamp && blockIdx.x < 8192) {
+		unsigned long long *stamps = d_sweep_stamps;
+		const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+		stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st_c0;
+		stamps[2 * blockIdx.x + 1] = r1 - st_r0;
+		stamps[2 * 8192 + 3 * blockIdx.x] = st_entry; stamps[2 * 8192 + 3 * blockIdx.x + 1] = st_r0; stamps[2 * 8192 + 3 * blockIdx.x + 2] = r1;
+	}
+#endif
 	// drain: the last tile's accumulators (16 pushes, the fill checked every CHECK_PUSHES)
 	wq_drain(w, fill);
 #define Q16_LAST(ACC)                                                                                                           \

@@ -52,3 +52,24 @@ def test_bench_rejects_a_world_size_mismatch_before_any_collective():
 	env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
 	p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
 	assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_bench_single_gpu_default_line_and_scan_placements():
+	"""The N = 1 line of the driver: default flags except a short run.  The exact scan's placement is the CU partition (masked stream +
+	three graphs per step) at cfg2's Kp = 256; the same steps with the second-stream placement must report the same recall."""
+	short = ["--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--cpu-sample-queries", "0", "--no-k500", "--no-ivf"]
+	outs = {}
+	for mode in (None, "side"):
+		p = _run(args=short + (["--scan-mode", mode] if mode else []))
+		assert p.returncode == 0, p.stderr[-3000:]
+		assert "Memory access fault" not in p.stderr
+		lines = [l for l in p.stdout.splitlines() if l.strip()]
+		assert len(lines) == 1, p.stdout[-2000:]
+		outs[mode] = json.loads(lines[0])
+	d = outs[None]
+	assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "queries/s" and d["vs_baseline"] is None and d["dtype"] == "bf16"
+	assert d["scan_mode"]["used"] == "partition" and d["scan_mode"]["scan_cus"] == 96 and outs["side"]["scan_mode"]["used"] == "side"
+	assert d["value"] == pytest.approx(10000 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
+	assert d["roofline"]["bound"] == "mfma" and 0.2 < d["roofline"]["frac"] < 1.0 and d["roofline_scan"]["bound"] == "hbm"
+	assert all(b == 2 for b in d["fused_plan"]["stage_pred"])          # the 16x16x32 body
+	assert d["recall"] == outs["side"]["recall"] and d["recall"]["recall@1"] == 1.0

@@ -507,10 +507,22 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const TS *__restrict__
 	const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= n_rows) return;
 	const TS *row = A + r * lda;
-	for (int j = threadIdx.x & 63; j < n_idx; j += 64) {
-		const int32_t c = col_idx[j];
-		const bool in = c >= 0 && (int64_t)c < n_cols;
-		out[r * ldo + j] = in ? cvt<TS, TD>(row[c]) : cvt<float, TD>(0.f);
+	// four elements per lane and pass, their loads issued back to back (round 3: one element per loop iteration, index load -> element
+	// load -> store in a dependent chain, left one or two loads in flight per lane: 0.069 ms for 10 000 x 256 elements)
+	constexpr int U = 4;
+	for (int j0 = threadIdx.x & 63; j0 < n_idx; j0 += 64 * U) {
+		int32_t c[U];
+		TS v[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) c[u] = (j0 + 64 * u < n_idx) ? col_idx[j0 + 64 * u] : -1;
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const bool in = c[u] >= 0 && (int64_t)c[u] < n_cols;
+			v[u] = in ? row[c[u]] : cvt<float, TS>(0.f);
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u)
+			if (j0 + 64 * u < n_idx) out[r * ldo + j0 + 64 * u] = cvt<TS, TD>(v[u]);
 	}
 }
 

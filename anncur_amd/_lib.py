@@ -42,6 +42,9 @@ SIGNATURES = {
 	"anncur_approx_error": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64,
 									c_int64, c_void_p, c_void_p, c_void_p]),
 	"anncur_rowwise_topk": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+	"anncur_gather_tables": (c_int, [c_void_p, c_int32, c_int64, c_int, c_void_p, c_void_p]),
+	"anncur_rowwise_topk_gather": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p,
+										   c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
 	"anncur_score_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
 	"anncur_score_topk_supported": (c_int, [c_int64, c_int64, c_int32, c_int32]),
 	"anncur_score_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,

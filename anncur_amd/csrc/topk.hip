@@ -221,9 +221,48 @@ template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer comp
 	}
 };
 
-template <typename T>
+// element e of a 16-byte vector, e not a compile-time constant (select chain: the vector stays in registers)
+template <typename T> __device__ __forceinline__ T dyn_elem(const u32x4 &v, int e);
+template <> __device__ __forceinline__ uint16_t dyn_elem<uint16_t>(const u32x4 &v, int e) {
+	const int wi = e >> 1;
+	const uint32_t x = wi == 0 ? v[0] : (wi == 1 ? v[1] : (wi == 2 ? v[2] : v[3]));
+	return (uint16_t)((e & 1) ? (x >> 16) : (x & 0xffffu));
+}
+template <> __device__ __forceinline__ float dyn_elem<float>(const u32x4 &v, int e) {
+	return __uint_as_float(e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3])));
+}
+
+// the two tables of ScanGather from the ascending anchor columns: one thread per vector
+__global__ __launch_bounds__(256) void gather_tables_kernel(const int32_t *__restrict__ col_idx, int n_idx, int64_t n_vec, int vec,
+															uint32_t *__restrict__ vtab) {
+	const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (v >= n_vec) return;
+	const int64_t c0 = v * vec;
+	int lo = 0, hi = n_idx;   // first anchor >= c0
+	while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)col_idx[mid] < c0) lo = mid + 1; else hi = mid; }
+	uint32_t m = 0u;
+	for (int j = lo; j < n_idx && (int64_t)col_idx[j] < c0 + vec; ++j) m |= 1u << (int)((int64_t)col_idx[j] - c0);
+	vtab[v] = ((uint32_t)lo << 8) | m;
+}
+
+// GATHER (round 3, a2 folded into the first pass over A -- SURVEY a2, reference ...splits.py:297,300): the wave also copies the row's
+// anchor columns to cq[q, 0..n_idx) as their vectors stream past, so C_q = A[:, anchors] costs no second read of the row's sectors (the
+// separate gather re-reads one 64-byte sector per anchor: 164 MB at cfg2).  The anchors arrive as a table over the row's 16-byte
+// vectors (anncur_gather_tables: which elements of vector v are anchors, and how many anchors lie before it); a vector's table word
+// is prefetched with the vector.  Rows must start 16-byte aligned (one vector grid for all rows).
+struct ScanGather {
+	const uint32_t *vtab;    // [ceil(I / VEC)]: bits 0..7: bit e = element e of the vector is an anchor column; bits 8..: anchors in the
+	                         // vectors before it.  ONE word, prefetched with the vector: a rank fetched where it is needed would be a
+	                         // dependent load whose wait also drains the eight prefetches in flight (loads return in order)
+	const int32_t *col_idx;  // the n_idx anchor columns, ascending (the row's tail elements are looked up here)
+	int32_t n_idx;
+	void *cq;                // [Q x ldo] of A's element type
+	int64_t ldo;
+};
+template <typename T, bool GATHER = false>
 __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
-																 uint32_t trig, float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+																 uint32_t trig, float *__restrict__ out_val, int32_t *__restrict__ out_idx,
+																 const ScanGather gt = ScanGather{}) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// (the wave index through readfirstlane: the compiler then knows the row pointer is wave-uniform and keeps the stream's base address
 	//  in scalar registers -- without it every load of the stream carried 64-bit per-lane address arithmetic)
@@ -245,9 +284,12 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 
 	// the first WS_PF vectors of every lane: they seed the threshold AND are the first prefetch set of the stream
 	u32x4 pf[WS_PF];
+	uint32_t pm[GATHER ? WS_PF : 1];   // (GATHER) anchor mask of the prefetched vector; 0 for the clamped duplicates past the row
+	T *cqrow = GATHER ? reinterpret_cast<T *>(gt.cq) + q * gt.ldo : nullptr;
 #pragma unroll
 	for (int d = 0; d < WS_PF; ++d) {
 		const int64_t iv = (int64_t)d * WAVE + lane;
+		if (GATHER) pm[d] = iv < nvec ? gt.vtab[iv] : 0u;
 		pf[d] = vp[iv < nvec ? iv : vlast];
 	}
 	if (nvec >= (int64_t)WS_PF * WAVE && k <= (uint32_t)(WS_PF * WAVE)) {
@@ -305,15 +347,26 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 #define SCAN_STEP(d, FULL)                                                                                                      \
 	{                                                                                                                           \
 		const u32x4 cur = pf[d];                                                                                                \
+		const uint32_t mcur = GATHER ? pm[GATHER ? (d) : 0] : 0u;                                                               \
 		const u32x4 y = sp.xform(cur);                                                                                          \
 		bool pass = sp.any(y);                                                                                                  \
 		if (FULL) {  /* the block and its prefetch lie inside the row: wave-uniform base + lane, nothing to clamp */            \
+			if (GATHER) pm[GATHER ? (d) : 0] = mblk[((d) + WS_PF) * WAVE + lane];                                     \
 			pf[d] = __builtin_nontemporal_load(blk + ((d) + WS_PF) * WAVE + lane);                                              \
 		} else {  /* the last blocks: prefetches clamped, steps past the row masked (never branched around) */                  \
 			const int64_t iv = (s0 + (d)) * WAVE + lane;                                                                        \
 			const int64_t ivn = iv + (int64_t)WS_PF * WAVE;                                                                     \
+			if (GATHER) pm[GATHER ? (d) : 0] = ivn < nvec ? gt.vtab[ivn] : 0u;                                       \
 			pf[d] = vp[ivn < nvec ? ivn : vlast];                                                                               \
 			pass = pass && iv < nvec;                                                                                           \
+		}                                                                                                                       \
+		if (GATHER) {  /* this vector's anchor elements -> cq[q, rank of the column], in column order */                        \
+			if (__ballot((mcur & 0xffu) != 0u) != 0ull) {                                                                       \
+				if ((mcur & 0xffu) != 0u) {                                                                                     \
+					uint32_t pos = mcur >> 8;                                                                                   \
+					for (uint32_t mm = mcur & 0xffu; mm != 0u; mm &= mm - 1u) cqrow[pos++] = dyn_elem<T>(cur, __builtin_ctz(mm)); \
+				}                                                                                                               \
+			}                                                                                                                   \
 		}                                                                                                                       \
 		const unsigned long long pm = __ballot(pass);                                                                           \
 		if (pm != 0ull) {                                                                                                       \
@@ -336,12 +389,15 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	for (; (s0 + 2 * WS_PF) * WAVE <= nvec; s0 += WS_PF) {
 		sp.set(w.tau);  // frozen for the block
 		const u32x4 *blk = vp + s0 * WAVE;  // (uniform)
+		const uint32_t *mblk = GATHER ? gt.vtab + s0 * WAVE : nullptr;
+		(void)mblk;
 		SCAN_STEP(0, true) SCAN_STEP(1, true) SCAN_STEP(2, true) SCAN_STEP(3, true) SCAN_STEP(4, true) SCAN_STEP(5, true) SCAN_STEP(6, true) SCAN_STEP(7, true)
 	}
 	for (; s0 < nsteps; s0 += WS_PF) {
 		sp.set(w.tau);
 		const u32x4 *blk = vp;  // (unused)
-		(void)blk;
+		const uint32_t *mblk = nullptr;
+		(void)blk; (void)mblk;
 		SCAN_STEP(0, false) SCAN_STEP(1, false) SCAN_STEP(2, false) SCAN_STEP(3, false) SCAN_STEP(4, false) SCAN_STEP(5, false) SCAN_STEP(6, false) SCAN_STEP(7, false)
 	}
 	if (scnt > 0u) SCAN_DRAIN()
@@ -350,6 +406,12 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	{  // the tail (fewer than VEC elements), still in index order
 		const bool in = lane < I - tail0;
 		wsel_offer_inorder(w, in, in ? load_as_f32<T>(row + tail0 + lane) : 0.f, (uint32_t)(tail0 + lane));
+	}
+	if (GATHER) {  // anchors among the tail elements (no vector covers them): looked up directly
+		for (int j = lane; j < gt.n_idx; j += WAVE) {
+			const int32_t c = gt.col_idx[j];
+			if ((int64_t)c >= tail0 && (int64_t)c < I) cqrow[j] = row[c];
+		}
 	}
 	wsel_finish<WS_CAP, HP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
@@ -645,6 +707,41 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 		if (kc == 128) LAUNCH_ROWTOPK(uint16_t, 128); else if (kc == 512) LAUNCH_ROWTOPK(uint16_t, 512); else LAUNCH_ROWTOPK(uint16_t, 2048);
 	}
 #undef LAUNCH_ROWTOPK
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+/* a2 folded into a8's scan: see ScanGather.  Tables for anncur_rowwise_topk_gather from the ascending, distinct anchor columns. */
+extern "C" int anncur_gather_tables(const int32_t *col_idx, int32_t n_idx, int64_t I, int dtype, uint32_t *vec_tab, void *stream) {
+	ANNCUR_REQUIRE(dtype_ok(dtype) && col_idx && vec_tab && n_idx >= 1 && n_idx <= 65535 && I >= 1, ANNCUR_E_INVALID, "gather_tables: bad arguments");
+	const int vec = dtype == ANNCUR_F32 ? 4 : 8;
+	const int64_t n_vec = ceil_div64(I, vec);
+	hipLaunchKernelGGL(gather_tables_kernel, dim3((unsigned)ceil_div64(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, col_idx, (int)n_idx, n_vec, vec, vec_tab);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+/* anncur_rowwise_topk (k <= 128) + cq[q, j] = A[q, col_idx[j]] in the same pass over A.  A 16-byte aligned with 16-byte aligned rows,
+ * col_idx ascending and distinct in [0, I), tables from anncur_gather_tables for the same (col_idx, I, dtype); cq has A's element type. */
+extern "C" int anncur_rowwise_topk_gather(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k, float *out_val, int32_t *out_idx,
+										  const int32_t *col_idx, int32_t n_idx, const uint32_t *vec_tab, void *cq, int64_t ldo, void *stream) {
+	ANNCUR_REQUIRE(dtype_ok(dtype), ANNCUR_E_INVALID, "rowwise_topk_gather: bad dtype %d", dtype);
+	ANNCUR_REQUIRE(Q >= 0 && I >= 1 && lda >= I && Q < (int64_t)0x7fffffff && I < (int64_t)0x7fffffff, ANNCUR_E_INVALID, "rowwise_topk_gather: bad shape");
+	ANNCUR_REQUIRE(k >= 1 && k <= WSEL_K && k <= I, ANNCUR_E_UNSUPPORTED, "rowwise_topk_gather: k=%d outside the wave-level scan (1..%d)", k, WSEL_K);
+	ANNCUR_REQUIRE(A && out_val && out_idx && col_idx && vec_tab && cq, ANNCUR_E_INVALID, "rowwise_topk_gather: null pointer");
+	ANNCUR_REQUIRE(n_idx >= 1 && n_idx <= 65535 && ldo >= n_idx, ANNCUR_E_INVALID, "rowwise_topk_gather: bad anchor count / output pitch");
+	ANNCUR_REQUIRE(((uintptr_t)A % 16) == 0 && ((size_t)lda * dtype_size(dtype)) % 16 == 0, ANNCUR_E_UNSUPPORTED,
+				   "rowwise_topk_gather: A and its rows must be 16-byte aligned (use anncur_gather_cols + anncur_rowwise_topk)");
+	if (Q == 0) return ANNCUR_OK;
+	hipStream_t st = (hipStream_t)stream;
+	const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
+	const unsigned grid = (unsigned)ceil_div64(Q, 4);
+	const uint32_t trig = ws_trigger((uint32_t)k);
+	ScanGather gt{vec_tab, col_idx, n_idx, cq, ldo};
+	if (dtype == ANNCUR_F32)
+		hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx, gt);
+	else
+		hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, true>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx, gt);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

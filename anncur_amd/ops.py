@@ -294,6 +294,54 @@ def rowwise_topk(A, k, out=None):
 	return TopK(val, idx)
 
 
+GatherTables = namedtuple("GatherTables", ["col_idx", "vec_tab", "n_items", "dtype"])
+
+
+@_on_device
+def gather_tables(col_idx, n_items, dtype):
+	"""The per-anchor-set tables of rowwise_topk_gather: col_idx ascending, distinct columns (int32 / int64 tensor on the GPU)."""
+	_dev(col_idx)
+	if col_idx.dim() != 1 or col_idx.numel() < 1 or col_idx.numel() > 65535:
+		raise ValueError("gather_tables: 1..65535 anchor columns")
+	ci = col_idx.to(torch.int32).contiguous()
+	if bool((ci[1:] <= ci[:-1]).any()) or int(ci[0]) < 0 or int(ci[-1]) >= n_items:
+		raise ValueError("gather_tables: columns must be ascending, distinct and inside the matrix")
+	vec = 8 if dtype == torch.bfloat16 else 4
+	n_vec = -(-n_items // vec)
+	tab = torch.empty(n_vec, dtype=torch.int32, device=ci.device)
+	check(_lib.load().anncur_gather_tables(_p(ci), ci.numel(), n_items, BF16 if dtype == torch.bfloat16 else F32, _p(tab), _stream()), "gather_tables")
+	return GatherTables(ci, tab, n_items, dtype)
+
+
+def rowwise_topk_gather_ok(A, k):
+	"""True if rowwise_topk_gather takes this matrix: wave-level scan (k <= 128), 16-byte aligned rows."""
+	return (k <= 128 and A.dim() == 2 and A.stride(1) == 1 and A.data_ptr() % 16 == 0 and (_ld(A) * A.element_size()) % 16 == 0
+			and A.dtype in (torch.float32, torch.bfloat16))
+
+
+@_on_device
+def rowwise_topk_gather(A, k, tables, out=None, cq_out=None):
+	"""rowwise_topk(A, k) and C_q = A[:, tables.col_idx] from ONE pass over A (reference: the slice test_scores[:, anchor_ent_idxs] of
+	..._splits.py:297,300 folded into the exact top-k of :86).  Returns (TopK, C_q [Q x n_idx] of A's dtype)."""
+	_dev(A)
+	A = _rowmajor(A)
+	Q, I = A.shape
+	if tables.n_items != I or tables.dtype != A.dtype or not rowwise_topk_gather_ok(A, k):
+		raise ValueError("rowwise_topk_gather: tables built for another matrix shape / dtype, k > 128, or rows not 16-byte aligned")
+	n_idx = tables.col_idx.numel()
+	if out is not None:
+		val, idx = out
+	else:
+		val = torch.empty((Q, k), dtype=torch.float32, device=A.device)
+		idx = torch.empty((Q, k), dtype=torch.int32, device=A.device)
+	cq = cq_out if cq_out is not None else torch.empty((Q, n_idx), dtype=A.dtype, device=A.device)
+	if tuple(cq.shape) != (Q, n_idx) or cq.dtype != A.dtype or cq.stride(1) != 1:
+		raise ValueError("rowwise_topk_gather: cq_out must be [Q x n_idx] of A's dtype, unit column stride")
+	check(_lib.load().anncur_rowwise_topk_gather(_p(A), _dt(A), Q, I, _ld(A), k, _p(val), _p(idx), _p(tables.col_idx), n_idx,
+												  _p(tables.vec_tab), _p(cq), _ld(cq), _stream()), "rowwise_topk_gather")
+	return TopK(val, idx), cq
+
+
 _KP_CHOICES = (64, 128, 256, 512)   # query operand resident in registers (score_kernel)
 _KP_WIDE_MAX = 4096                  # beyond: LDS-tiled K-general kernel (wide_kernel), Kp a multiple of 128
 

@@ -126,6 +126,8 @@ def main():
 						 "retrieval on all of them (default where the retrieval's sweep draws its tiles dynamically: Kp <= 256); side = on a second stream "
 						 "from the start of the step, joined before the overlap count (default otherwise); chunks = anncur_eval_topk (row chunks forked "
 						 "beside the retrieval's latency-bound launches); serial = one stream")
+	ap.add_argument("--fold-gather", action="store_true", help="--scan-mode partition: C_q out of the scan's own pass over A (anncur_rowwise_topk_gather) instead of "
+					"the gather kernel -- built for SURVEY a2's 'fold into the first pass', measured slower (see the comment at its use): off by default")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
 	args = ap.parse_args()
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,8 +290,20 @@ def main():
 			main.wait_stream(torch.cuda.current_stream()); s_st.wait_stream(torch.cuda.current_stream())
 			state = [{} for _ in range(2)]
 			tail_done = [torch.cuda.Event() for _ in range(2)]
-			def piece_scan(slot): state[slot]["exact"] = ops.rowwise_topk(A_test, k)
-			def piece_retr(slot): state[slot]["approx"] = retrieve()
+			# --fold-gather: C_q = A[:, anchors] out of the scan's own pass over A (anncur_rowwise_topk_gather: a2 folded into a8's first pass)
+			# instead of the separate gather, which re-reads one 64-byte sector per anchor and query (164 MB at cfg2, 0.065 ms).  The
+			# retrieval of step i then waits for scan i; scan i+1 is issued one step ahead, beside it (two result slots).  Measured (round 3,
+			# MI355X): the fused kernel takes 0.50 ms on the whole chip against 0.357 (scan) + 0.049 (gather) -- 256 anchors per row are 1.3
+			# per 64-vector step, so 72 % of the steps take the extraction branch (a divergent per-lane loop of 2-byte stores) and the table
+			# word per vector doubles the loads in flight; the step goes 0.944 -> 1.26 ms.  Off by default; kept as the measured answer.
+			fold = args.fold_gather and ops.rowwise_topk_gather_ok(A_test, k) and Kp == len(anc)
+			tabs = ops.gather_tables(anc_dev, I, A_test.dtype) if fold else None
+			def piece_scan(slot):
+				if fold: state[slot]["exact"], state[slot]["Xq"] = ops.rowwise_topk_gather(A_test, k, tabs)
+				else: state[slot]["exact"] = ops.rowwise_topk(A_test, k)
+			def piece_retr(slot):
+				state[slot]["approx"] = (ops.score_topk_fused(state[slot]["Xq"], cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
+										 if fold else retrieve())
 			def piece_tail(slot): ops.copy_to_mapped_host(ops.overlap_counts(state[slot]["exact"].indices, state[slot]["approx"].indices, cells), pinned[slot])
 			pieces = ((piece_scan, s_st), (piece_retr, main), (piece_tail, main))
 			for fn, st in pieces:   # workspaces / code objects loaded outside capture
@@ -312,14 +326,32 @@ def main():
 					pgraphs = None
 					torch.cuda.synchronize()
 			for e in tail_done: e.record(main)
+			scan_done = [torch.cuda.Event() for _ in range(2)]
+			scan_ready = [False, False]   # a scan whose results slot s holds has been issued and not yet consumed by a retrieval
+			def run_piece(j, slot):
+				fn, st = pieces[j]
+				with torch.cuda.stream(st):
+					if pgraphs is not None: pgraphs[slot][j].replay()
+					else: fn(slot)
+			def issue_scan(slot):
+				s_st.wait_event(tail_done[slot])       # the overlap count that last read this slot's scan results
+				run_piece(0, slot)
+				scan_done[slot].record(s_st)
+				scan_ready[slot] = True
 			def launch_partition(slot):
-				s_st.wait_event(tail_done[slot])
-				for j, (fn, st) in enumerate(pieces):
-					if j == 2:
-						main.wait_stream(s_st)
-					with torch.cuda.stream(st):
-						if pgraphs is not None: pgraphs[slot][j].replay()
-						else: fn(slot)
+				if not fold:   # scan i beside retrieval i, joined before the overlap count
+					issue_scan(slot)
+					run_piece(1, slot)
+					main.wait_event(scan_done[slot])
+					run_piece(2, slot)
+				else:          # retrieval i needs C_q from scan i: the scans run ONE STEP AHEAD -- scan i+1 is issued first, beside retrieval i
+					if not scan_ready[slot]:
+						issue_scan(slot)
+					issue_scan(slot ^ 1)   # (run_steps alternates the slots: this is the next step's)
+					main.wait_event(scan_done[slot])
+					scan_ready[slot] = False
+					run_piece(1, slot)
+					run_piece(2, slot)
 				tail_done[slot].record(main)
 				events[slot].record(main)
 				return slot
@@ -376,11 +408,13 @@ def main():
 		stats = overlap_stats_batch(c, [t for t, _ in cells])
 		return {t: flatten_overlap(stats[j]) for j, (t, _) in enumerate(cells)}
 
+	step_no = [0]   # the result slots alternate across ALL calls of run_steps (the partition launcher issues the next slot's scan ahead)
 	def run_steps(n):
 		res, pending = None, None
 		for i in range(n):
 			t_a = time.perf_counter()
-			cur_slot = launch(i & 1)
+			cur_slot = launch(step_no[0] & 1)
+			step_no[0] += 1
 			t_b = time.perf_counter()
 			if pending is not None:
 				res = finish(pending)
@@ -543,7 +577,8 @@ def main():
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
 			"fused_plan": plan_now,
 			"launch_mode": "eager" if not graphed else "hipGraph replay (the step's launches captured once per result slot)",
-			"scan_mode": {"used": scan_mode_used, "scan_cus": args.scan_cus if scan_mode_used == "partition" else None},
+			"scan_mode": {"used": scan_mode_used, "scan_cus": args.scan_cus if scan_mode_used == "partition" else None,
+						  "gather_folded_into_scan": bool(scan_mode_used == "partition" and args.fold_gather and ops.rowwise_topk_gather_ok(A_test, k) and Kp == len(anc))},
 			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
 			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),
 		}

@@ -132,6 +132,20 @@ int anncur_approx_error_packed(const void *X, int64_t ldx, const void *Et, int64
 int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k,
                         float *out_val, int32_t *out_idx, void *stream);
 
+/* a2 folded into a8's pass over A (SURVEY a2 "fold into the first pass"; reference ..._splits.py:297,300 + 86): the scan of
+ * anncur_rowwise_topk (k <= 128) also copies the anchor columns, cq[q, j] = A[q, col_idx[j]], as their 16-byte vectors stream past --
+ * C_q costs no second read of the rows' sectors.  col_idx: n_idx (<= 65535) ascending, distinct columns in [0, I);
+ * vec_tab uint32[ceil(I / V)] (V = 8 elements for bf16, 4 for fp32; per 16-byte vector: which elements are anchors, and how many
+ * anchors lie before it) from anncur_gather_tables for the same (col_idx, I, dtype) -- built once per anchor set; cq [Q x ldo] has A's
+ * element type.  A and its rows must be 16-byte aligned
+ * (ANNCUR_E_UNSUPPORTED otherwise: use anncur_gather_cols + anncur_rowwise_topk).  Same top-k result as anncur_rowwise_topk.
+ * Measured on MI355X (cfg2: 10 000 x 100 000 bf16, 256 anchors): 0.50 ms against 0.357 + 0.049 ms for the two separate kernels -- one HBM
+ * pass less, but the per-vector extraction costs more than the sectors it saves; callers that are HBM-capacity- rather than
+ * time-bound may still prefer it. */
+int anncur_gather_tables(const int32_t *col_idx, int32_t n_idx, int64_t I, int dtype, uint32_t *vec_tab, void *stream);
+int anncur_rowwise_topk_gather(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k, float *out_val, int32_t *out_idx,
+                               const int32_t *col_idx, int32_t n_idx, const uint32_t *vec_tab, void *cq, int64_t ldo, void *stream);
+
 /* a6+a7 fused: S_hat = X . E never written; per-query top-k ---------------------------
  *   CURApprox.topk_in_row                    eval/matrix_approx_zeshel.py:121-126
  *   approx_curr_ment_scores.topk(top_k_retvr) ...crossenc.py:106 ; ..._splits.py:89

@@ -500,6 +500,31 @@ def test_rowwise_topk_threshold_crossing_zero_nan_and_sorted_rows(ops, dtype):
 		assert torch.equal(i.cpu().long(), order)
 
 
+@pytest.mark.parametrize("Q,I,n_idx,k,dt", [(300, 100000, 256, 100, torch.bfloat16), (257, 40007, 100, 10, torch.bfloat16), (64, 4096, 500, 128, torch.bfloat16),
+											 (130, 20003, 64, 50, torch.float32), (1000, 9000, 1024, 1, torch.bfloat16), (5, 1031, 7, 5, torch.float32)])
+def test_rowwise_topk_gather_equals_scan_plus_gather(ops, Q, I, n_idx, k, dt):
+	"""a2 folded into a8's pass (anncur_rowwise_topk_gather): the same top-k as anncur_rowwise_topk bit for bit, and C_q equal to the
+	separate gather -- anchors in the first / last vectors, in the row's tail (I % V != 0), adjacent anchors, padded row pitch."""
+	g = _g(Q + I + n_idx)
+	vec = 8 if dt == torch.bfloat16 else 4
+	ld = (I + vec - 1) // vec * vec + 2 * vec                      # 16-byte aligned rows, padded
+	Abuf = torch.randn(Q, ld, generator=g).to(dt).cuda()
+	A = Abuf[:, :I]
+	cols = torch.randperm(I, generator=g)[:n_idx]
+	cols[0] = 0; cols[1] = I - 1; cols[2] = 1; cols[3] = max(2, I - 2)   # first vector, tail, neighbours
+	cols = torch.unique(cols).sort().values.cuda()
+	assert ops.rowwise_topk_gather_ok(A, k)
+	tab = ops.gather_tables(cols, I, dt)
+	(v, i), cq = ops.rowwise_topk_gather(A, k, tab)
+	v0, i0 = ops.rowwise_topk(A, k)
+	assert torch.equal(v, v0) and torch.equal(i, i0)
+	assert torch.equal(cq, A[:, cols.long()])
+	assert torch.equal(cq, ops.gather_cols(A, cols))
+	assert not ops.rowwise_topk_gather_ok(Abuf[:, 1:I + 1], k)     # misaligned rows: the caller gathers separately
+	with pytest.raises(ValueError):
+		ops.gather_tables(cols.flip(0), I, dt)                     # not ascending
+
+
 @pytest.mark.parametrize("Q,I,K,adt,pad", [(300, 4096, 64, torch.bfloat16, 8), (257, 10031, 128, torch.bfloat16, 8), (130, 7000, 256, torch.bfloat16, 8),
 										   (70, 5023, 500, torch.bfloat16, 8), (129, 6400, 256, torch.float32, 8), (40, 40, 64, torch.bfloat16, 8),
 										   (33, 20, 128, torch.float32, 8), (257, 10031, 128, torch.bfloat16, 4), (600, 9000, 256, torch.bfloat16, 4),

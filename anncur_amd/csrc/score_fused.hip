@@ -1612,7 +1612,10 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.n_tiles = (int)ceil_div64(I, TILE_I);
 	P.n_full = (int)(I / TILE_I);
 	// prepass sample: enough groups that the k-th largest group maximum is a tight bound
-	const int target = (4 * k > 512) ? 4 * k : 512;
+	int target = (4 * k > 512) ? 4 * k : 512;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_SAMPLE_GROUPS")) target = atoi(dbg);   // prepass sample size in groups (tuning knob)
+#endif
 	int n_st16 = (target + 1) / 2;
 	if ((int64_t)n_st16 * 8 <= P.n_full) { P.group = 16; P.n_st = n_st16; }
 	else { P.group = 4; P.n_st = (target + 7) / 8; }

@@ -126,6 +126,7 @@ def main():
 						 "retrieval on all of them (default where the retrieval's sweep draws its tiles dynamically: Kp <= 256); side = on a second stream "
 						 "from the start of the step, joined before the overlap count (default otherwise); chunks = anncur_eval_topk (row chunks forked "
 						 "beside the retrieval's latency-bound launches); serial = one stream")
+	ap.add_argument("--retr-streams", type=int, default=2, choices=[1, 2], help="--scan-mode partition: retrieval chains of consecutive steps on one stream or on two (a workspace each)")
 	ap.add_argument("--fold-gather", action="store_true", help="--scan-mode partition: C_q out of the scan's own pass over A (anncur_rowwise_topk_gather) instead of "
 					"the gather kernel -- built for SURVEY a2's 'fold into the first pass', measured slower (see the comment at its use): off by default")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
@@ -222,11 +223,11 @@ def main():
 		args.scan_mode = "partition" if Kp <= 256 else "side"
 	rounds_rows = int(os.environ.get("ANNCUR_BENCH_ROUND_ROWS", "4096"))
 
-	def retrieve():
+	def retrieve(workspace=None):
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
-		return ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)   # a6 + a7 fused (item rows in the index's norm order)
+		return ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, workspace=workspace)   # a6 + a7 fused (item rows in the index's norm order)
 
 	def make_launcher(mode):
 		"""launch(slot) for one way of placing the exact scan (a8's HBM-bound half) beside the MFMA-bound retrieval:
@@ -286,8 +287,14 @@ def main():
 			# (neither piece on the default stream: hipExtStreamCreateWithCUMask makes a BLOCKING stream, which the NULL stream synchronises
 			#  with implicitly -- with the retrieval there the two ran strictly one after the other: 1.41 ms per step)
 			_, s_st = ops.cu_partition_streams(device, args.scan_cus)
-			main = torch.cuda.Stream(device=device)
-			main.wait_stream(torch.cuda.current_stream()); s_st.wait_stream(torch.cuda.current_stream())
+			# --retr-streams 2 (default): the retrievals of consecutive steps on two streams with a workspace each -- the latency-bound tail of
+			# one chain (refinement, select, overlap count: most CUs idle) overlaps the head of the next (gather, prepass)
+			n_rs = 2 if args.retr_streams == 2 else 1
+			mains = [torch.cuda.Stream(device=device) for _ in range(n_rs)]
+			mains = [mains[s % n_rs] for s in range(2)]
+			wss = [ops.fused_workspace(Q, I, Kp, kr, device) for _ in range(2)] if n_rs == 2 else [None, None]
+			for m in mains: m.wait_stream(torch.cuda.current_stream())
+			s_st.wait_stream(torch.cuda.current_stream())
 			state = [{} for _ in range(2)]
 			tail_done = [torch.cuda.Event() for _ in range(2)]
 			# --fold-gather: C_q = A[:, anchors] out of the scan's own pass over A (anncur_rowwise_topk_gather: a2 folded into a8's first pass)
@@ -302,22 +309,24 @@ def main():
 				if fold: state[slot]["exact"], state[slot]["Xq"] = ops.rowwise_topk_gather(A_test, k, tabs)
 				else: state[slot]["exact"] = ops.rowwise_topk(A_test, k)
 			def piece_retr(slot):
-				state[slot]["approx"] = (ops.score_topk_fused(state[slot]["Xq"], cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
-										 if fold else retrieve())
+				state[slot]["approx"] = (ops.score_topk_fused(state[slot]["Xq"], cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, workspace=wss[slot])
+										 if fold else retrieve(wss[slot]))
 			def piece_tail(slot): ops.copy_to_mapped_host(ops.overlap_counts(state[slot]["exact"].indices, state[slot]["approx"].indices, cells), pinned[slot])
-			pieces = ((piece_scan, s_st), (piece_retr, main), (piece_tail, main))
-			for fn, st in pieces:   # workspaces / code objects loaded outside capture
-				with torch.cuda.stream(st): fn(0)
-				torch.cuda.synchronize()
+			fns = (piece_scan, piece_retr, piece_tail)
+			def stream_of(j, slot): return s_st if j == 0 else mains[slot]
+			for slot in range(2):   # workspaces / code objects loaded outside capture
+				for j, fn in enumerate(fns):
+					with torch.cuda.stream(stream_of(j, slot)): fn(slot)
+					torch.cuda.synchronize()
 			pgraphs = None
 			if not args.no_graph:
 				try:
 					pgraphs = []
 					for slot in range(2):
 						gs = []
-						for fn, st in pieces:
+						for j, fn in enumerate(fns):
 							g = torch.cuda.CUDAGraph()
-							with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+							with torch.cuda.graph(g, stream=stream_of(j, slot), capture_error_mode="thread_local"):
 								fn(slot)
 							gs.append(g)
 						pgraphs.append(gs)
@@ -325,20 +334,20 @@ def main():
 					print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
 					pgraphs = None
 					torch.cuda.synchronize()
-			for e in tail_done: e.record(main)
+			for slot in range(2): tail_done[slot].record(mains[slot])
 			scan_done = [torch.cuda.Event() for _ in range(2)]
 			scan_ready = [False, False]   # a scan whose results slot s holds has been issued and not yet consumed by a retrieval
 			def run_piece(j, slot):
-				fn, st = pieces[j]
-				with torch.cuda.stream(st):
+				with torch.cuda.stream(stream_of(j, slot)):
 					if pgraphs is not None: pgraphs[slot][j].replay()
-					else: fn(slot)
+					else: fns[j](slot)
 			def issue_scan(slot):
 				s_st.wait_event(tail_done[slot])       # the overlap count that last read this slot's scan results
 				run_piece(0, slot)
 				scan_done[slot].record(s_st)
 				scan_ready[slot] = True
 			def launch_partition(slot):
+				main = mains[slot]
 				if not fold:   # scan i beside retrieval i, joined before the overlap count
 					issue_scan(slot)
 					run_piece(1, slot)
@@ -578,7 +587,7 @@ def main():
 			"fused_plan": plan_now,
 			"launch_mode": "eager" if not graphed else "hipGraph replay (the step's launches captured once per result slot)",
 			"scan_mode": {"used": scan_mode_used, "scan_cus": args.scan_cus if scan_mode_used == "partition" else None,
-						  "gather_folded_into_scan": bool(scan_mode_used == "partition" and args.fold_gather and ops.rowwise_topk_gather_ok(A_test, k) and Kp == len(anc))},
+						  "retrieval_streams": args.retr_streams if scan_mode_used == "partition" else 1, "gather_folded_into_scan": bool(scan_mode_used == "partition" and args.fold_gather and ops.rowwise_topk_gather_ok(A_test, k) and Kp == len(anc))},
 			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
 			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),
 		}

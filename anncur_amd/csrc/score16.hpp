@@ -16,9 +16,9 @@
 // append their survivors to ONE queue per wave in LDS (rank among the hitting lanes by mbcnt, wave-uniform fill pointer in an SGPR);
 // an entry carries its query in the item word (bits 26..31: query sub-tile and lane & 15; I < 2^26).  The drain is dense -- 64 entries
 // per pass, one entry per lane: the entry's query draws its slot from the wave's 64 per-query counters in LDS (ds_add_rtn) and the entry
-// goes to the segment of (query, item split): ONE segment per (query, split), S per query.  The queue cannot overflow: a push that
-// leaves fewer than 64 free entries drains on the spot (cold path inside the tile function), and a step drains at its head when
-// the queue holds DRAIN_AT entries or more.
+// goes to the segment of (query, item split): ONE segment per (query, split), S per query.  The queue cannot overflow: the tile
+// function checks the fill a few times per tile (every 8 pushes of at most 64 entries) and drains on the spot (cold path) while the
+// next pushes might not fit, and a step drains at its head when the queue holds DRAIN_AT entries or more.
 #pragma once
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;

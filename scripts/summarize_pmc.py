@@ -17,7 +17,7 @@ qt = 2 if kp <= 256 else 1
 # are "the sweep kernel" of the roofline, whose per-launch figures average over the launches of a step
 sweep_variants = [f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 1, 16, true, false, {qt}>", f"score16_kernel<{kp}>", f"scoreq1_kernel<{kp}>", f"scoreq16_kernel<{kp}>"]
 sweep, prepass = f"score_kernel<{kp}, sweep>", f"score_kernel<{kp}, 0, 16, false, false, {qt}>"
-names = sweep_variants + [prepass, f"score_kernel<{kp}, 1, 16, false, false, 1>", "rowwise_topk_wave_kernel<unsigned short>", "select_wave_kernel<false", "select_wave_kernel<true", "select_stream_kernel<false",
+names = sweep_variants + [prepass, f"score_kernel<{kp}, 1, 16, false, false, 1>", "rowwise_topk_wave_kernel<unsigned short", "select_wave_kernel<false", "select_wave_kernel<true", "select_stream_kernel<false",
 		 "select_stream_kernel<true", "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel", "gemm_f64_kernel"]
 def key_of(n): return sweep if n in sweep_variants else n
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -74,7 +74,7 @@ if sw and "FETCH_SIZE" in sw and "WRITE_SIZE" in sw:
 		clk = sw["GRBM_GUI_ACTIVE"] / 8 / (stats[sweep]["avg_us"] * 1e-6)
 		res["score_kernel_sweep_clock_ghz"] = round(clk / 1e9, 3)
 		res["score_kernel_sweep_mfma_pipe_busy"] = round(sw.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / (sw["GRBM_GUI_ACTIVE"] / 8), 3)
-sc = out.get("rowwise_topk_wave_kernel<unsigned short>")
+sc = out.get("rowwise_topk_wave_kernel<unsigned short")
 if sc and "FETCH_SIZE" in sc:
 	res["exact_scan_hbm_bytes_per_launch"] = round(2 * sc["FETCH_SIZE"] * 1024 + sc.get("WRITE_SIZE", 0) * 1024)
 print(json.dumps(res, indent=1))

@@ -730,7 +730,7 @@ extern "C" int anncur_rowwise_topk_gather(const void *A, int dtype, int64_t Q, i
 	ANNCUR_REQUIRE(k >= 1 && k <= WSEL_K && k <= I, ANNCUR_E_UNSUPPORTED, "rowwise_topk_gather: k=%d outside the wave-level scan (1..%d)", k, WSEL_K);
 	ANNCUR_REQUIRE(A && out_val && out_idx && col_idx && vec_tab && cq, ANNCUR_E_INVALID, "rowwise_topk_gather: null pointer");
 	ANNCUR_REQUIRE(n_idx >= 1 && n_idx <= 65535 && ldo >= n_idx, ANNCUR_E_INVALID, "rowwise_topk_gather: bad anchor count / output pitch");
-	ANNCUR_REQUIRE(((uintptr_t)A % 16) == 0 && ((size_t)lda * dtype_size(dtype)) % 16 == 0, ANNCUR_E_UNSUPPORTED,
+	ANNCUR_REQUIRE(((uintptr_t)A % 16) == 0 && (Q == 1 || ((size_t)lda * dtype_size(dtype)) % 16 == 0), ANNCUR_E_UNSUPPORTED,
 				   "rowwise_topk_gather: A and its rows must be 16-byte aligned (use anncur_gather_cols + anncur_rowwise_topk)");
 	if (Q == 0) return ANNCUR_OK;
 	hipStream_t st = (hipStream_t)stream;

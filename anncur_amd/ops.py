@@ -315,8 +315,8 @@ def gather_tables(col_idx, n_items, dtype):
 
 def rowwise_topk_gather_ok(A, k):
 	"""True if rowwise_topk_gather takes this matrix: wave-level scan (k <= 128), 16-byte aligned rows."""
-	return (k <= 128 and A.dim() == 2 and A.stride(1) == 1 and A.data_ptr() % 16 == 0 and (_ld(A) * A.element_size()) % 16 == 0
-			and A.dtype in (torch.float32, torch.bfloat16))
+	return (k <= 128 and A.dim() == 2 and A.stride(1) == 1 and A.data_ptr() % 16 == 0
+			and (A.shape[0] == 1 or (_ld(A) * A.element_size()) % 16 == 0) and A.dtype in (torch.float32, torch.bfloat16))
 
 
 @_on_device

@@ -71,6 +71,32 @@ def test_rowwise_topk_random(ops, Q, I, kfrac, bf16, kind, off, seed):
 		assert all(len(set(r[r >= 0].tolist())) == int((r >= 0).sum()) for r in i)
 
 
+@settings(max_examples=_N or 40, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 24), I=st.integers(1, 40000), kfrac=st.floats(0.0, 1.0), bf16=st.booleans(), nfrac=st.floats(0.0, 1.0),
+	   kind=st.sampled_from(["normal", "ties", "const", "negative", "special", "masked", "ascending", "descending"]), pad=st.integers(0, 3), seed=st.integers(0, 10 ** 6))
+def test_rowwise_topk_gather_random(ops, Q, I, kfrac, bf16, nfrac, kind, pad, seed):
+	"""anncur_rowwise_topk_gather == anncur_rowwise_topk + A[:, columns] bit for bit: random row lengths (tails of I % V elements), anchor
+	counts from 1 to min(I, 2000) (dense and sparse, first / last columns included), padded 16-byte aligned rows, special values."""
+	g = torch.Generator().manual_seed(seed)
+	dt = torch.bfloat16 if bf16 else torch.float32
+	vec = 8 if bf16 else 4
+	k = max(1, min(I, 128, 1 + int(kfrac * min(I, 128))))
+	ld = (I + vec - 1) // vec * vec + pad * vec
+	buf = torch.zeros(Q, ld)
+	buf[:, :I] = _row_data(kind, Q, I, g)
+	A = buf.to(dt).cuda()[:, :I]
+	n_idx = max(1, min(I, 2000, 1 + int(nfrac * nfrac * min(I, 2000))))
+	cols = torch.randperm(I, generator=g)[:n_idx]
+	if n_idx >= 2: cols[0] = 0; cols[1] = I - 1
+	cols = torch.unique(cols).sort().values.cuda()
+	assert ops.rowwise_topk_gather_ok(A, k)
+	(v, i), cq = ops.rowwise_topk_gather(A, k, ops.gather_tables(cols, I, dt))
+	v0, i0 = ops.rowwise_topk(A, k)
+	assert torch.equal(v, v0) and torch.equal(i, i0)
+	want = A[:, cols.long()]
+	assert torch.equal(cq.view(torch.int16 if bf16 else torch.int32), want.contiguous().view(torch.int16 if bf16 else torch.int32))   # bit patterns (NaN-safe)
+
+
 @settings(max_examples=(_N // 4) or 25, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(Q=st.integers(1, 300), I=st.integers(2500, 90000), K=st.integers(8, 512), k=st.integers(1, 200), rank=st.integers(2, 48),
 	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), variant=st.sampled_from(["", "", "mfma16", "qt1", "mfma32"]))
@@ -85,7 +111,8 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	kw = dict(mfma16=variant == "mfma16", qt1=variant == "qt1", mfma32=variant == "mfma32")
 	plan = ops.fused_plan(Q, I, Kp, k, **kw)
 	if Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = 16x16x32 up to k = 128)
-		assert plan["lg"] in {"mfma16": (1,), "mfma32": (2,), "qt1": (2,), "": (1, 2)}[variant] and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
+		want_lg = {"mfma16": (1,), "mfma32": (2,), "qt1": (2,) if Kp >= 128 else (1, 2), "": (1, 2)}[variant]   # (qt1 at Kp = 64: no such body, the default runs)
+		assert plan["lg"] in want_lg and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
 	v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)   # (sweep variants: same answer)
 	S = X.double() @ E.double()
 	rv, ri = torch.topk(S, k, dim=1)

@@ -57,6 +57,7 @@ SIGNATURES = {
 										c_void_p, c_size_t, c_int32, c_void_p, c_void_p, POINTER(ctypes.c_float)]),
 	"anncur_score_topk_plan": (c_int, [c_int64, c_int64, c_int32, c_int32, _p32]),
 	"anncur_score_topk_plan_ex": (c_int, [c_int64, c_int64, c_int32, c_int32, c_int32, _p32, c_int32]),
+	"anncur_score_topk_survivors": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, ctypes.POINTER(ctypes.c_double), c_void_p]),
 	"anncur_rerank": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_overlap_counts": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, _p32, _p32, c_int32, c_void_p, c_void_p]),
 	"anncur_copy_bytes": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

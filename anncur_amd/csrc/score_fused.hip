@@ -2332,6 +2332,23 @@ extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32
 	return ANNCUR_OK;
 }
 
+/* diagnostics: candidates the sweep of the LAST call on this workspace kept, per query on average (the segment counts it left behind;
+ * synchronises the stream).  What a threshold plan is judged by: k ln(I / k) is what an online threshold can reach. */
+extern "C" int anncur_score_topk_survivors(const void *workspace, int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, double *mean_per_query,
+										   void *stream) {
+	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0 && workspace && mean_per_query, ANNCUR_E_INVALID, "score_topk_survivors: bad arguments");
+	const FusedPlan P = plan_any(Q, I, Kp, k, flags);
+	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED, "score_topk_survivors: unsupported shape");
+	const size_t n = (size_t)Q * (wide_kp(Kp) ? 4 : P.lg) * P.S;
+	std::vector<uint32_t> h(n);
+	ANNCUR_HIP_OK(hipMemcpyAsync(h.data(), (const unsigned char *)workspace + P.off_segcnt, n * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	ANNCUR_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+	double tot = 0.0;
+	for (size_t i = 0; i < n; ++i) tot += (h[i] & 0x80000000u) ? 0.0 : (double)h[i];   // (a poisoned count marks a repaired split)
+	*mean_per_query = tot / (double)Q;
+	return ANNCUR_OK;
+}
+
 /* a11 on packed bf16 operands (the layout of anncur_score_topk): err_sq[q] = sum_i (X[q,:].Et[i,:] - A[q,i])^2, norm_sq[q] = sum_i A[q,i]^2 */
 extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *A, int a_dtype, int64_t lda,
 										  int64_t Q, int64_t I, int32_t Kp, float *err_sq, float *norm_sq, void *stream) {

@@ -580,6 +580,15 @@ def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, m
 	return TopK(val, idx), [float(x) for x in ms]
 
 
+@_on_device
+def fused_survivors(workspace, Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False):
+	"""Mean number of candidates per query the sweep of the last score_topk_fused call on `workspace` kept (diagnostics; synchronises)."""
+	out = ctypes.c_double()
+	check(_lib.load().anncur_score_topk_survivors(_p(workspace), Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32), ctypes.byref(out), _stream()),
+		  "score_topk_survivors")
+	return out.value
+
+
 def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False):
 	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 body (per-lane
 	rings; the default above k = 128, and for Kp = 512), 1 = the 16x16x32 body (one queue per wave; the default for Kp <= 256, k <= 128),

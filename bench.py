@@ -514,6 +514,11 @@ def main():
 		ops.score_topk_fused(Xr, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
 	ev[1].record(); torch.cuda.synchronize()
 	retrieve_ms = ev[0].elapsed_time(ev[1]) / n_ro
+	def survivors(kk):   # candidates per query the sweep of the last call kept (the default workspace those calls ran on)
+		ws_ = ops._Workspace.get(_lib.load().anncur_score_topk_workspace_bytes(Q, I, Kp, kk), device)
+		return ops.fused_survivors(ws_, Q, I, Kp, kk, leading_sample=True)
+	survivors_k = survivors(kr)
+	survivors_k500 = None
 	# retrieve-only at k_retvr = 500, the reference's default for entry A (crossenc.py:238): more survivors, wave-level select with
 	# 8 keys per lane, predicated sweep stages
 	retrieve500_ms = None
@@ -528,6 +533,7 @@ def main():
 			ops.score_topk_fused(Xr, cur._Etp_sorted, I, 500, leading_sample=True, item_ids=cur._item_ids)
 		ev[1].record(); torch.cuda.synchronize()
 		retrieve500_ms = ev[0].elapsed_time(ev[1]) / n_ro
+		survivors_k500 = survivors(500)
 	# the same index build with the reference's own pseudo-inverse call (numpy.linalg.pinv on the host: U bit-identical to the
 	# reference) instead of the default "auto" route (fp64 Newton-Schulz on the GPU while the block is well conditioned)
 	torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -578,8 +584,10 @@ def main():
 			"sweep_stages": [{"tiles": int(t1 - t0), "ms": float(stage[6 + g]), "tflops": 2.0 * Q * Kp * 32.0 * (t1 - t0) / (max(float(stage[6 + g]), 1e-9) * 1e-3) / 1e12}
 							 for g, (t0, t1) in enumerate(zip([0] + plan_now["stage_end"][:-1], plan_now["stage_end"]))],
 			"retrieve_only": {"value": world * Q / (retrieve_ms * 1e-3), "unit": "queries/s", "ms_per_step": retrieve_ms,
-							  "what": "gather C_q + fused S_hat/top-k_retvr only (no exact scan, no overlap), eager launches, this rank x world"},
+							  "survivors_per_query": survivors_k,
+							  "what": "gather C_q + fused S_hat/top-k_retvr only (no exact scan, no overlap), eager launches, this rank x world; survivors = candidates the sweep kept per query (k ln(I/k) is what a sequential threshold can reach)"},
 			"retrieve_only_k500": ({"value": world * Q / (retrieve500_ms * 1e-3), "unit": "queries/s", "ms_per_step": retrieve500_ms,
+									"survivors_per_query": survivors_k500,
 									"what": "as retrieve_only with k_retvr = 500 (the reference's default for entry A)"} if retrieve500_ms else None),
 			"index_build_s": index_build_s, "index_build_numpy_pinv_s": index_build_numpy_s,
 			"index_build_what": "gather anchor columns + U = pinv(W) + E = U.R + bf16 packs; pinv 'auto' = fp64 Newton-Schulz on the GPU (host LAPACK only for ill-conditioned blocks); numpy = the reference's host call",

@@ -221,6 +221,10 @@ int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t 
  * filter, 1: 32x32x16 with the exec-mask filter, 2: 16x16x32, 3 / 4: the Kp = 512 body with the wave-level queue on 32x32x16 / 16x16x32 MFMAs), ring
  * drain period per stage[3]}.  Lets a caller (and the parity tests) see that a variant flag was honoured for the shape. */
 int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out);
+/* Diagnostics: mean number of candidates per query the sweep of the last call on `workspace` kept (reads the segment counts it left
+ * behind; synchronises `stream`).  k ln(I / k) is what a sequential threshold can reach. */
+int anncur_score_topk_survivors(const void *workspace, int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, double *mean_per_query,
+                                void *stream);
 
 /* a8: exact re-rank of the approximately retrieved items + a10 overlap counts --------
  *   temp[approx_idx] = exact[approx_idx]; temp.topk(k)      ...crossenc.py:108-113 ; ..._splits.py:93-96

@@ -1006,6 +1006,8 @@ __device__ __forceinline__ void error_mfma_tile(const uint32_t (&aoff)[FusedCfg<
 // comes in by the same direct-to-LDS loads as the item tile (16 bytes per lane, four lanes per row, 16 rows per instruction), double
 // buffered, one tile ahead; the lanes then read their four quads per sub-tile from LDS (ds_read_b64; the 16-byte chunk of a row is
 // XOR-swizzled with (row >> 2) & 3 on the DMA's source address: two-way bank conflicts instead of eight-way).
+// (The sweep's stagger with the sums in the filter's place -- sub-tile 0's sums in the shadow of sub-tile 1's chain -- was built and
+//  measured: no gain at Kp = 128 (0.460 vs 0.459 ms), 16 spilled registers at Kp = 256 (1.28 ms): the epilogue is not what bounds it.)
 template <int KP>
 __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, const uint16_t *__restrict__ Aex, int64_t lda,
 															float *__restrict__ err_sq, float *__restrict__ norm_sq) {
@@ -1037,20 +1039,31 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 			xb[t][s] = __builtin_bit_cast(bf16x8, w);
 		}
 	}
-	// exact-tile DMA: piece i of this wave fills LDS chunks (wave * PA + i) * 64 + lane: row = chunk >> 2, position = chunk & 3
-	const uint16_t *asrc[PA];
+	// exact-tile DMA: piece i of this wave fills LDS chunks (wave * PA + i) * 64 + lane: row = chunk >> 2, position = chunk & 3.
+	// Source = the row block's base (uniform) + a 32-bit byte offset per piece (a row block spans at most 256 rows of the matrix)
+	const unsigned char *abase = reinterpret_cast<const unsigned char *>(Aex + (int64_t)rb * Cfg::BQ * lda);
+	uint32_t asrc[PA];
 #pragma unroll
 	for (int i = 0; i < PA; ++i) {
 		const int ch = (wave * PA + i) * 64 + lane, row = ch >> 2, pos = ch & 3;
-		int64_t q = (int64_t)rb * Cfg::BQ + row;
-		if (q >= p.Q) q = p.Q - 1;  // rows past Q re-read the last row (their sums are dropped)
-		asrc[i] = Aex + q * lda + 8 * (pos ^ ((row >> 2) & 3));
+		const int64_t last = p.Q - 1 - (int64_t)rb * Cfg::BQ;   // rows past Q re-read the last row (their sums are dropped)
+		asrc[i] = (uint32_t)(((int64_t)row < last ? (int64_t)row : last) * lda * 2) + (uint32_t)(16 * (pos ^ ((row >> 2) & 3)));
 	}
+	// both DMAs hand-placed (tile_dma_s: SGPR base, 32-bit lane offsets, M0 from a scalar): the builtin's per-lane 64-bit pointers and LDS
+	// destinations cost ~24 VGPRs, which the staggered Kp = 256 body does not have
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
+	uint32_t dma_off[Cfg::TILE_BYTES / 4096];
+	tile_dma_offsets<KP>(dma_off, wave_u, lane);
 	auto adma = [&](int j, int buf) {
+		const unsigned char *src = abase + (int64_t)j * (TILE_I * 2);   // (uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-		for (int i = 0; i < PA; ++i)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc[i] + (int64_t)j * TILE_I),
-											 (__attribute__((address_space(3))) void *)(smem + AOFF + buf * ATILE + (wave * PA + i) * 1024), 16, 0, 0);
+		for (int i = 0; i < PA; ++i) {
+			const uint32_t m0v = lds_base + (uint32_t)(AOFF + buf * ATILE + (wave_u * PA + i) * 1024);
+			asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(asrc[i]), "s"(src) : "memory", "m0");
+		}
+#endif
 	};
 	__builtin_amdgcn_s_waitcnt(0x0F70);  // see score_kernel: keeps vmcnt(0) out of the tile loop
 
@@ -1059,7 +1072,7 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 #pragma unroll
 	for (int t = 0; t < QT; ++t) { se[t] = 0.f; sn[t] = 0.f; }
 	if (j_begin < j_end) {
-		tile_dma<KP>(p.Et, j_begin, smem, wave, lane);
+		tile_dma_s<KP>(p.Et, j_begin, lds_base, wave_u, dma_off);
 		adma(j_begin, 0);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
@@ -1071,7 +1084,7 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 #define ERRL_STEP(CUR, J)                                                                                                       \
 	do {                                                                                                                        \
 		if ((J) + 1 < j_end) {                                                                                                  \
-			tile_dma<KP>(p.Et, (J) + 1, smem + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave, lane);                                      \
+			tile_dma_s<KP>(p.Et, (J) + 1, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);                                      \
 			adma((J) + 1, (CUR) ^ 1);                                                                                           \
 		}                                                                                                                       \
 		f32x16 acc[QT];                                                                                                         \

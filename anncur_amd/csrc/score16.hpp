@@ -30,13 +30,8 @@ struct Fused16Cfg {
 	static constexpr int CPR = KP / 8;
 	static constexpr int TILE_BYTES = TILE_I * KP * 2;
 	static constexpr int QCAP = 1024;                // entries of a wave's queue
-#if defined(ANNCUR_V_DRAIN128)
-	static constexpr int DRAIN_AT = 128;
-#elif defined(ANNCUR_V_DRAIN320)
-	static constexpr int DRAIN_AT = 320;
-#else
-	static constexpr int DRAIN_AT = 192;             // a step drains at its head from this fill on (three full passes; 128 / 320 measured: see DESIGN 4.1)
-#endif
+	static constexpr int DRAIN_AT = 192;             // without a drain schedule (p.drain_tiles = 0): a step drains at its head from this fill on
+	static constexpr int DRAIN_HARD = 320;           // with one: the unscheduled drain of a wave whose queue ran ahead of the plan (<= QCAP - 640: see w.limit)
 	static constexpr int QUEUE_OFF = 2 * TILE_BYTES;
 	static constexpr int CNT_OFF = QUEUE_OFF + 4 * QCAP * 8;        // 256 per-query candidate counts of this item split
 	static constexpr int TICKET_OFF = CNT_OFF + 256 * 4;            // ticket words of the dynamic tile schedule (score_kernel)
@@ -50,29 +45,38 @@ struct WaveQueue {
 	uint32_t base, limit;      // LDS byte address of the queue, of the fill from which a step of the tile function drains first
 	uint32_t cnt;              // LDS byte address of the wave's 64 per-query counts
 	uint2 *seg;                // segment of the wave's first query for this item split
-	int64_t q_stride;          // entries between the segments of consecutive queries (segments per query x capg)
+	uint32_t q_stride8;        // BYTES between the segments of consecutive queries (segments per query x capg x 8; x 63 queries < 2^32: nseg <= 255, capg <= 16384)
 	uint32_t capg, n_items;
 	int lane;
 };
 
-// Drain: entry i of the queue -> lane i & 63 of pass i >> 6.
+// Drain: entry i of the queue -> lane i & 63 of pass i >> 6, TWO passes per iteration: both entries read back to back (one wait), both
+// slots drawn from the per-query counters back to back (one wait), then the two stores.  (Round 3 drained pass by pass: read, wait, draw,
+// wait, store -- two exposed LDS round trips per 64 entries, ~250 cycles; the phase stamps put the drain at 198 cycles per first-stage tile
+// and, because the four waves of a workgroup drained in DIFFERENT tiles, the per-tile barrier at 633: see 'Scheduled drain' in the kernel.)
+// A lane past the end re-reads the last entry and adds 0 to its counter.  Segment address = uniform base + 32-bit byte offset.
 __device__ __forceinline__ void wq_drain(const WaveQueue &w, uint32_t &fill) {
 	const uint32_t n = (fill - w.base) >> 3;  // (uniform)
+	unsigned char *const segb = reinterpret_cast<unsigned char *>(w.seg);
 #pragma nounroll
-	for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-		const uint32_t i = i0 + (uint32_t)w.lane;
-		if (i < n) {
-			const uint2 e = lds_load_u64(w.base + i * 8u);
-			const uint32_t item = e.y & WQ_ITEM_MASK, ql = e.y >> WQ_ITEM_BITS;
-			if (item < w.n_items) {  // (the matrix' last tile may be partial)
-				uint32_t pos = 0;
+	for (uint32_t i0 = 0; i0 < n; i0 += 128) {
+		const uint32_t iA = i0 + (uint32_t)w.lane, iB = iA + 64u;
+		const bool inA = iA < n, inB = iB < n;
+		unsigned long long dA = 0, dB = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-				const uint32_t one = 1u;
-				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(w.cnt + ql * 4u), "v"(one) : "memory");
+		asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+					 : "=&v"(dA), "=&v"(dB) : "v"(w.base + (inA ? iA : n - 1u) * 8u), "v"(w.base + (inB ? iB : n - 1u) * 8u) : "memory");
 #endif
-				if (pos < w.capg) w.seg[(int64_t)ql * w.q_stride + pos] = make_uint2(e.x, item);
-			}
-		}
+		const uint32_t hiA = (uint32_t)(dA >> 32), hiB = (uint32_t)(dB >> 32);
+		const uint32_t itemA = hiA & WQ_ITEM_MASK, qlA = hiA >> WQ_ITEM_BITS, itemB = hiB & WQ_ITEM_MASK, qlB = hiB >> WQ_ITEM_BITS;
+		const bool okA = inA && itemA < w.n_items, okB = inB && itemB < w.n_items;  // (the matrix' last tile may be partial)
+		uint32_t posA = 0, posB = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+		asm volatile("ds_add_rtn_u32 %0, %2, %4\n\tds_add_rtn_u32 %1, %3, %5\n\ts_waitcnt lgkmcnt(0)"
+					 : "=&v"(posA), "=&v"(posB) : "v"(w.cnt + qlA * 4u), "v"(w.cnt + qlB * 4u), "v"(okA ? 1u : 0u), "v"(okB ? 1u : 0u) : "memory");
+#endif
+		if (okA && posA < w.capg) *reinterpret_cast<uint2 *>(segb + (qlA * w.q_stride8 + posA * 8u)) = make_uint2((uint32_t)dA, itemA);
+		if (okB && posB < w.capg) *reinterpret_cast<uint2 *>(segb + (qlB * w.q_stride8 + posB * 8u)) = make_uint2((uint32_t)dB, itemB);
 	}
 	fill = w.base;
 }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	w.base = lds_base + (uint32_t)(C::QUEUE_OFF + wave_u * C::QCAP * 8);
 	w.limit = w.base + (uint32_t)(C::QCAP - 64 * (8 + 2 * (16 / K > 0 ? 16 / K : 1))) * 8u;  // see stagger16_tile: 8 + 2 EPS pushes between two checks
 	w.cnt = lds_base + (uint32_t)(C::CNT_OFF + wave_u * 256);
-	w.q_stride = (int64_t)p.nseg * p.capg;
+	w.q_stride8 = (uint32_t)p.nseg * (uint32_t)p.capg * 8u;
 	w.seg = p.cand + (q_wave0 * p.nseg + split) * (int64_t)p.capg;
 	w.capg = (uint32_t)p.capg; w.n_items = (uint32_t)p.I; w.lane = lane;
 	uint32_t fill = w.base;
@@ -253,6 +257,16 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 #define PH16(i) do { } while (0)
 #define PH16_TILE() do { } while (0)
 #endif
+	// Scheduled drain (round 4).  Round 3 drained a wave's queue when IT held DRAIN_AT entries: every wave in a tile of its own, a few
+	// hundred to 1500 cycles each, while the other three waited at the tile's barrier -- the phase stamps charged the barrier with 633 of
+	// a first-stage tile's 4773 cycles and 308 of a second-stage tile's 2929 ("hit imbalance" in round 3's notes: it was drain imbalance:
+	// 4 waves x one drain every ~7 tiles x ~1400 cycles = 800 expected cycles of waiting per tile).  Now the plan gives the stage a drain
+	// period in tiles (expected fill ~160 entries, half of it in the norm-ordered leading quarter of the first stage) and the four waves
+	// count it down together; a wave whose queue runs ahead of the plan still drains on its own at DRAIN_HARD.
+	const int drain_tiles = p.drain_tiles > 0 ? p.drain_tiles : 0x40000000, drain_dense = p.drain_tiles > 1 ? (p.drain_tiles + 1) / 2 : drain_tiles;
+	const int dense_end = (p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
+	const uint32_t drain_level = w.base + (uint32_t)(p.drain_tiles > 0 ? C::DRAIN_HARD : C::DRAIN_AT) * 8u;
+	int drain_in = t_cur >= 0 && t_cur < dense_end ? drain_dense : drain_tiles;
 #define STAGGER16_STEP(CUR)                                                                                                     \
 	do {                                                                                                                        \
 		const int J = t_cur;                                                                                                    \
@@ -269,7 +283,11 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		uint32_t ticket = 0;                                                                                                    \
 		if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);                                                         \
 		PH16(0);                                                                                                                \
-		if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                               \
+		/* Scheduled drain: all four waves drain in the SAME step (a uniform countdown), whatever their fill -- see above */    \
+		if (--drain_in == 0) {                                                                                                  \
+			drain_in = J < dense_end ? drain_dense : drain_tiles;                                                               \
+			if (fill != w.base) wq_drain(w, fill);                                                                              \
+		} else if (fill >= drain_level) wq_drain(w, fill);                                                                      \
 		const uint32_t item0 = ((uint32_t)J * TILE_I + 4 * g4) | lane_code;                                                     \
 		PH16(1);                                                                                                                \
 		stagger16_tile<KP, CUR>(aoff, xb, accP, tau, tau_prev, item0, item0_prev, w, fill);                                        \

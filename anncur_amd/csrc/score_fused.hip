@@ -99,6 +99,7 @@ struct FusedParams {
 	int nseg;                         // candidate segments per query (2 S: 32x32x16 body, lane halves; S: 16x16x32 body)
 	int rb_major;                     // work id -> (row block, split): 1 = row-block-major (dynamic tile schedule), 0 = split-major
 	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
+	int drain_tiles;                  // wave-queue bodies: scheduled drain period in tiles (0: every wave on its own, by fill) -- score16.hpp
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	int debug_stamp;                  // timing experiments only: this launch writes the in-kernel clock stamps
 	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
@@ -1517,6 +1518,7 @@ struct FusedPlan {
 	bool ok;
 	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
 	int n_stages, stage_end[3], stage_tps[3], stage_flush[3], stage_pred[3];
+	int stage_drain[3];   // wave-queue bodies: the stage's scheduled drain period in tiles (score16.hpp 'Scheduled drain')
 	int leading;
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
 	bool body16;  // the sweep stages run score16_kernel
@@ -1602,6 +1604,13 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		// 0.84 vs 0.88; I = 10^6, Kp = 256 (P ~ 0.2 over most of the sweep) 2.80 vs 2.76 -> exec above P = 0.25.
 		// (staggered Kp <= 256 loop only: launch_fused ignores it elsewhere)
 		P.stage_pred[i] = (1.0 - exp(-4.0 * rate)) > 0.25 ? 1 : 0;
+		// wave-queue bodies: a wave collects 2 * rate survivors per query and tile, from 64 queries (16x16x32 body, Kp <= 256: 1024-entry
+		// queue) or 32 (Kp = 512: 448 entries); the period aims at ~160 / ~96 entries per scheduled drain (2-3 / 1-2 dense passes)
+		{
+			const double per_wave_tile = 2.0 * rate * (P.bodyq1 ? 32.0 : 64.0), target = P.bodyq1 ? 96.0 : 160.0;
+			const int dt = (int)(target / (per_wave_tile > 1e-9 ? per_wave_tile : 1e-9) + 0.5);
+			P.stage_drain[i] = dt < 1 ? 1 : (dt > 64 ? 64 : dt);
+		}
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		if (const char *dbg = getenv("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = atoi(dbg) != 0;
 #endif
@@ -1956,6 +1965,10 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
+		p.drain_tiles = P.stage_drain[stg];
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (const char *dbg = getenv("ANNCUR_DEBUG_DRAIN_TILES")) p.drain_tiles = atoi(dbg);   // 0: round 3's per-wave drain by fill
+#endif
 		p.tile_step = tile_step;
 		if (chunk > 0) {
 			// (row-block-major work ids -- the workgroups of a row block on ONE XCD -- were measured for the ticket schedule, round 3, one box:

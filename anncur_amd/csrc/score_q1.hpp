@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void scoreq1_kernel(const FusedParams p) {
 	w.base = lds_base + (uint32_t)(C::QUEUE_OFF + wave_u * C::QCAP * 8);
 	w.limit = w.base + (uint32_t)(C::QCAP - 64 * (C::CHECK_PUSHES + 1)) * 8u;
 	w.cnt = lds_base + (uint32_t)(C::CNT_OFF + wave_u * 128);
-	w.q_stride = (int64_t)p.nseg * p.capg;
+	w.q_stride8 = (uint32_t)p.nseg * (uint32_t)p.capg * 8u;
 	w.seg = p.cand + (q_wave0 * p.nseg + split) * (int64_t)p.capg;
 	w.capg = (uint32_t)p.capg; w.n_items = (uint32_t)p.I; w.lane = lane;
 	uint32_t fill = w.base;
@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256, 2) void scoreq1_kernel(const FusedParams p) {
 	for (int s = 0; s < 8; ++s) aoff8[s] = lds_addr(smem) + (uint32_t)(r * CPR + ((2 * s + h) ^ (r & 15))) * 16u;
 	const uint32_t lane_code = (uint32_t)r << WQ_ITEM_BITS;
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger1q_tile() counts LDS reads
+	// scheduled drain (score16.hpp 'Scheduled drain'): the plan's period in tiles, halved in the norm-ordered leading quarter of the first stage
+	const int drain_tiles = p.drain_tiles > 0 ? p.drain_tiles : 0x40000000, drain_dense = p.drain_tiles > 1 ? (p.drain_tiles + 1) / 2 : drain_tiles;
+	const int dense_end = (p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
+	int drain_in = t_cur >= 0 && t_cur < dense_end ? drain_dense : drain_tiles;
 #define Q1_STEP(CUR, ACC, ACCP)                                                                                                 \
 	do {                                                                                                                        \
 		const int J = t_cur;                                                                                                    \
@@ -155,7 +159,10 @@ __global__ __launch_bounds__(256, 2) void scoreq1_kernel(const FusedParams p) {
 		if (nx >= 0) tile_dma_s<KP>(p.Et, nx, lds_base + ((CUR) ^ 1) * C::TILE_BYTES, wave_u, dma_off);                         \
 		uint32_t ticket = 0;                                                                                                    \
 		if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);                                                         \
-		if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                               \
+		if (--drain_in == 0) {  /* scheduled drain: the four waves together (score16.hpp) */                                     \
+			drain_in = J < dense_end ? drain_dense : drain_tiles;                                                               \
+			if (fill != w.base) wq_drain(w, fill);                                                                              \
+		} else if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                        \
 		stagger1q_tile<KP, CUR>(aoff8, xb, ACC, ACCP, tau_prev, item0_prev, w, fill);                                           \
 		tau_prev = tau; item0_prev = ((uint32_t)J * TILE_I + 4 * h) | lane_code;                                                \
 		ticket_wait(ticket);                                                                                                    \

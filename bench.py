@@ -13,8 +13,10 @@ prints ONE JSON line on rank 0 (metric, value, roofline, cpu_baseline, ...).
 
 N > 1: one process per GPU.  Under torchrun (RANK / WORLD_SIZE in the environment) this process is one of the ranks; started
 plainly with --gpus N > 1 it launches the N ranks itself (torch.distributed.run, before any GPU call) and relays their result.
-The multi-GPU workload is BASELINE.json configs[3] (cfg4: 50k x 1M bf16, 512 anchors) at its per-GPU shape -- 6 250 query rows
-per rank whatever N is (weak scaling) -- with the anchor rows assembled by ONE RCCL all-gather (timed as allgather_ms).
+ONE workload per JSON key at every N: the top-level value / config is the headline workload (cfg2's shape on every rank: weak scaling,
+the anchor rows assembled by ONE RCCL all-gather, timed as allgather_ms), so value(N) / value(1) is a scaling curve of one workload and
+the N = 1 point is the single-GPU line.  At N > 1 the line also carries "cfg4": BASELINE.json configs[3] (50k x 1M bf16, 512 anchors)
+at its per-GPU shape -- 6 250 query rows per rank -- measured in the same job with its own value, roofline, allgather_ms, solo_rank0.
 """
 import argparse
 import glob
@@ -105,69 +107,13 @@ def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 			"data": "synthetic clustered vectors (200 centres), host numpy in / out like FAISS", "parity": "unpinned (FAISS absent): recall-judged in tests/"}
 
 
-def main():
-	ap = argparse.ArgumentParser()
-	ap.add_argument("--gpus", type=int, default=None, help="default: WORLD_SIZE under torchrun, else 1")
-	ap.add_argument("--steps", type=int, default=30)
-	ap.add_argument("--warmup", type=int, default=5)
-	ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg2 on one GPU, cfg4_per_gpu on several")
-	ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-rank path with ranks sharing GPUs")
-	ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses GPU r %% device_count (RCCL cannot; use --backend gloo)")
-	ap.add_argument("--no-k500", action="store_true", help="skip the retrieve_only_k500 side-line (profiling runs: its launches share the sweep kernel's name)")
-	ap.add_argument("--sustained-seconds", type=float, default=10.0, help="also loop the same step for this long and report it (DVFS-settled rate); 0 = skip")
-	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
-	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
-	ap.add_argument("--no-ivf", action="store_true", help="skip the ivf_search side-line (the IVF-flat branch of build_flat_or_ivff_index at the hard-negative-mining size)")
-	ap.add_argument("--seed", type=int, default=0)
-	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
-	ap.add_argument("--scan-cus", type=int, default=96, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD)")
-	ap.add_argument("--scan-mode", default=None, choices=["side", "partition", "tail", "chunks", "serial"],
-					help="how the exact scan is scheduled against the retrieval: partition = on a stream whose CU mask leaves it --scan-cus CUs, beside the "
-						 "retrieval on all of them (default where the retrieval's sweep draws its tiles dynamically: Kp <= 256); side = on a second stream "
-						 "from the start of the step, joined before the overlap count (default otherwise); chunks = anncur_eval_topk (row chunks forked "
-						 "beside the retrieval's latency-bound launches); serial = one stream")
-	ap.add_argument("--retr-streams", type=int, default=2, choices=[1, 2], help="--scan-mode partition: retrieval chains of consecutive steps on one stream or on two (a workspace each)")
-	ap.add_argument("--fold-gather", action="store_true", help="--scan-mode partition: C_q out of the scan's own pass over A (anncur_rowwise_topk_gather) instead of "
-					"the gather kernel -- built for SURVEY a2's 'fold into the first pass', measured slower (see the comment at its use): off by default")
-	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
-	args = ap.parse_args()
-	world = int(os.environ.get("WORLD_SIZE", "1"))
-	if args.gpus is None:
-		args.gpus = world if os.environ.get("RANK") is not None else 1
-	if args.gpus > 1 and os.environ.get("RANK") is None:
-		self_launch(args)
-	if args.gpus != world:   # before any process group exists: nothing to tear down, no rank left waiting in a collective
-		raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-	if args.config is None:
-		args.config = "cfg2" if world == 1 else "cfg4_per_gpu"
-	cfg = CONFIGS[args.config]
-	# stdout carries exactly ONE line (the result JSON): libraries that print banners to fd 1 (RCCL at communicator creation
-	# does) are sent to stderr for the whole run, the JSON goes to the saved descriptor at the end
-	sys.stdout.flush()
-	result_fd = os.dup(1)
-	os.dup2(2, 1)
-
-	rank = int(os.environ.get("RANK", "0"))
-	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-	if not torch.cuda.is_available():
-		raise SystemExit("bench.py needs an MI355X: anncur_amd has no CPU path")
-	torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
-	if args.share_gpu:
-		local_rank %= torch.cuda.device_count()
-	torch.cuda.set_device(local_rank)
-	device = torch.device("cuda", local_rank)
-	use_dist = world > 1 or (os.environ.get("RANK") is not None and os.environ.get("ANNCUR_BENCH_FORCE_DIST"))
-	if use_dist:
-		import torch.distributed as dist
-		if args.backend == "nccl":
-			dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
-		else:
-			dist.init_process_group("gloo")
-	ranks_seen = torch.distributed.get_world_size() if use_dist else 1
-
-	if os.environ.get("ANNCUR_BENCH_FAIL_RANK") == str(rank):   # fault injection for tests/test_gpu_bench_multirank.py
-		raise RuntimeError(f"[bench] injected failure on rank {rank} (ANNCUR_BENCH_FAIL_RANK)")
-
+def run_config(args, cfg_name, ctx, light=False):
+	"""The whole measurement of ONE workload (CONFIGS[cfg_name]) on every rank: data + index build, the timed K steps, the per-kernel
+	side-lines.  Returns the result dict on rank 0 (None elsewhere).  light: the timed steps, solo_rank0 and the roofline figures only
+	(the cfg4 sub-object of a multi-rank run)."""
+	rank, world, device, use_dist, ranks_seen = ctx["rank"], ctx["world"], ctx["device"], ctx["use_dist"], ctx["ranks_seen"]
+	cfg = CONFIGS[cfg_name]
+	scan_mode = args.scan_mode
 	from anncur_amd import _lib, ops
 	from anncur_amd.cur import CURApprox
 	from anncur_amd.eval_utils import flatten_overlap, overlap_stats_batch, overlap_stats_from_counts
@@ -215,12 +161,12 @@ def main():
 	events = [torch.cuda.Event() for _ in range(2)]
 
 	if args.no_overlap:
-		args.scan_mode = "serial"
-	if args.scan_mode is None:
+		scan_mode = "serial"
+	if scan_mode is None:
 		# Measured on MI355X, one box (round 3): cfg2 (Kp = 256) 0.939 ms per step with the partition, 1.007 with "side"; the cfg4 per-GPU
 		# shape (Kp = 512: static tile shares, and a scan a third of the step) 9.00 vs 7.42 -- a workgroup that shares its CU with the scan
 		# for the whole launch holds a static share back, the dynamic schedule just hands it fewer tiles.
-		args.scan_mode = "partition" if Kp <= 256 else "side"
+		scan_mode = "partition" if Kp <= 256 else "side"
 	rounds_rows = int(os.environ.get("ANNCUR_BENCH_ROUND_ROWS", "4096"))
 
 	def retrieve(workspace=None):
@@ -396,13 +342,13 @@ def main():
 		return launch_one, graphs is not None
 
 	try:
-		launchers = {args.scan_mode: make_launcher(args.scan_mode)}
+		launchers = {scan_mode: make_launcher(scan_mode)}
 	except Exception as exc:   # measurement plumbing only: a runtime without CU-masked streams falls back to the second-stream placement
-		if args.scan_mode != "partition":
+		if scan_mode != "partition":
 			raise
 		print(f"[bench] --scan-mode partition unavailable ({type(exc).__name__}: {exc}); using --scan-mode side", file=sys.stderr)
 		torch.cuda.synchronize()
-		args.scan_mode = "side"
+		scan_mode = "side"
 		launchers = {"side": make_launcher("side")}
 	launch, graphed = None, False
 
@@ -439,8 +385,8 @@ def main():
 			torch.distributed.barrier()
 		torch.cuda.synchronize()
 
-	launch, graphed = launchers[args.scan_mode]
-	scan_mode_used = args.scan_mode
+	launch, graphed = launchers[scan_mode]
+	scan_mode_used = scan_mode
 	res = run_steps(args.warmup)
 	barrier()
 	t0 = time.perf_counter()
@@ -469,7 +415,7 @@ def main():
 	# sustained: the same step looped for >= 10 s (the timed region above is a burst of K steps; under a long MFMA load the chip
 	# lowers its clock -- MI355X_MICROARCH.md 'DVFS give-back'; long enough for a 5 s utilisation sampler to see the GPU busy)
 	sustained = None
-	if args.sustained_seconds > 0:
+	if args.sustained_seconds > 0 and not light:
 		barrier()
 		t0 = time.perf_counter(); n_sus = 0
 		while True:
@@ -522,7 +468,7 @@ def main():
 	# retrieve-only at k_retvr = 500, the reference's default for entry A (crossenc.py:238): more survivors, wave-level select with
 	# 8 keys per lane, predicated sweep stages
 	retrieve500_ms = None
-	if not args.no_k500 and ops.fused_supported(Q, I, Kp, 500):
+	if not args.no_k500 and not light and ops.fused_supported(Q, I, Kp, 500):
 		for _ in range(2):
 			ops.score_topk_fused(Xr, cur._Etp_sorted, I, 500, leading_sample=True, item_ids=cur._item_ids)
 		ev[0].record()
@@ -549,10 +495,10 @@ def main():
 	# HBM bytes per launch of the sweep from the PMC passes of THIS config (scripts/profile_round.sh -> profiles/); null if this
 	# config has not been profiled -- never another shape's number
 	traffic = traffic_src = None
-	for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{args.config}.json")), reverse=True):
+	for tfile in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{cfg_name}.json")), reverse=True):
 		try:
 			d = json.load(open(tfile))
-			if d.get("config") == args.config and d.get("Q") == Q and d.get("I") == I and d.get("Kp") == Kp:
+			if d.get("config") == cfg_name and d.get("Q") == Q and d.get("I") == I and d.get("Kp") == Kp:
 				traffic, traffic_src = d.get("score_kernel_sweep_hbm_bytes_per_launch"), os.path.basename(tfile)
 				break
 		except Exception:
@@ -566,7 +512,7 @@ def main():
 			"value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
 			"ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": "bf16", "data": "synthetic",
-			"config": {"workload": f"{args.config}: Q={Q}/GPU x I={I} bf16 score matrix, {cfg['Ki']} anchor items, {cfg['Kq']} anchor queries, "
+			"config": {"workload": f"{cfg_name}: Q={Q}/GPU x I={I} bf16 score matrix, {cfg['Ki']} anchor items, {cfg['Kq']} anchor queries, "
 								   f"k={k}, k_retvr={kr}; step = gather C_q + fused S_hat/top-k + exact top-k scan + overlap/recall",
 					   "Q_per_gpu": Q, "I": I, "anchors": cfg["Ki"], "anchor_queries": cfg["Kq"], "k": k, "k_retvr": kr,
 					   "parallelism": f"row-sharded x{world}, index replicated (one RCCL all-gather of anchor rows at build time)"},
@@ -601,11 +547,11 @@ def main():
 		}
 
 	# ------------------------------------------------------------------ side-line: the IVF-flat branch at the hard-negative-mining size
-	if rank == 0 and world == 1 and not args.no_ivf:
+	if rank == 0 and world == 1 and not args.no_ivf and not light:
 		out["ivf_search"] = ivf_sideline(device, args.seed)
 
 	# ------------------------------------------------------------------ CPU baseline: the oracle (reference-faithful loop) on a bounded sample
-	if rank == 0 and world == 1 and args.cpu_sample_queries > 0:
+	if rank == 0 and world == 1 and args.cpu_sample_queries > 0 and not light:
 		from oracle import cur_oracle as O
 		# bounded sample (~10-30 s of CPU work): the oracle's per-query cost grows with I, so the sample shrinks with it (cfg2: 4096
 		# queries, the per-GPU shape of cfg4 with I = 10^6: 409); a fixed 4096 at I = 10^6 ran for minutes without a line of output
@@ -646,6 +592,83 @@ def main():
 							   "recall_cpu_fp32_tie_stable": {f"recall@{t}": want_stable[t][key] for t in top_k_vals},
 							   "recall_gpu_same_queries": {f"recall@{t}": got[t][key] for t in top_k_vals}}
 		out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+	return out
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=None, help="default: WORLD_SIZE under torchrun, else 1")
+	ap.add_argument("--steps", type=int, default=30)
+	ap.add_argument("--warmup", type=int, default=5)
+	ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default: cfg2 (the headline workload) at every N, plus -- at N > 1 -- cfg4_per_gpu as the \"cfg4\" sub-object; given: that workload alone")
+	ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the multi-rank path with ranks sharing GPUs")
+	ap.add_argument("--share-gpu", action="store_true", help="rehearsal: rank r uses GPU r %% device_count (RCCL cannot; use --backend gloo)")
+	ap.add_argument("--no-k500", action="store_true", help="skip the retrieve_only_k500 side-line (profiling runs: its launches share the sweep kernel's name)")
+	ap.add_argument("--sustained-seconds", type=float, default=10.0, help="also loop the same step for this long and report it (DVFS-settled rate); 0 = skip")
+	ap.add_argument("--cpu-sample-queries", type=int, default=4096, help="queries timed through the CPU oracle (0 = skip)")
+	ap.add_argument("--cpu-threads", type=int, default=8, help="torch CPU threads for the baseline (the per-query loop gets SLOWER with more)")
+	ap.add_argument("--no-ivf", action="store_true", help="skip the ivf_search side-line (the IVF-flat branch of build_flat_or_ivff_index at the hard-negative-mining size)")
+	ap.add_argument("--seed", type=int, default=0)
+	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
+	ap.add_argument("--scan-cus", type=int, default=96, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD)")
+	ap.add_argument("--scan-mode", default=None, choices=["side", "partition", "tail", "chunks", "serial"],
+					help="how the exact scan is scheduled against the retrieval: partition = on a stream whose CU mask leaves it --scan-cus CUs, beside the "
+						 "retrieval on all of them (default where the retrieval's sweep draws its tiles dynamically: Kp <= 256); side = on a second stream "
+						 "from the start of the step, joined before the overlap count (default otherwise); chunks = anncur_eval_topk (row chunks forked "
+						 "beside the retrieval's latency-bound launches); serial = one stream")
+	ap.add_argument("--retr-streams", type=int, default=2, choices=[1, 2], help="--scan-mode partition: retrieval chains of consecutive steps on one stream or on two (a workspace each)")
+	ap.add_argument("--fold-gather", action="store_true", help="--scan-mode partition: C_q out of the scan's own pass over A (anncur_rowwise_topk_gather) instead of "
+					"the gather kernel -- built for SURVEY a2's 'fold into the first pass', measured slower (see the comment at its use): off by default")
+	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
+	args = ap.parse_args()
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if args.gpus is None:
+		args.gpus = world if os.environ.get("RANK") is not None else 1
+	if args.gpus > 1 and os.environ.get("RANK") is None:
+		self_launch(args)
+	if args.gpus != world:   # before any process group exists: nothing to tear down, no rank left waiting in a collective
+		raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+	# stdout carries exactly ONE line (the result JSON): libraries that print banners to fd 1 (RCCL at communicator creation
+	# does) are sent to stderr for the whole run, the JSON goes to the saved descriptor at the end
+	sys.stdout.flush()
+	result_fd = os.dup(1)
+	os.dup2(2, 1)
+
+	rank = int(os.environ.get("RANK", "0"))
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	if not torch.cuda.is_available():
+		raise SystemExit("bench.py needs an MI355X: anncur_amd has no CPU path")
+	torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
+	if args.share_gpu:
+		local_rank %= torch.cuda.device_count()
+	torch.cuda.set_device(local_rank)
+	device = torch.device("cuda", local_rank)
+	use_dist = world > 1 or (os.environ.get("RANK") is not None and os.environ.get("ANNCUR_BENCH_FORCE_DIST"))
+	if use_dist:
+		import torch.distributed as dist
+		if args.backend == "nccl":
+			dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+		else:
+			dist.init_process_group("gloo")
+	ranks_seen = torch.distributed.get_world_size() if use_dist else 1
+
+	if os.environ.get("ANNCUR_BENCH_FAIL_RANK") == str(rank):   # fault injection for tests/test_gpu_bench_multirank.py
+		raise RuntimeError(f"[bench] injected failure on rank {rank} (ANNCUR_BENCH_FAIL_RANK)")
+
+	ctx = dict(rank=rank, world=world, device=device, use_dist=use_dist, ranks_seen=ranks_seen)
+	# ONE workload per JSON key at every N: the top-level value / config is the headline workload (cfg2: 10 000 queries x 100 000 items per
+	# rank, anchor rows assembled by the one all-gather) whatever N is -- value(N) / value(1) is then a weak-scaling curve of one workload,
+	# and the N = 1 point is the single-GPU bench line.  BASELINE cfg4's per-GPU shape (6 250 x 10^6, 512 anchors) rides along at N > 1 as
+	# the "cfg4" sub-object with its own value, roofline, allgather_ms and solo_rank0.  (--config X: that workload alone, at any N.)
+	out = run_config(args, args.config or "cfg2", ctx)
+	if world > 1 and args.config is None:
+		import gc
+		gc.collect(); torch.cuda.empty_cache()
+		sub = run_config(args, "cfg4_per_gpu", ctx, light=True)
+		if rank == 0:
+			out["cfg4"] = {kk: sub.get(kk) for kk in ("value", "unit", "ms_per_step", "n_gpus", "steps", "warmup", "scaling", "config", "recall", "roofline", "roofline_scan",
+														"stage_ms", "sweep_stages", "allgather_ms", "solo_rank0", "scan_mode", "launch_mode", "index_build_s")}
+			out["cfg4"]["what"] = "BASELINE configs[3] (50k x 1M bf16, 512 anchors, 8 GPUs) at its per-GPU shape on every rank, same job, same ranks; weak scaling like the top level"
 	if rank == 0:
 		sys.stdout.flush()
 		os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -40,6 +40,45 @@ def test_bench_two_ranks_self_launch_prints_one_json_line():
 	assert "cpu_baseline" not in out                 # the CPU leg runs at N = 1 only
 
 
+_N1_DEFAULT = {}
+
+
+def _n1_default_line(mode=None):
+	"""The N = 1 line with the driver's default config (cached: two tests read it)."""
+	if mode not in _N1_DEFAULT:
+		short = ["--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--cpu-sample-queries", "0", "--no-k500", "--no-ivf"]
+		p = _run(args=short + (["--scan-mode", mode] if mode else []))
+		assert p.returncode == 0, p.stderr[-3000:]
+		assert "Memory access fault" not in p.stderr
+		lines = [l for l in p.stdout.splitlines() if l.strip()]
+		assert len(lines) == 1, p.stdout[-2000:]
+		_N1_DEFAULT[mode] = json.loads(lines[0])
+	return _N1_DEFAULT[mode]
+
+
+def test_bench_default_config_is_one_workload_at_every_n():
+	"""What the driver runs: plain `bench.py --gpus N` for N = 1, 2, 4, 8.  The top-level value / config must name the SAME workload at
+	every N (the headline cfg2 shape per rank), so that value(N) / value(1) is a scaling curve; BASELINE cfg4's per-GPU shape rides along
+	at N > 1 as the "cfg4" sub-object with its own value, roofline, allgather_ms and solo_rank0."""
+	one = _n1_default_line()
+	p = _run(args=["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1", "--sustained-seconds", "0", "--no-k500", "--no-ivf"], timeout=1200)
+	assert p.returncode == 0, p.stderr[-3000:]
+	lines = [l for l in p.stdout.splitlines() if l.strip()]
+	assert len(lines) == 1, p.stdout[-2000:]
+	two = json.loads(lines[0])
+	assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and one["n_gpus"] == 1
+	assert two["config"]["workload"] == one["config"]["workload"] and two["config"]["workload"].startswith("cfg2:")
+	assert two["metric"] == one["metric"] and two["unit"] == one["unit"] and two["config"]["Q_per_gpu"] == one["config"]["Q_per_gpu"] == 10000
+	assert two["value"] == pytest.approx(2 * 10000 * 2 / (two["ms_per_step"] * 2e-3), rel=1e-6)
+	assert two["allgather_ms"] > 0 and two["solo_rank0"]["value"] > 0 and two["recall"]["recall@1"] >= 0.999
+	assert "cfg4" not in one
+	c4 = two["cfg4"]
+	assert c4["config"]["workload"].startswith("cfg4_per_gpu:") and c4["config"]["Q_per_gpu"] == 6250 and c4["config"]["I"] == 1000000
+	assert c4["n_gpus"] == 2 and c4["value"] == pytest.approx(2 * 6250 * 2 / (c4["ms_per_step"] * 2e-3), rel=1e-6)
+	assert c4["allgather_ms"] > 0 and c4["solo_rank0"]["value"] > 0 and c4["roofline"]["bound"] == "mfma" and c4["roofline"]["achieved"] > 0
+	assert 0.5 < c4["recall"]["recall@100"] <= 1.0
+
+
 def test_bench_fails_loudly_when_a_rank_raises():
 	p = _run({"ANNCUR_BENCH_FAIL_RANK": "1"})
 	assert p.returncode != 0
@@ -57,15 +96,7 @@ def test_bench_rejects_a_world_size_mismatch_before_any_collective():
 def test_bench_single_gpu_default_line_and_scan_placements():
 	"""The N = 1 line of the driver: default flags except a short run.  The exact scan's placement is the CU partition (masked stream +
 	three graphs per step) at cfg2's Kp = 256; the same steps with the second-stream placement must report the same recall."""
-	short = ["--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--cpu-sample-queries", "0", "--no-k500", "--no-ivf"]
-	outs = {}
-	for mode in (None, "side"):
-		p = _run(args=short + (["--scan-mode", mode] if mode else []))
-		assert p.returncode == 0, p.stderr[-3000:]
-		assert "Memory access fault" not in p.stderr
-		lines = [l for l in p.stdout.splitlines() if l.strip()]
-		assert len(lines) == 1, p.stdout[-2000:]
-		outs[mode] = json.loads(lines[0])
+	outs = {mode: _n1_default_line(mode) for mode in (None, "side")}
 	d = outs[None]
 	assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "queries/s" and d["vs_baseline"] is None and d["dtype"] == "bf16"
 	assert d["scan_mode"]["used"] == "partition" and d["scan_mode"]["scan_cus"] == 96 and outs["side"]["scan_mode"]["used"] == "side"

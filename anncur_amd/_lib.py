@@ -63,6 +63,7 @@ SIGNATURES = {
 	"anncur_copy_bytes": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
 	"anncur_ivf_build_lists": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
 	"anncur_ivf_list_means": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+	"anncur_renorm_rows": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p]),
 	"anncur_ivf_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_ivf_group_scores": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
 	"anncur_ivf_map_ids": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

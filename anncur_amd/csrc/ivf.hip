@@ -93,6 +93,22 @@ __global__ __launch_bounds__(256) void ivf_means_kernel(const float *__restrict_
 	}
 }
 
+// rows of M rescaled to unit L2 norm in place (a zero row stays): FAISS' fvec_renorm_L2, the "spherical" k-means step that IndexIVF switches
+// on for METRIC_INNER_PRODUCT (cp.spherical = true).  One workgroup per row.
+__global__ __launch_bounds__(256) void renorm_rows_kernel(float *__restrict__ M, int64_t n_cols, int64_t ld) {
+	float *row = M + (int64_t)blockIdx.x * ld;
+	float s = 0.f;
+	for (int64_t c = threadIdx.x; c < n_cols; c += 256) { const float v = row[c]; s = fmaf(v, v, s); }
+	for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+	__shared__ float part[4];
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+	__syncthreads();
+	const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+	if (!(tot > 0.f)) return;
+	const float inv = 1.0f / sqrtf(tot);
+	for (int64_t c = threadIdx.x; c < n_cols; c += 256) row[c] *= inv;
+}
+
 // One workgroup per query: exact inner products with every vector of its nprobe lists, streamed through the workgroup-level
 // selector.  Vectors are stored in list order with a row pitch that is a multiple of 16 floats (zero padded), the query likewise:
 // four lanes share one vector (each reads 16 bytes per step: 16 vectors x 64 contiguous bytes per wave-instruction).
@@ -253,6 +269,15 @@ extern "C" int anncur_ivf_list_means(const float *Xs, int64_t ldx, int32_t d, co
 	ANNCUR_REQUIRE(nlist >= 1 && d >= 1 && ldx >= d && ldc >= d, ANNCUR_E_INVALID, "ivf_list_means: bad sizes");
 	ANNCUR_REQUIRE(Xs && offsets && centroids, ANNCUR_E_INVALID, "ivf_list_means: null pointer");
 	hipLaunchKernelGGL(ivf_means_kernel, dim3((unsigned)nlist), dim3(256), 0, (hipStream_t)stream, Xs, ldx, d, offsets, centroids, ldc);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_renorm_rows(float *M, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream) {
+	ANNCUR_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld >= n_cols && n_rows <= 0x7fffffff, ANNCUR_E_INVALID, "renorm_rows: bad shape");
+	if (n_rows == 0 || n_cols == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(M, ANNCUR_E_INVALID, "renorm_rows: null pointer");
+	hipLaunchKernelGGL(renorm_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, M, n_cols, ld);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -77,11 +77,15 @@ class IVFFlatIPIndex:
 	(inverted lists) / search (exact inner products inside the nprobe best lists).  Restated from FAISS' published algorithm and
 	defaults: IndexIVF trains its coarse quantiser through Level1Quantizer, whose ClusteringParameters carry niter = 10 (the
 	stand-alone Clustering default is 25: pass niter=25 for that), at most 256 training points per centroid, assignment through the
-	inner-product quantiser, centroid = mean of its points, an empty list re-seeded by splitting a large one.  FAISS' random draws
-	cannot be reproduced, so parity is unpinned and the index is judged on recall.  Results are deterministic for a given seed."""
+	inner-product quantiser, centroid = mean of its points RENORMALISED TO UNIT L2 NORM (IndexIVF sets cp.spherical = true for
+	METRIC_INNER_PRODUCT: fvec_renorm_L2 after every update, and after the re-seeding of empty lists -- with arg-max inner-product
+	assignment an unnormalised mean of large-norm points would keep attracting points and the lists would grow unbalanced; spherical=False
+	restores the plain means), an empty list re-seeded by splitting a large one.  FAISS' random draws cannot be reproduced, so parity is
+	unpinned and the index is judged on recall and list balance.  Results are deterministic for a given seed."""
 
-	def __init__(self, d, nlist, device=None, niter=10, seed=1234, max_points_per_centroid=256):
+	def __init__(self, d, nlist, device=None, niter=10, seed=1234, max_points_per_centroid=256, spherical=True):
 		self.d, self.nlist = int(d), int(nlist)
+		self.spherical = bool(spherical)
 		self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 		self.niter, self.seed, self.max_points_per_centroid = niter, seed, max_points_per_centroid
 		self.nprobe = 1
@@ -117,6 +121,8 @@ class IVFFlatIPIndex:
 			counts, offsets, ids = ops.ivf_build_lists(self._assign(X), self.nlist)
 			ops.ivf_list_means(ops.gather_rows(X, ids), offsets, self.centroids)
 			self._split_empty(counts.cpu().numpy(), rng)
+			if self.spherical:
+				ops.renorm_rows(self.centroids)   # (after the split, as FAISS does: the perturbed copies are renormalised too)
 		self.is_trained = True
 
 	def _split_empty(self, counts, rng, eps=1.0 / 1024):

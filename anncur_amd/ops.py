@@ -703,6 +703,16 @@ def ivf_list_means(Xs, offsets, centroids):
 
 
 @_on_device
+def renorm_rows(M):
+	"""Rows of the fp32 matrix M rescaled to unit L2 norm, in place (a zero row stays): FAISS' fvec_renorm_L2 (spherical k-means)."""
+	_dev(M)
+	if M.dtype != torch.float32 or M.dim() != 2 or (M.shape[1] > 1 and M.stride(1) != 1):
+		raise TypeError("renorm_rows takes a row-major fp32 matrix")
+	check(_lib.load().anncur_renorm_rows(_p(M), M.shape[0], M.shape[1], _ld(M), _stream()), "renorm_rows")
+	return M
+
+
+@_on_device
 def ivf_scan(Xs, offsets, ids, Q, probe, k):
 	"""Exact inner products inside the probed lists + top-k.  Xs [n x dp], Q [nq x dp] fp32 zero-padded to dp (multiple of 16)."""
 	_dev(Xs, offsets, ids, Q, probe)

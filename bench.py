@@ -504,6 +504,26 @@ def run_config(args, cfg_name, ctx, light=False):
 		except Exception:
 			pass
 
+	# the same kernel's duration in the last COMMITTED rocprofv3 summary of this config (profiles/rNN_kernel_stats_<config>.csv, written by
+	# scripts/profile_round.sh): one number per kernel and source on the line -- the un-profiled HIP events above and the profiler's average
+	# (which runs a few per cent longer: the profiled chip holds a lower clock, MI355X_MICROARCH.md 'DVFS give-back' (2))
+	rocprof_ms = rocprof_src = rocprof_stages = None
+	for sfile in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_kernel_stats_{cfg_name}.csv")), reverse=True):
+		try:
+			import csv
+			tot_ns = calls = 0
+			for r_ in csv.DictReader(open(sfile)):
+				if any(nm in r_["Name"] for nm in (f"score16_kernel<{Kp}>", f"scoreq16_kernel<{Kp}>", f"scoreq1_kernel<{Kp}>", f"score_kernel<{Kp}, 1, ")):
+					tot_ns += float(r_["TotalDurationNs"]); calls += int(r_["Calls"])
+			if calls:
+				rocprof_ms, rocprof_src = tot_ns / calls / 1e6, os.path.basename(sfile)
+				pj = sfile.replace("_kernel_stats_", "_pmc_summary_").replace(".csv", ".json")
+				if os.path.exists(pj):
+					rocprof_stages = json.load(open(pj)).get("sweep_stages_rocprof")
+				break
+		except Exception:
+			pass
+
 	out = None
 	if rank == 0:
 		recall = {f"recall@{t}": res[t]["exact_vs_reranked_approx_retvr~common_frac_mean"] for t in top_k_vals}
@@ -520,7 +540,10 @@ def run_config(args, cfg_name, ctx, light=False):
 			"roofline": {"bound": "mfma", "kernel": "sweep stages (fused S_hat GEMM + threshold filter): " + " + ".join(
 							 ({2: f"score16_kernel<{Kp}>", 3: f"scoreq1_kernel<{Kp}>", 4: f"scoreq16_kernel<{Kp}>"}.get(b, f"score_kernel<{Kp},sweep>")) for b in plan_now["stage_pred"]),
 						 "achieved": sweep_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": sweep_tflops / PEAK_BF16_TFLOPS,
-						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(sweep_ms), "launches_per_step": n_sweep},
+						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(sweep_ms), "launches_per_step": n_sweep,
+						 "frac_rocprof": (sweep_flops / (rocprof_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if rocprof_ms else None), "avg_launch_ms_rocprof": rocprof_ms,
+						 "rocprof_source": rocprof_src, "stages_rocprof": rocprof_stages,
+						 "what": "achieved / frac / avg_launch_ms: HIP events around every sweep launch of this (un-profiled) run; *_rocprof: the same kernel in the last committed rocprofv3 summary under profiles/"},
 			"roofline_scan": {"bound": "hbm", "kernel": "rowwise_topk_wave_kernel<bf16> (exact top-k scan, one wave per row)",
 							  "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
 							  "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},

@@ -251,11 +251,15 @@ int anncur_overlap_counts(const int32_t *a, int32_t la, const int32_t *b, int32_
  *    ids int32[n] (points of list l at ids[offsets[l] .. offsets[l+1]) in ascending id order; deterministic, no atomics);
  *  anncur_ivf_list_means: centroids[l] = mean of rows offsets[l]..offsets[l+1] of Xs (vectors stored in list order), summed in
  *    list order; an empty list keeps its centroid (k-means update step);
+ *  anncur_renorm_rows: every row of the fp32 matrix M rescaled to unit L2 norm in place (a zero row stays) -- FAISS' fvec_renorm_L2:
+ *    IndexIVF trains its coarse quantiser with cp.spherical = true for METRIC_INNER_PRODUCT, i.e. the centroids are renormalised after
+ *    every k-means update (faiss/IndexIVF.cpp Level1Quantizer::train_q1; the reference reaches it through models/nearest_nbr.py:46-49);
  *  anncur_ivf_scan: per query, exact inner products with every vector of its nprobe lists (probe int32[nq x nprobe], -1 = skip)
  *    and the k best: out_val float[nq x k] descending, out_idx int32[nq x k] (ids of the points; (-inf, -1) where the probed lists
  *    hold fewer than k vectors).  Xs / Q rows zero-padded to dp floats, dp a multiple of 16, 16-byte aligned. */
 int anncur_ivf_build_lists(const int32_t *assign, int64_t n, int32_t nlist, int32_t *counts, int32_t *offsets, int32_t *ids, void *stream);
 int anncur_ivf_list_means(const float *Xs, int64_t ldx, int32_t d, const int32_t *offsets, int32_t nlist, float *centroids, int64_t ldc, void *stream);
+int anncur_renorm_rows(float *M, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream);
 int anncur_ivf_scan(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, const float *Q, int64_t ldq, int64_t nq,
                     const int32_t *probe, int32_t nprobe, int32_t k, float *out_val, int32_t *out_idx, void *stream);
 

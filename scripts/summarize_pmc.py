@@ -63,7 +63,55 @@ for n in sweep_variants:
 		row["valu_insts_per_mfma"] = round(c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 1) / 32, 1), 2)
 		row["salu_insts_per_mfma"] = round(c.get("SQ_INSTS_SALU", 0) / max(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 1) / 32, 1), 2)
 	per_variant[n] = row
-res = {"config": cfg, **shape, "pmc_avg_per_launch": out, "kernel_stats": stats, "sweep_per_variant": per_variant}
+# ---- the sweep STAGE BY STAGE.  Both stages are launches of one kernel with one grid, so the stats CSV averages a short first stage with
+# a long second one; the kernel trace has every dispatch: the i-th sweep dispatch (in start order) is stage i mod n_stages (n_stages from
+# the bench line of the same run: every fused call of that run has the same plan; run with --no-k500).
+def _bench_line(path):
+	try:
+		for l in reversed(open(path).read().strip().splitlines()):
+			if l.startswith("{"): return json.loads(l)
+	except Exception:
+		pass
+	return None
+def _is_sweep(name): return any(v in name for v in sweep_variants)
+def stage_split():
+	b = _bench_line(root + "/bench_stats.json")
+	if not b or "fused_plan" not in b: return None
+	plan = b["fused_plan"]; ns = plan["n_stages"]; ends = plan["stage_end"]; tiles = [e - s0 for s0, e in zip([0] + ends[:-1], ends)]
+	tile_items = 256 if kp > 512 else 32
+	rows = []
+	for f in glob.glob(root + "/stats/*kernel_trace.csv"):
+		for r in csv.DictReader(open(f)):
+			if _is_sweep(r["Kernel_Name"]): rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+	if not rows or len(rows) % ns: return None
+	rows.sort()
+	per = [[d for i, (_, d) in enumerate(rows) if i % ns == g] for g in range(ns)]
+	stages = []
+	for g in range(ns):
+		avg_ns = sum(per[g]) / len(per[g]); flops = 2.0 * shape["Q"] * kp * tile_items * tiles[g]
+		stages.append({"stage": g, "tiles": tiles[g], "calls": len(per[g]), "avg_us": round(avg_ns / 1e3, 2), "min_us": round(min(per[g]) / 1e3, 2),
+					   "tflops": round(flops / (avg_ns * 1e-9) / 1e12, 1), "frac_of_2500": round(flops / (avg_ns * 1e-9) / 2.5e15, 4)})
+	# PMC rows per stage: dispatch order inside each counter pass
+	pm = collections.defaultdict(lambda: collections.defaultdict(list))
+	for f in glob.glob(root + "/pmc_*/*counter_collection.csv"):
+		disp = collections.defaultdict(dict)
+		for r in csv.DictReader(open(f)):
+			if _is_sweep(r["Kernel_Name"]): disp[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
+		ids = sorted(disp)
+		if len(ids) % ns: continue
+		for i, d in enumerate(ids):
+			for c, v in disp[d].items(): pm[i % ns][c].append(v)
+	for g in range(ns):
+		c = {k_: sum(v) / len(v) for k_, v in pm[g].items()}
+		if "GRBM_GUI_ACTIVE" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+			cyc = c["GRBM_GUI_ACTIVE"] / 8
+			stages[g]["mfma_pipe_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc, 3)
+			stages[g]["valu_insts_per_mfma"] = round(c.get("SQ_INSTS_VALU", 0) / max(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 32, 1), 2)
+		if "SQ_WAVE_CYCLES" in c: stages[g]["wait_any_share_of_wave_cycles"] = round(c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)
+		if "FETCH_SIZE" in c: stages[g]["read_bytes"] = round(2 * c["FETCH_SIZE"] * 1024)
+		if "WRITE_SIZE" in c: stages[g]["write_bytes"] = round(c["WRITE_SIZE"] * 1024)
+	return stages
+res = {"config": cfg, **shape, "pmc_avg_per_launch": out, "kernel_stats": stats, "sweep_per_variant": per_variant, "sweep_stages_rocprof": stage_split()}
 sw = out.get(sweep)
 if sw and "FETCH_SIZE" in sw and "WRITE_SIZE" in sw:
 	rd, wr = 2 * sw["FETCH_SIZE"] * 1024, sw["WRITE_SIZE"] * 1024

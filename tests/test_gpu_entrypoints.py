@@ -186,6 +186,45 @@ def test_ivf_flat_index_branch(gpu):
 	assert torch.equal(again.centroids, index.centroids) and torch.equal(again._ids, index._ids)
 
 
+def test_ivf_spherical_kmeans_keeps_lists_balanced_on_varying_norms(gpu):
+	"""FAISS' IndexIVF trains its inner-product quantiser with cp.spherical = true: centroids are renormalised (fvec_renorm_L2) after
+	every update.  With arg-max inner-product assignment an unnormalised mean of large-norm points keeps attracting points: on vectors
+	whose norms vary by 10x the plain means give a few huge lists (scan cost = the probed lists' sizes) -- the spherical update (the
+	default here) must keep the lists balanced, unit-norm, and at least as good in recall at the reference's nprobe."""
+	from anncur_amd.nearest_nbr import IVFFlatIPIndex
+	from anncur_amd import ops
+	from oracle import cur_oracle as O
+	g = np.random.default_rng(3)
+	n, d, nq, k, nlist = 30000, 64, 400, 10, 173
+	dirs = g.standard_normal((48, d)).astype(np.float32)
+	X = dirs[g.integers(0, 48, n)] + 0.6 * g.standard_normal((n, d)).astype(np.float32)
+	X = (X * np.exp(g.uniform(np.log(0.3), np.log(3.0), (n, 1)))).astype(np.float32)          # norms spread over a decade
+	q = (dirs[g.integers(0, 48, nq)] + 0.6 * g.standard_normal((nq, d))).astype(np.float32)
+	rD, rI = O.flat_ip_search(X, q, k)
+	stats = {}
+	for sph in (True, False):
+		index = IVFFlatIPIndex(d, nlist, spherical=sph)
+		index.train(X); index.add(X)
+		index.nprobe = int(np.floor(np.sqrt(nlist)))
+		sizes = np.diff(index._offsets.cpu().numpy())
+		D, I = index.search(q, k)
+		recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(I.tolist(), rI.tolist())])
+		probe = np.argsort(-(q @ index.centroids.cpu().numpy().T), axis=1)[:, :index.nprobe]
+		stats[sph] = dict(max=int(sizes.max()), imbalance=float((sizes.astype(np.float64) ** 2).sum() * nlist / n ** 2), recall=float(recall),
+						  scanned=float(sizes[probe].sum(axis=1).mean()), norms=index.centroids.norm(dim=1).cpu().numpy())
+	sp, pl = stats[True], stats[False]
+	np.testing.assert_allclose(sp["norms"], 1.0, rtol=1e-5)                 # unit-norm centroids
+	assert sp["imbalance"] < pl["imbalance"] and sp["max"] < pl["max"], (sp, pl)   # FAISS' imbalance factor: sum n_l^2 * nlist / n^2 (1 = uniform)
+	assert sp["imbalance"] < 3.0, sp
+	assert sp["recall"] >= pl["recall"] - 0.02 and sp["recall"] > 0.8, (sp, pl)
+	# the op itself: rows to unit norm in place, a zero row stays zero
+	M = torch.tensor(g.standard_normal((5, 37)).astype(np.float32), device=gpu); M[2] = 0
+	ref = M / M.norm(dim=1, keepdim=True).clamp_min(1e-30)
+	ops.renorm_rows(M)
+	torch.testing.assert_close(M[[0, 1, 3, 4]], ref[[0, 1, 3, 4]], rtol=1e-6, atol=1e-7)
+	assert float(M[2].abs().max()) == 0.0
+
+
 def test_ivf_batched_search_equals_the_per_query_scan(gpu):
 	"""Many queries (the reference's hard-negative mining, utils/data_process.py:343-365): pairs (query, probed list) grouped by list,
 	each list one fp32-MFMA GEMM (anncur_ivf_group_scores), exact scan over the lists side by side, column -> id map.  Same probed

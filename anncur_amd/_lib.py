@@ -17,6 +17,7 @@ TOPK_LEADING_SAMPLE = 1
 TOPK_MFMA16 = 2
 TOPK_QT1 = 4
 TOPK_MFMA32 = 8
+TOPK_RING = 16
 MAX_TOPK = 2048
 
 _p32 = POINTER(c_int32)

@@ -50,33 +50,28 @@ struct WaveQueue {
 	int lane;
 };
 
-// Drain: entry i of the queue -> lane i & 63 of pass i >> 6, TWO passes per iteration: both entries read back to back (one wait), both
-// slots drawn from the per-query counters back to back (one wait), then the two stores.  (Round 3 drained pass by pass: read, wait, draw,
-// wait, store -- two exposed LDS round trips per 64 entries, ~250 cycles; the phase stamps put the drain at 198 cycles per first-stage tile
-// and, because the four waves of a workgroup drained in DIFFERENT tiles, the per-tile barrier at 633: see 'Scheduled drain' in the kernel.)
-// A lane past the end re-reads the last entry and adds 0 to its counter.  Segment address = uniform base + 32-bit byte offset.
+// Drain: entry i of the queue -> lane i & 63 of pass i >> 6.  Segment address = uniform base + 32-bit byte offset (round 4; round 3 built a
+// 64-bit address per entry with two v_mad_u64_u32).  (Round 4 also tried two passes per iteration -- both entries read back to back, both
+// counter draws back to back: one LDS round trip less per 128 entries, seven more live registers where the drain is inlined into the tile
+// function, which the 256-register ring kernel does not have; no measurable gain in the 4-wave kernel either.)
 __device__ __forceinline__ void wq_drain(const WaveQueue &w, uint32_t &fill) {
 	const uint32_t n = (fill - w.base) >> 3;  // (uniform)
 	unsigned char *const segb = reinterpret_cast<unsigned char *>(w.seg);
 #pragma nounroll
-	for (uint32_t i0 = 0; i0 < n; i0 += 128) {
-		const uint32_t iA = i0 + (uint32_t)w.lane, iB = iA + 64u;
-		const bool inA = iA < n, inB = iB < n;
-		unsigned long long dA = 0, dB = 0;
+	for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+		const uint32_t i = i0 + (uint32_t)w.lane;
+		if (i < n) {
+			const uint2 e = lds_load_u64(w.base + i * 8u);
+			const uint32_t item = e.y & WQ_ITEM_MASK, ql = e.y >> WQ_ITEM_BITS;
+			if (item < w.n_items) {  // (the matrix' last tile may be partial)
+				uint32_t pos = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-		asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-					 : "=&v"(dA), "=&v"(dB) : "v"(w.base + (inA ? iA : n - 1u) * 8u), "v"(w.base + (inB ? iB : n - 1u) * 8u) : "memory");
+				const uint32_t one = 1u;
+				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(w.cnt + ql * 4u), "v"(one) : "memory");
 #endif
-		const uint32_t hiA = (uint32_t)(dA >> 32), hiB = (uint32_t)(dB >> 32);
-		const uint32_t itemA = hiA & WQ_ITEM_MASK, qlA = hiA >> WQ_ITEM_BITS, itemB = hiB & WQ_ITEM_MASK, qlB = hiB >> WQ_ITEM_BITS;
-		const bool okA = inA && itemA < w.n_items, okB = inB && itemB < w.n_items;  // (the matrix' last tile may be partial)
-		uint32_t posA = 0, posB = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-		asm volatile("ds_add_rtn_u32 %0, %2, %4\n\tds_add_rtn_u32 %1, %3, %5\n\ts_waitcnt lgkmcnt(0)"
-					 : "=&v"(posA), "=&v"(posB) : "v"(w.cnt + qlA * 4u), "v"(w.cnt + qlB * 4u), "v"(okA ? 1u : 0u), "v"(okB ? 1u : 0u) : "memory");
-#endif
-		if (okA && posA < w.capg) *reinterpret_cast<uint2 *>(segb + (qlA * w.q_stride8 + posA * 8u)) = make_uint2((uint32_t)dA, itemA);
-		if (okB && posB < w.capg) *reinterpret_cast<uint2 *>(segb + (qlB * w.q_stride8 + posB * 8u)) = make_uint2((uint32_t)dB, itemB);
+				if (pos < w.capg) *reinterpret_cast<uint2 *>(segb + (ql * w.q_stride8 + pos * 8u)) = make_uint2(e.x, item);
+			}
+		}
 	}
 	fill = w.base;
 }

@@ -109,6 +109,8 @@ struct FusedParams {
 	int chunk_tiles, n_chunks;
 	uint32_t *chunk_ctr;              // [n row blocks], zero at launch
 	uint8_t *chunk_owner;             // [n row blocks x n_chunks]: which item split swept the chunk (the repair path's map)
+	uint32_t *nfb;                    // the call's fallback counter (workspace word 0): the ring kernel reports a spin timeout there
+	int ring_stagger, ring_spin_sleep; // ring kernel: start delay of waves 4..7 in units of 64 cycles; s_sleep between two polls of a waiting wave
 };
 
 // Contiguous work ids per XCD (blocks b and b+8 share an XCD's L2): speed only, never correctness.
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 }
 
 #include "score16.hpp"
+#include "score16r.hpp"
 #include "score_q1.hpp"
 #include "score_q16.hpp"
 
@@ -1522,6 +1525,8 @@ struct FusedPlan {
 	int leading;
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
 	bool body16;  // the sweep stages run score16_kernel
+	bool ring16;  // ... score16r_kernel: 8-wave workgroups of BQ_s = 512 queries, flag-synchronised tile ring (score16r.hpp)
+	int BQ_s, n_rb_s;   // query rows per sweep workgroup and the sweep's row blocks (the prepass keeps BQ / n_rb)
 	bool bodyq1;  // the sweep stages run scoreq1_kernel (Kp = 512)
 	bool bodyq16; // ... scoreq16_kernel: the same body on 16x16x32 MFMAs
 	int chunk;  // dynamic tile schedule of the sweep stages: tiles per ticket (0: static shares)
@@ -1604,13 +1609,11 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		// 0.84 vs 0.88; I = 10^6, Kp = 256 (P ~ 0.2 over most of the sweep) 2.80 vs 2.76 -> exec above P = 0.25.
 		// (staggered Kp <= 256 loop only: launch_fused ignores it elsewhere)
 		P.stage_pred[i] = (1.0 - exp(-4.0 * rate)) > 0.25 ? 1 : 0;
-		// wave-queue bodies: a wave collects 2 * rate survivors per query and tile, from 64 queries (16x16x32 body, Kp <= 256: 1024-entry
-		// queue) or 32 (Kp = 512: 448 entries); the period aims at ~160 / ~96 entries per scheduled drain (2-3 / 1-2 dense passes)
-		{
-			const double per_wave_tile = 2.0 * rate * (P.bodyq1 ? 32.0 : 64.0), target = P.bodyq1 ? 96.0 : 160.0;
-			const int dt = (int)(target / (per_wave_tile > 1e-9 ? per_wave_tile : 1e-9) + 0.5);
-			P.stage_drain[i] = dt < 1 ? 1 : (dt > 64 ? 64 : dt);
-		}
+		// Scheduled drain of the wave-queue bodies (score16.hpp): 0 = off.  Round 4 measured it (all four waves of a workgroup drain in the
+		// same tile, period planned for ~160 entries): cfg2 sweep launches 0.4992 ms with it, 0.4893 without, 0.4888 at a period of 24 tiles
+		// (same box, one process, interleaved) -- the per-tile barrier wait it was meant to remove is the waves' HIT imbalance, not their
+		// drains (phase stamps: barrier 546 -> 441 cycles per first-stage tile, but the drains themselves 206 -> 274: more, emptier passes).
+		P.stage_drain[i] = 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		if (const char *dbg = getenv("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = atoi(dbg) != 0;
 #endif
@@ -1620,7 +1623,7 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	}
 }
 
-FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false, bool mfma32 = false) {
+FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false, bool mfma32 = false, bool ring = false) {
 	FusedPlan P{};
 	P.ok = false;
 	P.leading = leading ? 1 : 0;
@@ -1666,7 +1669,20 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = ticketed ? atoi(dbg) : 0;
 #endif
-	int S = P.chunk > 0 ? (slots + P.n_rb - 1) / P.n_rb : slots / P.n_rb;
+	// Body of the sweep stages, decided here because the ring body changes the decomposition (512-query workgroups, one per CU)
+	const bool can16 = KP <= 256 && P.QT == 2 && I < (int64_t)(1 << 26);
+	P.body16 = can16 && !mfma32 && (mfma16 || k <= WSEL_K);
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (getenv("ANNCUR_DEBUG_MFMA16")) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
+#endif
+	P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && ring;   // opt-in (ANNCUR_TOPK_RING): measured slower than the barrier body, see score16r.hpp
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_RING16")) P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && atoi(dbg) != 0;
+#endif
+	P.BQ_s = P.ring16 ? 512 : P.BQ;
+	P.n_rb_s = (int)ceil_div64(Q, P.BQ_s);
+	const int slots_s = P.ring16 ? num_cu() : slots;   // sweep workgroups resident at once
+	int S = P.chunk > 0 ? (slots_s + P.n_rb_s - 1) / P.n_rb_s : slots_s / P.n_rb_s;
 	if (P.chunk > 0 && k <= WQ_K2 && S > WAVE / 2) S = WAVE / 2;
 	if (S < 1) S = 1;
 	if (S > 255) S = P.chunk > 0 ? 255 : (S > 256 ? 256 : S);   // (the owner map holds a split in a byte, 255 = none)
@@ -1675,7 +1691,6 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	// tiles' elements pass the first threshold: the rings' raw-tile hand-over is built for that).  ANNCUR_TOPK_MFMA16 / _MFMA32 force one.
 	// Measured at cfg2, MI355X, same box, alternating (round 3): sweep launches 0.457 ms (16x16x32) vs 0.479 (32x32x16) at equal stage
 	// split, 0.450 with the split below; a mixed plan (first stage 32x32x16, later stages 16x16x32) was level with 16x16x32 throughout.
-	const bool can16 = KP <= 256 && P.QT == 2 && I < (int64_t)(1 << 26);
 	if (S > P.n_tiles) S = P.n_tiles;
 	P.tiles_per_split = (P.n_tiles + S - 1) / S;
 	P.S = (P.n_tiles + P.tiles_per_split - 1) / P.tiles_per_split;
@@ -1685,10 +1700,6 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.st_per_split = (P.n_st + S0 - 1) / S0;
 	P.S0 = (P.n_st + P.st_per_split - 1) / P.st_per_split;
 	// candidate segments per (query, item split): two (lane halves) in the 32x32x16 sweep, ONE in the 16x16x32 sweep (wave-level queue)
-	P.body16 = can16 && !mfma32 && (mfma16 || k <= WSEL_K);
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_MFMA16")) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
-#endif
 	P.lg = (P.body16 || P.bodyq1) ? 1 : 2;
 	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over lg S lane segments
 	// (segment capacity -- hence the workspace size -- is planned for the strided sample whatever the hint; with item rows ordered
@@ -1906,6 +1917,15 @@ int co_finish(CoScan *co, hipStream_t st) {
 	return co_join(co, st);
 }
 
+// A launch failed after chunks of the exact scan were forked onto the auxiliary stream: the launch stream still waits for every chunk
+// issued so far, so that no work is left running into the caller's buffers behind its back and a stream capture stays joined.  (The
+// exact result is then incomplete: outputs are undefined whenever a call returns an error.)
+void co_abort(CoScan *co, hipStream_t st) {
+	if (!co) return;
+	for (int i = 0; i < co->next; ++i)
+		if (co->row_end[i] > (i ? co->row_end[i - 1] : 0)) (void)hipStreamWaitEvent(st, co->ev[2 * i + 1], 0);
+}
+
 template <int KP, int QTV = FusedCfg<KP>::QT>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
 				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr, const int32_t *item_ids = nullptr) {
@@ -1919,6 +1939,12 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.cand = (uint2 *)(ws + P.off_cand); p.seg_cnt = (uint32_t *)(ws + P.off_segcnt); p.capg = P.capg; p.flush_tiles = P.flush_tiles;
 	p.tau_bias = 0.f;
 	p.chunk_tiles = 0; p.n_chunks = 0; p.chunk_ctr = nullptr; p.chunk_owner = nullptr;
+	p.nfb = (uint32_t *)ws;
+	p.ring_stagger = 0; p.ring_spin_sleep = 1;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_RING_STAGGER")) p.ring_stagger = atoi(dbg);
+	if (const char *dbg = getenv("ANNCUR_DEBUG_RING_SLEEP")) p.ring_spin_sleep = atoi(dbg);
+#endif
 	p.nseg = P.lg * P.S;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
@@ -1959,7 +1985,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	// as long as its FIRST split (cfg2: the first stage, 22 % of the tiles, 0.236 ms against 0.306 ms for the other 78 %).
 	// (score16_kernel keeps contiguous ranges)
 	const int tile_step = (!P.body16 && !P.bodyq1 && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
-	p.n_wg = P.n_rb * P.S;
+	p.n_wg = P.n_rb_s * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
 		EV(5 + 2 * stg);
@@ -2004,6 +2030,13 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			if (!launched && P.bodyq1) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)scoreq1_kernel<KP>, FusedQ1Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((scoreq1_kernel<KP>), dim3(p.n_wg), dim3(256), FusedQ1Cfg<KP>::LDS_BYTES, st, p);
+				launched = true;
+			}
+		}
+		if constexpr (KP >= 128 && KP <= 256 && QTV == 2) {  // 16x16x32 sweep, 8-wave workgroups with the flag-synchronised tile ring (score16r.hpp)
+			if (!launched && P.ring16) {
+				if ((rc = anncur_ensure_dyn_lds((const void *)score16r_kernel<KP>, Ring16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score16r_kernel<KP>), dim3(p.n_wg), dim3(512), Ring16Cfg<KP>::LDS_BYTES, st, p);
 				launched = true;
 			}
 		}
@@ -2058,7 +2091,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	SweepStages stages{};
 	stages.n = P.n_stages;
 	stages.stride = tile_step;
-	stages.chunk = chunk; stages.bq = P.BQ;
+	stages.chunk = chunk; stages.bq = P.BQ_s;
 	for (int g = 0, prev = 0; g < P.n_stages; prev = P.stage_end[g], ++g) {
 		stages.begin[g] = prev; stages.end[g] = P.stage_end[g]; stages.tps[g] = P.stage_tps[g];
 		stages.n_chunks[g] = chunk > 0 ? (P.stage_end[g] - prev + chunk - 1) / chunk : 0;
@@ -2216,9 +2249,9 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 
 FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, int flags = 0) {
 	const bool leading = (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, mfma16 = (flags & ANNCUR_TOPK_MFMA16) != 0, qt1 = (flags & ANNCUR_TOPK_QT1) != 0;
-	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1, (flags & ANNCUR_TOPK_MFMA32) != 0);
+	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1, (flags & ANNCUR_TOPK_MFMA32) != 0, (flags & ANNCUR_TOPK_RING) != 0);
 }
-constexpr int TOPK_FLAGS = ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1 | ANNCUR_TOPK_MFMA32;
+constexpr int TOPK_FLAGS = ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1 | ANNCUR_TOPK_MFMA32 | ANNCUR_TOPK_RING;
 
 }  // namespace
 
@@ -2226,7 +2259,7 @@ extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_
 	const FusedPlan P = plan_any(Q, I, Kp, k);
 	if (!P.ok) return 0;
 	size_t t = P.total;
-	for (int flags : {ANNCUR_TOPK_MFMA16, ANNCUR_TOPK_MFMA32, ANNCUR_TOPK_QT1}) {  // (whatever variant flag the call will carry)
+	for (int flags : {ANNCUR_TOPK_MFMA16, ANNCUR_TOPK_MFMA32, ANNCUR_TOPK_QT1, ANNCUR_TOPK_RING}) {  // (whatever variant flag the call will carry)
 		const FusedPlan V = plan_any(Q, I, Kp, k, flags);
 		if (V.ok && V.total > t) t = V.total;
 	}
@@ -2268,6 +2301,7 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
 	}
 	if (rc == ANNCUR_OK) rc = co_finish(co, st);
+	if (rc != ANNCUR_OK) co_abort(co, st);   // (never return with forked chunks unjoined)
 	return rc;
 }
 
@@ -2342,7 +2376,7 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 /* the same for the flags of anncur_score_topk_ex: out[0 .. n_out) = {sample tiles, item tiles, S, segment capacity, group, segments per
  * query and item split (2: 32x32x16 sweep, 1: 16x16x32 sweep, 4: wide kernel), 32-query sub-tiles per wave, sweep stages,
  * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32, 3 / 4: Kp = 512 with the
- * wave-level queue on 32x32x16 / 16x16x32 MFMAs), ring drain period[3]} --
+ * wave-level queue on 32x32x16 / 16x16x32 MFMAs, 5: 16x16x32 in 8-wave workgroups with the flag-synchronised tile ring), ring drain period[3]} --
  * what a test needs to see that a variant flag was honoured */
 extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
 	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
@@ -2352,7 +2386,7 @@ extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32
 	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
 	for (int g = 0; g < 3; ++g) {
 		const bool on = g < P.n_stages;
-		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.body16 ? 2 : (!wide && P.bodyq16 ? 4 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g]))) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
+		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.ring16 ? 5 : !wide && P.body16 ? 2 : (!wide && P.bodyq16 ? 4 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g]))) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
 	}
 	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
 	return ANNCUR_OK;

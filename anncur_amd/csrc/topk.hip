@@ -1,5 +1,6 @@
 // Exact row-wise top-k (HBM-streaming scan), re-rank, overlap counts, gathers, dtype conversion.
 #include <stdlib.h>
+#include <atomic>
 #include "select.hpp"
 #include "wave_select.hpp"
 
@@ -643,17 +644,25 @@ int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int
 // rows of the wave-per-row scan resident on the chip at once (what one "round" of the scan covers): anncur_eval_topk sizes its row
 // chunks in multiples of this so that a chunk does not end on a mostly empty round
 int anncur_internal_scan_rows_in_flight(int dtype) {
-	static int cached[2] = {0, 0};
+	// per (device, dtype), like the caches of misc.hip (a process may drive GPUs with different CU counts / partition modes); relaxed
+	// atomics: two threads racing on the first use both compute the same value
+	constexpr int MAX_DEV = 64;
+	static std::atomic<int> cached[MAX_DEV][2];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
 	const int di = dtype == ANNCUR_F32 ? 0 : 1;
-	if (cached[di] == 0) {
+	std::atomic<int> *slot = (dev >= 0 && dev < MAX_DEV) ? &cached[dev][di] : nullptr;
+	int v = slot ? slot->load(std::memory_order_relaxed) : 0;
+	if (v == 0) {
 		int occ = 0;
 		const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
 		const hipError_t e = di == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rowwise_topk_wave_kernel<float>, 256, lds)
 									 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rowwise_topk_wave_kernel<uint16_t>, 256, lds);
 		if (e != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 3; }
-		cached[di] = occ * 4 * anncur_num_cu();
+		v = occ * 4 * anncur_num_cu();
+		if (slot) slot->store(v, std::memory_order_relaxed);
 	}
-	return cached[di];
+	return v;
 }
 
 // =================================================================== C ABI

@@ -293,11 +293,20 @@ class CURRowIndex(object):
 
 	def eval_topk(self, X, exact_rows, k, k_retvr):
 		"""(exact top-k of exact_rows, approximate top-k_retvr of X) -- the two rankings of the reference's per-query loop
-		(crossenc.py:97-106) -- co-scheduled in one call where the fused path takes the shape (ops.eval_topk)."""
-		Q = X.shape[0]
-		if self._Etp is not None and ops.fused_supported(Q, self.m, self._Etp.shape[1], k_retvr) and k <= self.m:
-			return ops.eval_topk(exact_rows, k, ops.pack_bf16(X, self._Etp.shape[1]), self._Etp_sorted, self.m, k_retvr, leading_sample=True, item_ids=self._item_ids)
-		return ops.rowwise_topk(exact_rows, k), self.topk(X, k_retvr)
+		(crossenc.py:97-106).  The exact scan (HBM-bound) runs on a second stream beside the retrieval (MFMA-bound) and is joined before
+		the call returns; the retrieval is self.topk(), i.e. chunked over the queries above the workspace limit.  (ops.eval_topk's
+		row-chunk co-scheduling is kept as an op but lost to this placement at every size measured: DESIGN 4.1 / bench.py --scan-mode.)"""
+		dev = exact_rows.device
+		Q = exact_rows.shape[0]
+		ev = torch.empty((Q, k), dtype=torch.float32, device=dev)
+		ei = torch.empty((Q, k), dtype=torch.int32, device=dev)   # (allocated on the launch stream: no record_stream needed after the join)
+		main, side = torch.cuda.current_stream(dev), ops.aux_stream(dev)
+		side.wait_stream(main)
+		with torch.cuda.stream(side):
+			exact = ops.rowwise_topk(exact_rows, k, out=(ev, ei))
+		approx = self.topk(X, k_retvr)
+		main.wait_stream(side)
+		return exact, approx
 
 	def approx_error_rows(self, X, exact_rows):
 		if self.compute_dtype == "bf16" and self._Etp is not None and ops.approx_error_packed_ok(self._Etp.shape[1], exact_rows):

@@ -331,12 +331,15 @@ def rowwise_topk_gather(A, k, tables, out=None, cq_out=None):
 	n_idx = tables.col_idx.numel()
 	if out is not None:
 		val, idx = out
+		if (tuple(val.shape) != (Q, k) or tuple(idx.shape) != (Q, k) or val.dtype != torch.float32 or idx.dtype != torch.int32
+				or not val.is_contiguous() or not idx.is_contiguous() or val.device != A.device or idx.device != A.device):
+			raise ValueError("rowwise_topk_gather: out must be contiguous (float32 [Q, k], int32 [Q, k]) on A's device")
 	else:
 		val = torch.empty((Q, k), dtype=torch.float32, device=A.device)
 		idx = torch.empty((Q, k), dtype=torch.int32, device=A.device)
 	cq = cq_out if cq_out is not None else torch.empty((Q, n_idx), dtype=A.dtype, device=A.device)
-	if tuple(cq.shape) != (Q, n_idx) or cq.dtype != A.dtype or cq.stride(1) != 1:
-		raise ValueError("rowwise_topk_gather: cq_out must be [Q x n_idx] of A's dtype, unit column stride")
+	if tuple(cq.shape) != (Q, n_idx) or cq.dtype != A.dtype or (n_idx > 1 and cq.stride(1) != 1) or cq.device != A.device or (Q > 1 and cq.stride(0) < n_idx):
+		raise ValueError("rowwise_topk_gather: cq_out must be [Q x n_idx] of A's dtype on A's device, unit column stride")
 	check(_lib.load().anncur_rowwise_topk_gather(_p(A), _dt(A), Q, I, _ld(A), k, _p(val), _p(idx), _p(tables.col_idx), n_idx,
 												  _p(tables.vec_tab), _p(cq), _ld(cq), _stream()), "rowwise_topk_gather")
 	return TopK(val, idx), cq
@@ -425,14 +428,14 @@ def _item_ids_arg(item_ids, I, device):
 	return item_ids
 
 
-def _topk_flags(leading_sample=False, mfma16=False, qt1=False, mfma32=False):
+def _topk_flags(leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False):
 	"""The flags word of anncur_score_topk_ex / _timed / _plan_ex."""
 	return ((_lib.TOPK_LEADING_SAMPLE if leading_sample else 0) | (_lib.TOPK_MFMA16 if mfma16 else 0) | (_lib.TOPK_QT1 if qt1 else 0)
-			| (_lib.TOPK_MFMA32 if mfma32 else 0))
+			| (_lib.TOPK_MFMA32 if mfma32 else 0) | (_lib.TOPK_RING if ring else 0))
 
 
 @_on_device
-def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False):
+def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False, ring=False):
 	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16).
 	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time).
 	leading_sample / item_ids: the index builder's hints of anncur_score_topk_ex (rows of Etp ordered by descending norm, and the
@@ -458,7 +461,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 		val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
 		idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 		for q0 in range(0, Q, qc):   # (a chunk of 512 queries is accepted whatever its workspace size)
-			part = score_topk_fused(Xp[q0:q0 + qc], Etp, I, k, leading_sample=leading_sample, item_ids=item_ids, mfma16=mfma16, qt1=qt1, mfma32=mfma32)
+			part = score_topk_fused(Xp[q0:q0 + qc], Etp, I, k, leading_sample=leading_sample, item_ids=item_ids, mfma16=mfma16, qt1=qt1, mfma32=mfma32, ring=ring)
 			val[q0:q0 + qc], idx[q0:q0 + qc] = part.values, part.indices
 		return TopK(val, idx)
 	if workspace is None:
@@ -471,7 +474,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 	ids = _item_ids_arg(item_ids, I, Xp.device)
 	check(lib.anncur_score_topk_ex(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
-								   _topk_flags(leading_sample, mfma16, qt1, mfma32), _p(ids) if ids is not None else None, _stream()), "score_topk")
+								   _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), _p(ids) if ids is not None else None, _stream()), "score_topk")
 	if return_fallbacks:
 		return TopK(val, idx), ws[:4].view(torch.int32)
 	return TopK(val, idx)
@@ -523,7 +526,7 @@ def cu_partition_streams(device, n_scan):
 
 
 @_on_device
-def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False, mfma32=False):
+def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False, mfma32=False, ring=False):
 	"""The per-query evaluation loop's two top-k's in one call (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:97-106):
 	(exact = rowwise_topk(A, k), approx = score_topk_fused(Xp, Etp, I, k_retvr)), the exact scan's row chunks co-scheduled with the
 	retrieval's latency-bound launches on a second stream (anncur_eval_topk).  serial=True: the same two results, one after the other."""
@@ -555,12 +558,12 @@ def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, i
 		aux = aux or aux_stream(A.device)
 		aux_p = ctypes.c_void_p(aux.cuda_stream)
 	check(lib.anncur_eval_topk(_p(A), _dt(A), _ld(A), k, _p(ev), _p(ei), _p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k_retvr, _p(av), _p(ai), _p(ws), nbytes,
-							   _topk_flags(leading_sample, mfma16, qt1, mfma32), _p(ids) if ids is not None else None, _stream(), aux_p), "eval_topk")
+							   _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), _p(ids) if ids is not None else None, _stream(), aux_p), "eval_topk")
 	return TopK(ev, ei), TopK(av, ai)
 
 
 @_on_device
-def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False):
+def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False, ring=False):
 	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches, sweep launch 1, 2, 3]) in
 	ms, from HIP events on the launch stream."""
 	_dev(Xp, Etp)
@@ -575,27 +578,28 @@ def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, m
 	ms = (ctypes.c_float * 9)()
 	ids = _item_ids_arg(item_ids, I, Xp.device)
 	check(lib.anncur_score_topk_timed(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
-									  _topk_flags(leading_sample, mfma16, qt1, mfma32), _p(ids) if ids is not None else None, _stream(), ms),
+									  _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), _p(ids) if ids is not None else None, _stream(), ms),
 		  "score_topk_timed")
 	return TopK(val, idx), [float(x) for x in ms]
 
 
 @_on_device
-def fused_survivors(workspace, Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False):
+def fused_survivors(workspace, Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False):
 	"""Mean number of candidates per query the sweep of the last score_topk_fused call on `workspace` kept (diagnostics; synchronises)."""
 	out = ctypes.c_double()
-	check(_lib.load().anncur_score_topk_survivors(_p(workspace), Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32), ctypes.byref(out), _stream()),
+	check(_lib.load().anncur_score_topk_survivors(_p(workspace), Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), ctypes.byref(out), _stream()),
 		  "score_topk_survivors")
 	return out.value
 
 
-def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False):
+def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False):
 	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 body (per-lane
 	rings; the default above k = 128, and for Kp = 512), 1 = the 16x16x32 body (one queue per wave; the default for Kp <= 256, k <= 128),
 	4 = the wide kernel (Kp > 512); "QT": 32-query sub-tiles per wave (1 = qt1 honoured, or Kp = 512);
-	"stage_pred": body of each sweep stage -- 0 / 1 = 32x32x16 with the ballot / exec-mask filter, 2 = 16x16x32."""
+	"stage_pred": body of each sweep stage -- 0 / 1 = 32x32x16 with the ballot / exec-mask filter, 2 = 16x16x32 (4-wave workgroups, barrier per
+	tile), 3 / 4 = Kp = 512 with the wave queue on 32x32x16 / 16x16x32, 5 = 16x16x32 in 8-wave workgroups with the tile ring (ring=True)."""
 	out = (ctypes.c_int32 * 17)()
-	check(_lib.load().anncur_score_topk_plan_ex(Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32), out, 17), "score_topk_plan_ex")
+	check(_lib.load().anncur_score_topk_plan_ex(Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), out, 17), "score_topk_plan_ex")
 	v = [int(x) for x in out]
 	plan = dict(zip(("n_sample_tiles", "n_tiles", "splits", "segment_capacity", "group", "lg", "QT", "n_stages"), v[:8]))
 	n = plan["n_stages"]

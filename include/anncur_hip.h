@@ -184,6 +184,11 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
  *    pipeline of the Kp = 512 sweep, instead of two sub-tiles staggered inside a wave at two workgroups per CU (A/B variant). */
 #define ANNCUR_TOPK_QT1 4
 #define ANNCUR_TOPK_MFMA32 8
+/*  ANNCUR_TOPK_RING (Kp = 128 / 256, k <= 128): the 16x16x32 body in 8-wave workgroups of 512 queries whose item tiles stream through a
+ *    ring of four LDS slots synchronised by per-wave landed / done counters in LDS instead of a workgroup barrier per tile (round 4,
+ *    csrc/score16r.hpp: half the L2 -> LDS traffic, half the DMA pieces per wave).  Same result bit for bit; measured slower than the
+ *    default (4-wave workgroups, two tile buffers, one barrier per tile) at every size tried -- an A/B variant, not the default. */
+#define ANNCUR_TOPK_RING 16
 int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde,
                          int64_t Q, int64_t I, int32_t Kp, int32_t k,
                          float *out_val, int32_t *out_idx,
@@ -196,7 +201,8 @@ int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde
  * of MFMA-bound sweep launches with latency-bound launches between them (threshold, refinements, select); the HBM-bound exact scan is
  * cut into row chunks (whole rounds of the scan's rows in flight) and chunk i runs on `aux_stream` beside the i-th latency-bound
  * launch -- forked and joined with events, so the call is one unit of work on `stream` (and capturable into a graph).  aux_stream
- * NULL or equal to stream: the two parts run one after the other.  Workspace as anncur_score_topk. */
+ * NULL or equal to stream: the two parts run one after the other.  Workspace as anncur_score_topk.
+ * On an error return the outputs are undefined (chunks of the scan already forked are joined back into `stream` first). */
 int anncur_eval_topk(const void *A, int a_dtype, int64_t lda, int32_t k_exact, float *exact_val, int32_t *exact_idx,
                      const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp, int32_t k_retvr,
                      float *approx_val, int32_t *approx_idx, void *workspace, size_t workspace_bytes,

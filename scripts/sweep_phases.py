@@ -17,7 +17,7 @@ Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), 256)
 Xp = ops.pack_bf16(X, 256)
 lib = _lib.load()
 lib.anncur_debug_sweep_phases.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-FLAGS = {"mfma16": True} if os.environ.get("PH_MFMA16") else {}
+FLAGS = {"mfma16": True} if os.environ.get("PH_MFMA16") else ({"ring": True} if os.environ.get("PH_RING") else {})
 plan = ops.fused_plan(Q, I, 256, k, leading_sample=True, **FLAGS)
 print("plan", plan)
 for stage in range(plan["n_stages"]):
@@ -30,8 +30,11 @@ for stage in range(plan["n_stages"]):
 	a = np.frombuffer(raw, dtype=np.uint64).astype(np.float64).reshape(8192, 8)[:, :5]
 	a = a[a.sum(1) > 0]
 	tot = a.sum(1)
-	tiles = (plan["stage_end"][stage] - ([0] + plan["stage_end"])[stage]) * (Q + 255) // 256 * 4 / len(a)   # mean tiles per wave
-	names = ["ticket+DMA issue", "ring drain", "MFMA/filter section", "vmcnt wait", "barrier"]
+	ring = plan["stage_pred"][stage] == 5   # 8-wave workgroups of 512 queries with the flag-synchronised tile ring (score16r.hpp)
+	bq = 512 if ring else 256
+	tiles = (plan["stage_end"][stage] - ([0] + plan["stage_end"])[stage]) * ((Q + bq - 1) // bq) * (bq // 64) / len(a)   # mean tiles per wave
+	names = (["sequence + FREE wait + DMA issue + landed", "queue drain", "FULL wait", "MFMA/filter section", "ticket publish + poll wait"] if ring
+			 else ["ticket+DMA issue", "ring drain", "MFMA/filter section", "vmcnt wait", "barrier"])
 	print(f"stage {stage}: launch {1e3 * ms[6 + stage]:.1f} us, {len(a)} waves, mean loop {tot.mean():.0f} cycles (p10 {np.percentile(tot, 10):.0f}, p90 {np.percentile(tot, 90):.0f}); ~{tiles:.1f} tiles per wave -> {tot.mean() / tiles:.0f} cycles per tile (MFMA alone: 1024 per wave, 2048 per SIMD)")
 	for i, nm in enumerate(names):
 		print(f"    {nm:22s} {a[:, i].mean() / tiles:8.0f} cycles per tile  ({100 * a[:, i].sum() / tot.sum():.1f} %)")

@@ -228,6 +228,42 @@ def test_pinv_auto_goes_to_the_host_call_when_ill_conditioned(CUR):
 	assert torch.equal(a.U, b.U)
 
 
+@pytest.mark.parametrize("cond,route", [(600.0, "device"), (1500.0, "host")])
+def test_pinv_auto_gate_on_a_heavy_tailed_block(CUR, cond, route):
+	"""`auto`'s cond_2 gate had only seen rank-64 + noise synthetics (cond_2 ~ 200).  A cross-encoder block's spectrum is heavy
+	tailed: here the anchor block W [400 x 160] has singular values j^-p falling to 1 / cond, with cond inside the band 5e2 .. 2e3 around the
+	gate (limit 1e3 / safety 1.25 = 800): at 600 the device route must be kept AND reproduce the numpy route's S_hat to 1e-4, at 1500 the
+	host call must be taken (U bit for bit numpy's)."""
+	g = torch.Generator().manual_seed(11)
+	kq, ki, n_items, n_test = 400, 160, 3000, 200
+	Uo = torch.linalg.qr(torch.randn(kq, ki, generator=g, dtype=torch.float64)).Q
+	Vo = torch.linalg.qr(torch.randn(ki, ki, generator=g, dtype=torch.float64)).Q
+	sv = torch.arange(1, ki + 1, dtype=torch.float64) ** (-np.log(cond) / np.log(ki))          # 1 ... 1 / cond, power law
+	W = (Uo * sv) @ Vo.t()
+	anc = sorted(np.random.default_rng(4).choice(n_items, ki, replace=False).tolist())
+	mix = torch.randn(ki, n_items, generator=g, dtype=torch.float64) / ki ** 0.5                # the other items: combinations of the anchors' columns
+	R = W @ mix + 1e-3 * torch.randn(kq, n_items, generator=g, dtype=torch.float64)
+	R[:, anc] = W
+	R = R.float()
+	assert abs(float(torch.linalg.cond(R[:, anc].double())) / cond - 1.0) < 0.02                # (fp32 rounding of W moves it by < 1 %)
+	X = (torch.randn(n_test, kq, generator=g, dtype=torch.float64) @ W / kq ** 0.5).float()     # test queries' scores against the anchor items
+	ref = CUR(rows=R, cols=R[:, anc], row_idxs=np.arange(kq), col_idxs=anc, approx_preference="rows", pinv_backend="numpy")
+	got = CUR(rows=R, cols=R[:, anc], row_idxs=np.arange(kq), col_idxs=anc, approx_preference="rows", pinv_backend="auto")
+	if route == "host":
+		assert torch.equal(got.U, ref.U)
+		return
+	assert not torch.equal(got.U, ref.U)                                                       # the device route was kept ...
+	# ... and is as good as pinned: against the fp64 pseudo-inverse of the same fp32 block both routes sit at their own round-off,
+	exact = torch.linalg.pinv(R[:, anc].double())
+	err_dev = float((got.U.double() - exact).norm() / exact.norm()); err_np = float((ref.U.double() - exact).norm() / exact.norm())
+	assert err_dev < 1e-6 and err_dev <= err_np, (err_dev, err_np)
+	# S_hat of the two routes within 1e-4 (the north star's score tolerance)
+	Sa, Sb = got.get_complete_row(X), ref.get_complete_row(X)
+	assert float((Sa - Sb).norm() / Sb.norm()) < 1e-4, float((Sa - Sb).norm() / Sb.norm())
+	ia = got.topk_in_row(X, 20).indices.numpy(); ib = ref.topk_in_row(X, 20).indices.numpy()
+	assert np.mean([len(set(a) & set(b)) / 20 for a, b in zip(ia.tolist(), ib.tolist())]) > 0.999
+
+
 def test_device_pinv_backend_gives_same_retrieval(CUR):
 	from oracle import cur_oracle as O
 	A_train, A_test = O.synth_protocol_b(400, 300, 20000, rank=64, noise=0.05, seed=5)

@@ -22,7 +22,7 @@ def cfg2():
 	(av, ai), nfb = ops.score_topk_fused(X, index._Etp, 100000, 100, return_fallbacks=True)
 	ev, ei = ops.rowwise_topk(A_test, 100)
 	torch.cuda.synchronize()
-	return dict(ops=ops, A=A_test, X=X, index=index, av=av, ai=ai, ev=ev, ei=ei, nfb=int(nfb.item()))
+	return dict(ops=ops, A=A_test, A_train=A_train, anc=anc, X=X, index=index, av=av, ai=ai, ev=ev, ei=ei, nfb=int(nfb.item()))
 
 
 def test_cfg2_fused_topk_properties(cfg2):
@@ -78,6 +78,30 @@ def test_cfg2_recall_properties(cfg2):
 	fast = eval_topk_recall(A[:512], ai[:512], [1, 10, 100], [100], literal_rerank=False)
 	assert lit == fast                                                                          # closed form == the reference's scatter + topk re-rank
 	assert 0.85 < fast[(100, 100)]["exact_vs_reranked_approx_retvr~common_frac_mean"] < 0.92
+
+
+def test_cfg2_recall_matches_oracle_on_a_slice(cfg2):
+	"""The headline config against the ORACLE, not only against its own unfused route: the oracle's recall (tie-stable statement of the
+	reference loop -- bf16 scores are tie-heavy --, fp32 CUR of the same bf16-rounded matrices) on 512 of the 10 000 queries, as
+	tests/test_gpu_cfg45.py does for cfg4.  This is bench.py's `recall_gpu_same_queries` vs `recall_cpu_fp32_tie_stable` as a test."""
+	from anncur_amd.retrieval import eval_topk_recall
+	from oracle import cur_oracle as O
+	KEY = "exact_vs_reranked_approx_retvr~common_frac_mean"
+	n, anc = 512, cfg2["anc"]
+	At = cfg2["A_train"].float().cpu()
+	Aq = cfg2["A"][:n].float().cpu()
+	ref = O.CURApproxOracle(rows=At, cols=At[:, anc], row_idxs=np.arange(At.shape[0]), col_idxs=anc, approx_preference="rows")
+	S_hat = ref.get_complete_row(Aq[:, anc])
+	want = O.eval_all_topk_stable(Aq, S_hat, [1, 10, 50, 100], 100)
+	got = eval_topk_recall(cfg2["A"][:n], cfg2["ai"][:n], [1, 10, 50, 100], [100], exact=None)
+	for k in (1, 10, 50, 100):
+		g, w = got[(k, 100)][KEY], want[k][KEY]
+		assert g == pytest.approx(w, abs=5e-3), (k, g, w)                   # bf16 item embeddings vs the fp32 oracle
+	# the index-builder's route (norm-ordered rows, leading sample, id map) returns the same lists
+	ops, index = cfg2["ops"], cfg2["index"]
+	av2, ai2 = ops.score_topk_fused(cfg2["X"][:n].contiguous(), index._Etp_sorted, 100000, 100, leading_sample=True, item_ids=index._item_ids)
+	assert torch.equal(av2, cfg2["av"][:n])
+	assert (torch.sort(ai2, 1).values == torch.sort(cfg2["ai"][:n], 1).values).float().mean() > 0.9999
 
 
 def test_cfg3_shape_matches_oracle_fp32_and_bf16():

@@ -175,6 +175,32 @@ def test_fused_score_topk_matches_dense_and_cpu(ops, Q, I, K, k):
 	assert all(s or c for s, c in zip(same, close.tolist()))
 
 
+@pytest.mark.parametrize("Q,I,K,k", [(1000, 40000, 256, 10), (777, 50001, 200, 64), (513, 30000, 128, 32), (5, 20000, 256, 7), (2049, 123457, 256, 128), (4100, 200000, 128, 100)])
+def test_fused_ring_body_equals_the_barrier_body(ops, Q, I, K, k):
+	"""ANNCUR_TOPK_RING (round 4, csrc/score16r.hpp): 8-wave workgroups of 512 queries, the item tiles through a ring of four LDS slots
+	synchronised by per-wave landed / done counters (no barrier in the tile loop), the tile sequence published by wave 0.  The tile
+	arithmetic is the barrier body's instruction for instruction: values bit for bit, index sets identical, no repaired query, no spin
+	timeout (a timeout adds 2^30 to the fallback counter).  Ragged row blocks (Q not a multiple of 512), a partial last tile, both
+	item orders, one- and two-stage plans."""
+	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
+	Kp = Xp.shape[1]
+	plan = ops.fused_plan(Q, I, Kp, k, ring=True)
+	assert all(b == 5 for b in plan["stage_pred"]) and all(b == 2 for b in ops.fused_plan(Q, I, Kp, k)["stage_pred"])
+	(v0, i0), nfb0 = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True)
+	for _ in range(3):   # (a protocol race would come and go)
+		(v, i), nfb = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, ring=True)
+		torch.cuda.synchronize()
+		assert nfb.item() == 0 and nfb0.item() == 0
+		assert torch.equal(v, v0)
+		assert torch.equal(torch.sort(i, 1).values, torch.sort(i0, 1).values)
+	# with the index builder's hints (norm-ordered rows, leading sample, id map)
+	from anncur_amd.cur import _norm_sorted_pack
+	Ets, ids = _norm_sorted_pack(E.t().contiguous().float().cuda(), Kp)
+	a = ops.score_topk_fused(Xp, Ets, I, k, leading_sample=True, item_ids=ids, ring=True)
+	b = ops.score_topk_fused(Xp, Ets, I, k, leading_sample=True, item_ids=ids)
+	assert torch.equal(a.values, b.values) and torch.equal(torch.sort(a.indices, 1).values, torch.sort(b.indices, 1).values)
+
+
 @pytest.mark.parametrize("Q,I,K,k", [(300, 40000, 64, 10), (257, 65536, 128, 100), (1000, 50007, 256, 100), (64, 70000, 256, 1), (50, 131072, 200, 500)])
 def test_fused_mfma16_sweep_gives_the_same_topk(ops, Q, I, K, k):
 	"""The 16x16x32 sweep (ANNCUR_TOPK_MFMA16, score16.hpp): other lane <-> (query, item) map, survivors through one queue per wave

@@ -109,6 +109,7 @@ struct FusedParams {
 	int chunk_tiles, n_chunks;
 	uint32_t *chunk_ctr;              // [n row blocks], zero at launch
 	uint8_t *chunk_owner;             // [n row blocks x n_chunks]: which item split swept the chunk (the repair path's map)
+	int sliced, chunks_per_slice;     // XCD-sliced tickets: chunk_ctr is [row block][N_SLICES], slice s = chunks [s * chunks_per_slice, + chunks_per_slice)
 	uint32_t *nfb;                    // the call's fallback counter (workspace word 0): the ring kernel reports a spin timeout there
 	int ring_stagger, ring_spin_sleep; // ring kernel: start delay of waves 4..7 in units of 64 cycles; s_sleep between two polls of a waiting wave
 };
@@ -942,6 +943,37 @@ __global__ __launch_bounds__(256, (QTV == 1 && KP <= 256) ? 3 : 2) void score_ke
 	}
 }
 
+// ---- XCD-sliced tickets (round 4).  Under round 3's schedule a row block's workgroups -- spread over all eight XCDs -- drew their chunks from
+// ONE counter per row block: every XCD ended up reading every tile of the stage (cfg4's per-GPU shape: 8.9 GB of L2 -> fabric traffic per
+// launch against 1.0 GB of E^T, 5.3 TB/s).  Now the stage's chunks are cut into eight contiguous slices, one per XCD, each with its own
+// counter per row block: a workgroup draws from the slice of the XCD it RUNS on (s_getreg XCC_ID -- measured, never assumed: placement is
+// speed only) and, once that slice is exhausted, steals from the following ones.  All the row blocks resident on an XCD walk the same
+// slice at about the same pace, so a tile crosses the fabric about once (plus the steals) instead of once per XCD, and the schedule
+// stays dynamic: a slow workgroup still draws fewer chunks, a fast one moves on to help its neighbours.  Any assignment is exact
+// (chunk ids stay global: the owner map and the repair path are unchanged).
+constexpr int N_SLICES = 8;
+__device__ __forceinline__ uint32_t slice_len(int n_chunks, int cps, int s) {
+	const int b = s * cps, e = min(b + cps, n_chunks);
+	return e > b ? (uint32_t)(e - b) : 0u;
+}
+// local ticket `l` drawn from slice `slice` of this row block -> global chunk id, or n_chunks when every slice is exhausted.  Steals (a
+// blocking atomic per exhausted slice, at most seven per workgroup and stage) happen here; `tried` = slices this workgroup found exhausted.
+__device__ __forceinline__ uint32_t slice_resolve(uint32_t l, uint32_t *ctr_rb, int n_chunks, int cps, int &slice, int &tried) {
+	for (;;) {
+		if (l < slice_len(n_chunks, cps, slice)) return (uint32_t)(slice * cps) + l;
+		if (++tried >= N_SLICES) return (uint32_t)n_chunks;
+		slice = (slice + 1) & (N_SLICES - 1);
+		l = atomicAdd(ctr_rb + slice, 1u);
+	}
+}
+__device__ __forceinline__ int xcc_id() {
+	uint32_t x = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+#endif
+	return (int)(x & (N_SLICES - 1));
+}
+
 #include "score16.hpp"
 #include "score16r.hpp"
 #include "score_q1.hpp"
@@ -1221,6 +1253,8 @@ __global__ __launch_bounds__(256, 2) void error_kernel(const FusedParams p, cons
 			atomicAdd(&norm_sq[qv[t]], sn[t]);
 		}
 }
+
+#include "score_evalf.hpp"
 
 // ------------------------------------------------------------------ select
 // Item-tile ranges of the sweep stages (which tiles item split s swept in stage g): [begin[g] + s*tps[g], + tps[g]) below end[g].
@@ -1525,6 +1559,7 @@ struct FusedPlan {
 	int leading;
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
 	bool body16;  // the sweep stages run score16_kernel
+	bool bodyef;  // the sweep stages run evalf_kernel (anncur_eval_fused: candidates + error sums in one pass; 32x32x16, wave queue, static shares)
 	bool ring16;  // ... score16r_kernel: 8-wave workgroups of BQ_s = 512 queries, flag-synchronised tile ring (score16r.hpp)
 	int BQ_s, n_rb_s;   // query rows per sweep workgroup and the sweep's row blocks (the prepass keeps BQ / n_rb)
 	bool bodyq1;  // the sweep stages run scoreq1_kernel (Kp = 512)
@@ -1623,7 +1658,7 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	}
 }
 
-FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false, bool mfma32 = false, bool ring = false) {
+FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false, bool mfma32 = false, bool ring = false, bool evalf = false) {
 	FusedPlan P{};
 	P.ok = false;
 	P.leading = leading ? 1 : 0;
@@ -1631,6 +1666,9 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	if (k < 1 || k > ANNCUR_MAX_TOPK || Q < 1 || I < 1 || I >= (int64_t)0x7fffffff - 64 || k > I) return P;
 	// qt1 (ANNCUR_TOPK_QT1, Kp = 128 / 256): one 32-query sub-tile per wave with the cross-tile pipeline of the Kp = 512 sweep,
 	// 3 workgroups per CU (<= 168 VGPRs) instead of two sub-tiles staggered inside a wave at 2 workgroups per CU
+	if (evalf && !(KP <= 256 && I < (int64_t)(1 << 26))) return P;   // anncur_eval_fused: Kp <= 256 (two workgroups per CU), queue entries carry the query
+	if (evalf) { qt1 = false; mfma16 = false; mfma32 = false; ring = false; leading = false; P.leading = 0; }
+	P.bodyef = evalf;
 	P.QT = (KP <= 256 && !(qt1 && KP >= 128)) ? 2 : 1;
 	P.BQ = 128 * P.QT;
 	P.n_rb = (int)ceil_div64(Q, P.BQ);
@@ -1664,16 +1702,16 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_Q16")) P.bodyq16 = P.bodyq1 && atoi(dbg) != 0;
 #endif
-	const bool ticketed = P.QT == 2 || P.bodyq1;   // the bodies with the ticket schedule
+	const bool ticketed = (P.QT == 2 || P.bodyq1) && !evalf;   // the bodies with the ticket schedule
 	P.chunk = ticketed ? CHUNK_TILES : 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = ticketed ? atoi(dbg) : 0;
 #endif
 	// Body of the sweep stages, decided here because the ring body changes the decomposition (512-query workgroups, one per CU)
 	const bool can16 = KP <= 256 && P.QT == 2 && I < (int64_t)(1 << 26);
-	P.body16 = can16 && !mfma32 && (mfma16 || k <= WSEL_K);
+	P.body16 = can16 && !mfma32 && !evalf && (mfma16 || k <= WSEL_K);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_MFMA16")) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
+	if (getenv("ANNCUR_DEBUG_MFMA16") && !evalf) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
 #endif
 	P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && ring;   // opt-in (ANNCUR_TOPK_RING): measured slower than the barrier body, see score16r.hpp
 #ifdef ANNCUR_TIMING_EXPERIMENTS
@@ -1700,7 +1738,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.st_per_split = (P.n_st + S0 - 1) / S0;
 	P.S0 = (P.n_st + P.st_per_split - 1) / P.st_per_split;
 	// candidate segments per (query, item split): two (lane halves) in the 32x32x16 sweep, ONE in the 16x16x32 sweep (wave-level queue)
-	P.lg = (P.body16 || P.bodyq1) ? 1 : 2;
+	P.lg = (P.body16 || P.bodyq1 || P.bodyef) ? 1 : 2;
 	// expected survivors per query ~ 1.3 k * (tiles / sample tiles), spread over lg S lane segments
 	// (segment capacity -- hence the workspace size -- is planned for the strided sample whatever the hint; with item rows ordered
 	//  by descending norm the leading sample's threshold lets ~40 % fewer elements through: measured on the synthetic protocol)
@@ -1721,7 +1759,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
-	P.off_ctr = off;    off = align256(off + (size_t)P.n_rb * 3 * 4);   // ticket counters [stage][row block]: zeroed with the header, one memset
+	P.off_ctr = off;    off = align256(off + (size_t)P.n_rb * 3 * 4 * N_SLICES);   // ticket counters [stage][row block][slice]: zeroed with the header, one memset
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
 	P.off_tval = off;   off = align256(off + (size_t)Q * k * 4);
 	P.off_tidx = off;   off = align256(off + (size_t)Q * k * 4);
@@ -1926,9 +1964,13 @@ void co_abort(CoScan *co, hipStream_t st) {
 		if (co->row_end[i] > (i ? co->row_end[i - 1] : 0)) (void)hipStreamWaitEvent(st, co->ev[2 * i + 1], 0);
 }
 
+// anncur_eval_fused: the exact matrix and the two per-row sums the sweep stages also produce (evalf_kernel)
+struct EvalArgs { const uint16_t *A; int64_t lda; float *err_sq, *norm_sq; };
+
 template <int KP, int QTV = FusedCfg<KP>::QT>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
-				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr, const int32_t *item_ids = nullptr) {
+				 int32_t *out_idx, unsigned char *ws, hipStream_t st, hipEvent_t *ev, CoScan *co = nullptr, const int32_t *item_ids = nullptr,
+				 const EvalArgs *ea = nullptr) {
 	using Cfg = FusedCfg<KP, QTV>;
 	FusedParams p{};
 	p.X = (const uint16_t *)X; p.ldx = ldx; p.Et = (const uint16_t *)Et; p.Q = Q; p.I = I;
@@ -1984,7 +2026,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	// the survivors crowd into the leading tiles, all the workgroups of a stage run at once, and with contiguous ranges the stage took
 	// as long as its FIRST split (cfg2: the first stage, 22 % of the tiles, 0.236 ms against 0.306 ms for the other 78 %).
 	// (score16_kernel keeps contiguous ranges)
-	const int tile_step = (!P.body16 && !P.bodyq1 && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
+	const int tile_step = (!P.body16 && !P.bodyq1 && !P.bodyef && P.S > 1 && chunk == 0 && !contiguous_splits()) ? P.S : 1;
 	p.n_wg = P.n_rb_s * P.S;
 	if ((rc = anncur_ensure_dyn_lds((const void *)score_kernel<KP, 1, 16, false, false, QTV>, Cfg::LDS_BYTES)) != ANNCUR_OK) return rc;
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
@@ -2004,7 +2046,13 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			if (const char *dbg = getenv("ANNCUR_DEBUG_RB_MAJOR")) p.rb_major = atoi(dbg);
 #endif
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
-			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb;
+			// XCD-sliced tickets: the Kp = 512 queue bodies (the shape whose sweep is close to the fabric's bandwidth); [row block][slice] counters
+			p.sliced = (P.bodyq1 || P.bodyq16) ? 1 : 0;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+			if (const char *dbg = getenv("ANNCUR_DEBUG_SLICED")) p.sliced = p.sliced && atoi(dbg) != 0;
+#endif
+			p.chunks_per_slice = (p.n_chunks + N_SLICES - 1) / N_SLICES;
+			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb * N_SLICES;
 			p.chunk_owner = (uint8_t *)(ws + P.off_owner) + (size_t)stg * owner_stride;
 		}
 		bool launched = false;
@@ -2021,6 +2069,14 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			launched = true;
 		}
 #endif
+		if constexpr (KP <= 256 && QTV == 2) {  // anncur_eval_fused: candidates + error sums in one pass (score_evalf.hpp)
+			if (!launched && P.bodyef) {
+				if (!ea) { anncur_set_error("launch_fused: evalf plan without the exact matrix"); return ANNCUR_E_INVALID; }
+				if ((rc = anncur_ensure_dyn_lds((const void *)evalf_kernel<KP>, EvalFCfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((evalf_kernel<KP>), dim3(p.n_wg), dim3(256), EvalFCfg<KP>::LDS_BYTES, st, p, ea->A, ea->lda, ea->err_sq, ea->norm_sq);
+				launched = true;
+			}
+		}
 		if constexpr (KP == 512) {  // Kp = 512 with the wave-level queue and tickets (score_q1.hpp)
 			if (!launched && P.bodyq16) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)scoreq16_kernel<KP>, FusedQ1Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
@@ -2274,9 +2330,9 @@ extern "C" int anncur_score_topk_supported(int64_t Q, int64_t I, int32_t Kp, int
 //  a row index is always < I there: it comes out of a candidate the sweep wrote or a recomputed item)
 static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
-						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr, CoScan *co = nullptr) {
+						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr, CoScan *co = nullptr, const EvalArgs *ea = nullptr) {
 	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
-	const FusedPlan P = plan_any(Q, I, Kp, k, flags);
+	const FusedPlan P = ea ? plan_fused(Q, I, Kp, k, false, false, false, false, false, true) : plan_any(Q, I, Kp, k, flags);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
 				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512} or a multiple of 128 up to %d, "
 				   "1<=k<=%d, I large enough for a sampled threshold); use anncur_gemm + anncur_rowwise_topk",
@@ -2292,11 +2348,11 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 	int rc;
 	if (co && (rc = co_plan(*co, P.n_stages + 1)) != ANNCUR_OK) return rc;   // one chunk per latency-bound launch: threshold, refinements, select
 	switch (Kp) {
-		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
+		case 64: rc = launch_fused<64>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids, ea); break;
 		case 128: rc = P.QT == 1 ? launch_fused<128, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids)
-								  : launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
+								  : launch_fused<128>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids, ea); break;
 		case 256: rc = P.QT == 1 ? launch_fused<256, 1>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids)
-								  : launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
+								  : launch_fused<256>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids, ea); break;
 		case 512: rc = launch_fused<512>(P, X, ldx, Et, Q, I, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
 		default: rc = launch_wide(P, X, ldx, Et, Q, I, Kp, k, out_val, out_idx, ws, st, ev, co, item_ids); break;
 	}
@@ -2335,6 +2391,37 @@ extern "C" int anncur_eval_topk(const void *A, int a_dtype, int64_t lda, int32_t
 	co.aux = (hipStream_t)aux_stream;
 	co.A = A; co.a_dtype = a_dtype; co.lda = lda; co.Q = Q; co.I = I; co.k = k_exact; co.val = exact_val; co.idx = exact_idx;
 	return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k_retvr, approx_val, approx_idx, workspace, workspace_bytes, stream, nullptr, flags, item_ids, &co);
+}
+
+/* a8 + a11 of one grid cell of entry point A in ONE sweep: top-k_retvr of S_hat = X . E AND err_sq[q] = sum_i (S_hat - A)^2,
+ * norm_sq[q] = sum_i A^2 (score_evalf.hpp).  Operands as anncur_score_topk (Et in ITEM order) + the exact matrix as
+ * anncur_approx_error_packed's lds route takes it (bf16, 16-byte aligned rows). */
+extern "C" size_t anncur_eval_fused_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k) {
+	const FusedPlan P = plan_fused(Q, I, Kp, k, false, false, false, false, false, true);
+	return P.ok ? P.total : 0;
+}
+
+extern "C" int anncur_eval_fused(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *A, int a_dtype, int64_t lda,
+								 int64_t Q, int64_t I, int32_t Kp, int32_t k, float *out_val, int32_t *out_idx, float *err_sq, float *norm_sq,
+								 void *workspace, size_t workspace_bytes, void *stream) {
+	ANNCUR_REQUIRE(Kp == 64 || Kp == 128 || Kp == 256, ANNCUR_E_UNSUPPORTED, "eval_fused: Kp must be 64, 128 or 256 (got %d): use anncur_score_topk + anncur_approx_error_packed", Kp);
+	ANNCUR_REQUIRE(a_dtype == ANNCUR_BF16 && A && (lda % 8) == 0 && ((uintptr_t)A % 16) == 0 && lda >= I, ANNCUR_E_UNSUPPORTED,
+				   "eval_fused: the exact matrix must be bf16 with 16-byte aligned rows (lda a multiple of 8): use anncur_score_topk + anncur_approx_error(_packed) otherwise");
+	ANNCUR_REQUIRE(err_sq && norm_sq, ANNCUR_E_INVALID, "eval_fused: null pointer");
+	ANNCUR_REQUIRE(anncur_eval_fused_workspace_bytes(Q, I, Kp, k) > 0, ANNCUR_E_UNSUPPORTED, "eval_fused: shape (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path",
+				   (long long)Q, (long long)I, Kp, k);
+	if (Q == 0) return ANNCUR_OK;
+	hipStream_t st = (hipStream_t)stream;
+	ANNCUR_HIP_OK(hipMemsetAsync(err_sq, 0, (size_t)Q * 4, st));
+	ANNCUR_HIP_OK(hipMemsetAsync(norm_sq, 0, (size_t)Q * 4, st));
+	const int64_t I_full = I / TILE_I * TILE_I;
+	if (I_full < I) {  // the last I % 32 columns' error terms: strided kernel of gemm.hip, accumulating into the same sums
+		const int rc = anncur_internal_approx_error_acc((const uint16_t *)X, ANNCUR_BF16, ldx, (const uint16_t *)Et + I_full * lde, ANNCUR_BF16, lde,
+														(const void *)((const uint16_t *)A + I_full), a_dtype, lda, Q, I - I_full, Kp, err_sq, norm_sq, stream);
+		if (rc != ANNCUR_OK) return rc;
+	}
+	const EvalArgs ea{(const uint16_t *)A, lda, err_sq, norm_sq};
+	return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, nullptr, 0, nullptr, nullptr, &ea);
 }
 
 extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
@@ -2386,7 +2473,7 @@ extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32
 	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
 	for (int g = 0; g < 3; ++g) {
 		const bool on = g < P.n_stages;
-		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.ring16 ? 5 : !wide && P.body16 ? 2 : (!wide && P.bodyq16 ? 4 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g]))) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
+		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.bodyef ? 6 : !wide && P.ring16 ? 5 : !wide && P.body16 ? 2 : (!wide && P.bodyq16 ? 4 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g]))) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
 	}
 	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
 	return ANNCUR_OK;

@@ -241,6 +241,20 @@ class CURApprox(object):
 		v, i = self.topk_in_row_device(sparse_rows, k)
 		return TopK(self._back(v, sparse_rows), self._back(i.long(), sparse_rows))
 
+	def eval_rows(self, sparse_rows, exact_rows, k):
+		"""One grid cell of entry point A for these query rows (crossenc.py:84,106,146-147): (approximate top-k of S_hat, per-row
+		sum (S_hat - A)^2, per-row sum A^2).  On the bf16 route with Kp <= 256 and a bf16 exact matrix this is ONE sweep
+		(ops.eval_fused: the kernel that streams the exact tile beside the MFMA chain also filters its accumulator for candidates);
+		otherwise the two calls topk_in_row_device + approx_error_rows."""
+		if self.approx_preference != "rows":
+			raise NotImplementedError("This is not designed to give good approx of rows as C and U matrix are multiplied together. Build index w/ approx_preference = rows instead.")
+		X, A = self._to_dev(sparse_rows), self._to_dev(exact_rows)
+		if (self.compute_dtype == "bf16" and self._Etp is not None and ops.eval_fused_ok(self._Etp.shape[1], A, X.shape[0], self.m, k)):
+			return ops.eval_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, A, self.m, k)
+		approx = self.topk_in_row_device(sparse_rows, k)
+		err, nrm = self.approx_error_rows(sparse_rows, exact_rows)
+		return approx, err, nrm
+
 	def approx_error_rows(self, sparse_rows, exact_rows):
 		"""Per-row sum (S_hat - A)^2 and sum A^2 (a11) without materialising S_hat.  On the bf16 route S_hat is the one the retrieval
 		ranks (bf16 item embeddings), computed on the sweep's MFMA loop."""
@@ -307,6 +321,27 @@ class CURRowIndex(object):
 		approx = self.topk(X, k_retvr)
 		main.wait_stream(side)
 		return exact, approx
+
+	def eval_cell(self, X, exact_rows, k, k_retvr):
+		"""Everything one grid cell of entry point A needs for these query rows (crossenc.py:97-106,146-147): (exact top-k of exact_rows,
+		approximate top-k_retvr, per-row sum (S_hat - A)^2, per-row sum A^2).  The HBM-bound exact scan runs on a second stream beside
+		ONE sweep that yields the candidates and the error sums (ops.eval_fused) where the fused route takes the cell; otherwise beside
+		the retrieval, followed by the error kernel."""
+		dev = exact_rows.device
+		Q = exact_rows.shape[0]
+		ev = torch.empty((Q, k), dtype=torch.float32, device=dev)
+		ei = torch.empty((Q, k), dtype=torch.int32, device=dev)
+		main, side = torch.cuda.current_stream(dev), ops.aux_stream(dev)
+		side.wait_stream(main)
+		with torch.cuda.stream(side):
+			exact = ops.rowwise_topk(exact_rows, k, out=(ev, ei))
+		if self.compute_dtype == "bf16" and self._Etp is not None and ops.eval_fused_ok(self._Etp.shape[1], exact_rows, Q, self.m, k_retvr):
+			approx, err, nrm = ops.eval_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, exact_rows, self.m, k_retvr)
+		else:
+			approx = self.topk(X, k_retvr)
+			err, nrm = self.approx_error_rows(X, exact_rows)
+		main.wait_stream(side)
+		return exact, approx, err, nrm
 
 	def approx_error_rows(self, X, exact_rows):
 		if self.compute_dtype == "bf16" and self._Etp is not None and ops.approx_error_packed_ok(self._Etp.shape[1], exact_rows):

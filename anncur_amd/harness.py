@@ -62,7 +62,8 @@ def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, 
 		cur = CURApprox(rows=rows, cols=cols, row_idxs=row_idxs, col_idxs=col_idxs, approx_preference="rows", A=A_dev, pinv_backend=pinv_backend)
 	else:
 		raise NotImplementedError(f"approx_method = {approx_method} not supported")
-	approx = cur.topk_in_row_device(cols, top_k_retvr)       # approximate retrieval for EVERY query row
+	# approximate retrieval for EVERY query row + the per-row error terms: one sweep where the fused route takes the cell (cur.eval_rows)
+	approx, err_sq, norm_sq = cur.eval_rows(cols, A_dev, top_k_retvr)
 	if exact_cache is not None and exact_cache.get("k", 0) >= top_k:
 		exact = exact_cache["topk"]
 	else:
@@ -70,7 +71,6 @@ def run_approx_eval_w_seed(approx_method, A_dev, n_ment_anchors, n_ent_anchors, 
 		if exact_cache is not None:
 			exact_cache.update(k=top_k, topk=exact)
 	counts = ops.overlap_counts(exact.indices, approx.indices, [(top_k, top_k_retvr)]).cpu().numpy()[0]
-	err_sq, norm_sq = cur.approx_error_rows(cols, A_dev)
 	err_sq, norm_sq = err_sq.double().cpu().numpy(), norm_sq.double().cpu().numpy()
 
 	def score(idxs):
@@ -110,9 +110,8 @@ def run_approx_eval_w_seed_sharded(sharded, n_ment_anchors, n_ent_anchors, top_k
 	R = sharded.anchor_rows(row_idxs)                                  # the one exchange: [Kq x I] on every rank
 	index = CURRowIndex(R, col_idxs)
 	X_loc = ops.gather_cols(A_loc, col_idxs)
-	exact, approx = index.eval_topk(X_loc, A_loc, top_k, top_k_retvr)   # exact scan + retrieval, co-scheduled where the fused path applies
+	exact, approx, err_sq, norm_sq = index.eval_cell(X_loc, A_loc, top_k, top_k_retvr)   # exact scan beside ONE sweep for candidates + error sums
 	counts = ops.overlap_counts(exact.indices, approx.indices, [(top_k, top_k_retvr)])[0]
-	err_sq, norm_sq = index.approx_error_rows(X_loc, A_loc)
 	packed = torch.stack([counts.float(), err_sq, norm_sq], dim=1).contiguous()      # [n_loc x 3]
 	full = gather_rows_to_rank0(packed, n_ments, sharded.group)
 	if full is None:

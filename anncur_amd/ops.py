@@ -274,6 +274,38 @@ def approx_error_packed(Xp, Etp, A_exact, n_items):
 	return err, nrm
 
 
+def eval_fused_ok(Kp, A_exact, Q, I, k):
+	"""True if anncur_eval_fused takes this cell: Kp <= 256, bf16 exact matrix with 16-byte aligned rows, shape inside the fused path."""
+	return (Kp in (64, 128, 256) and A_exact.dim() == 2 and A_exact.dtype == torch.bfloat16 and A_exact.stride(1) == 1 and _ld(A_exact) % 8 == 0
+			and _ld(A_exact) >= A_exact.shape[1] and A_exact.data_ptr() % 16 == 0 and _lib.load().anncur_eval_fused_workspace_bytes(Q, I, Kp, k) > 0)
+
+
+@_on_device
+def eval_fused(Xp, Etp, A_exact, n_items, k, return_fallbacks=False):
+	"""One sweep for a grid cell of entry point A (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:84,106,146-147):
+	(TopK of S_hat = Xp . Etp^T, err_sq [Q], norm_sq [Q]).  Xp [Q x Kp], Etp [ceil32(I) x Kp] packed bf16 in ITEM order, A_exact [Q x I] bf16."""
+	_dev(Xp, Etp, A_exact)
+	Q, Kp = Xp.shape
+	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16 or Etp.shape[1] != Kp or not Etp.is_contiguous() or Etp.shape[0] < -(-n_items // 32) * 32 \
+			or tuple(A_exact.shape) != (Q, n_items):
+		raise ValueError("eval_fused: Xp [Q x Kp], Etp [ceil32(I) x Kp] packed bf16, A_exact [Q x I]")
+	if not eval_fused_ok(Kp, A_exact, Q, n_items, k):
+		raise _lib.AnncurHipError(f"eval_fused: cell (Q={Q}, I={n_items}, Kp={Kp}, k={k}, A {A_exact.dtype}) is outside the one-pass route")
+	Xp = _rowmajor(Xp)
+	lib = _lib.load()
+	nbytes = lib.anncur_eval_fused_workspace_bytes(Q, n_items, Kp, k)
+	ws = _Workspace.get(nbytes, Xp.device)
+	val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
+	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
+	err = torch.empty(Q, dtype=torch.float32, device=Xp.device)
+	nrm = torch.empty(Q, dtype=torch.float32, device=Xp.device)
+	check(lib.anncur_eval_fused(_p(Xp), _ld(Xp), _p(Etp), Kp, _p(A_exact), _dt(A_exact), _ld(A_exact), Q, n_items, Kp, k, _p(val), _p(idx), _p(err), _p(nrm),
+								_p(ws), nbytes, _stream()), "eval_fused")
+	if return_fallbacks:
+		return TopK(val, idx), err, nrm, ws[:4].view(torch.int32)
+	return TopK(val, idx), err, nrm
+
+
 # ------------------------------------------------------------------ a7/a8
 @_on_device
 def rowwise_topk(A, k, out=None):

@@ -123,6 +123,21 @@ int anncur_approx_error_packed(const void *X, int64_t ldx, const void *Et, int64
                                int64_t Q, int64_t I, int32_t Kp,
                                float *err_sq, float *norm_sq, void *stream);
 
+/* a8 (retrieval half) + a11 of one grid cell of entry point A in ONE sweep (SURVEY 8b.6 `anncur_eval_fused`) ---------------------------
+ *   approx = CURApprox(...).get(rows, cols); approx.topk(top_k_retvr); torch.norm((approx - A)[rows]) ; torch.norm(A[rows])
+ *                                                                     eval/run_retrieval_eval_wrt_exact_crossenc.py:84,106,146-147
+ * = anncur_score_topk(X, Et, k) + anncur_approx_error_packed(X, Et, A): out_val / out_idx = the exact top-k of S_hat = X . E (values
+ * and index sets those of anncur_score_topk_ex with ANNCUR_TOPK_MFMA32: same MFMAs in the same order), err_sq[q] = sum_i (S_hat - A)^2,
+ * norm_sq[q] = sum_i A^2 -- with ONE S_hat GEMM per sweep stage instead of two: the kernel that streams the exact tile through LDS
+ * beside the MFMA chain also runs the threshold filter on the accumulator it holds (csrc/score_evalf.hpp).
+ * X [Q x Kp], Et [ceil32(I) x Kp] packed bf16 in ITEM order (a tile of Et faces the same 32 columns of A), Kp in {64,128,256};
+ * A [Q x I] bf16, 16-byte aligned, lda a multiple of 8 (ANNCUR_E_UNSUPPORTED otherwise: the two calls above).  Workspace:
+ * anncur_eval_fused_workspace_bytes (0: shape outside the fused path). */
+size_t anncur_eval_fused_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32_t k);
+int anncur_eval_fused(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *A, int a_dtype, int64_t lda,
+                      int64_t Q, int64_t I, int32_t Kp, int32_t k, float *out_val, int32_t *out_idx, float *err_sq, float *norm_sq,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* a7/a8: exact row-wise top-k of a stored matrix (HBM-streaming scan) ---------------
  *   torch.topk(S, k, dim=1)                  eval/matrix_approx_zeshel.py:106,126
  *   curr_ment_scores.topk(top_k)             ...crossenc.py:103 ; ..._splits.py:86

@@ -93,11 +93,23 @@ def test_entry_point_A_cli_with_numpy_pinv_matches_reference_goldens_to_1e4(gpu,
 		for t in ("anchor", "non_anchor", "all"):
 			for m, v in gold[gkey][t].items():
 				tol = _tight(m, 10)
-				if method == "cur_oracle" and m.startswith("approx_error"):
-					# U = C^+ A R^+ is two pseudo-inverses around a 64 x 1000 x 5000 product: its Frobenius error carries the fp32 summation
-					# order of three GEMMs (measured 1.07e-4 from the reference's value; the retrieval metrics of the cell still hold to 1e-4)
-					tol = dict(rel=3e-4)
+				if m.startswith("approx_error"):
+					# the reference's torch.norm accumulates 4.7 M squares in fp32 and comes out 1.06e-4 LOW of the float64 value of its own
+					# S_hat - A (measured with the oracle in this container: 424.2436 vs 424.2885); this build sums per row and then in
+					# float64 -- the accurate value, checked against the oracle's float64 norm below -- so the golden is met to 2.5e-4
+					tol = dict(rel=2.5e-4)
 				assert cell[t][m] == pytest.approx(v, **tol), (method, t, m, cell[t][m], v)
+	# ... and the accurately summed error norm to 2e-5: the oracle's S_hat (fp32, as the reference computes it), its error norm in float64
+	from oracle import cur_oracle as O
+	want = []
+	for seed in range(2):
+		rng = np.random.default_rng(seed)
+		ri = sorted(rng.choice(1000, 128, replace=False)); ci = sorted(rng.choice(5000, 64, replace=False))
+		o = O.CURApproxOracle(rows=A[ri, :], cols=A[:, ci], row_idxs=ri, col_idxs=ci, approx_preference="rows")
+		non = sorted(set(range(1000)) - set(int(i) for i in ri))
+		want.append(float((o.get(list(range(1000)), list(range(5000))) - A)[non, :].double().norm()))
+	got = res["cur"]["top_k=10"]["k_retvr=100"]["anc_n_m=128~anc_n_e=64"]["non_anchor"]["approx_error"]
+	assert got == pytest.approx(np.mean(want), rel=2e-5), (got, want)
 
 
 def test_entry_point_B_cli_with_numpy_pinv_matches_reference_sweep_to_1e4(gpu, tmp_path, golden_meta):

@@ -175,6 +175,41 @@ def test_fused_score_topk_matches_dense_and_cpu(ops, Q, I, K, k):
 	assert all(s or c for s, c in zip(same, close.tolist()))
 
 
+@pytest.mark.parametrize("Q,I,K,k", [(300, 40000, 64, 10), (257, 65536, 128, 100), (1000, 50007, 256, 100), (64, 70001, 200, 1), (2049, 123457, 256, 128), (130, 200000, 256, 500)])
+def test_eval_fused_equals_the_two_kernel_route(ops, Q, I, K, k):
+	"""anncur_eval_fused: ONE sweep yields the top-k of S_hat AND the per-row sum (S_hat - A)^2, sum A^2 of entry
+	point A's cell (crossenc.py:106,146-147).  Against the two-kernel route: top-k values bit for bit with the 32x32x16 sweep body
+	(ANNCUR_TOPK_MFMA32: the same MFMAs in the same order), index sets identical, no repaired query; the two sums within fp32
+	summation order (different partition of the tiles over workgroups, atomics) of anncur_approx_error_packed, and within 1e-4 of fp64
+	on sampled rows.  Ragged Q / I (a partial last tile: candidates from the sweep, error terms from the strided kernel)."""
+	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
+	Kp = Xp.shape[1]
+	g = _g(Q + I)
+	A = (X.float() @ E.float() + 0.3 * torch.randn(Q, I, generator=g)).bfloat16().cuda()
+	if I % 8:   # rows must be 16-byte aligned: a padded pitch
+		Ap = torch.zeros((Q, -(-I // 8) * 8), dtype=torch.bfloat16, device="cuda"); Ap[:, :I] = A; A = Ap[:, :I]
+	assert ops.eval_fused_ok(Kp, A, Q, I, k)
+	(tk, err, nrm, nfb) = ops.eval_fused(Xp, Etp, A, I, k, return_fallbacks=True)
+	(v2, i2), nfb2 = ops.score_topk_fused(Xp, Etp, I, k, return_fallbacks=True, mfma32=True)
+	err2, nrm2 = ops.approx_error_packed(Xp, Etp, A, I)
+	torch.cuda.synchronize()
+	assert nfb.item() == 0 and nfb2.item() == 0
+	assert torch.equal(tk.values, v2)
+	assert torch.equal(torch.sort(tk.indices, 1).values, torch.sort(i2, 1).values)
+	torch.testing.assert_close(err, err2, rtol=2e-5, atol=1e-6)
+	torch.testing.assert_close(nrm, nrm2, rtol=2e-5, atol=1e-6)
+	rows = torch.arange(0, Q, max(1, Q // 16))
+	S64 = X[rows].double() @ E.double()
+	A64 = A[rows.cuda()].double().cpu()
+	torch.testing.assert_close(err[rows.cuda()].double().cpu(), ((S64 - A64) ** 2).sum(1), rtol=1e-4, atol=1e-6)
+	torch.testing.assert_close(nrm[rows.cuda()].double().cpu(), (A64 ** 2).sum(1), rtol=1e-4, atol=1e-6)
+	plan_codes = ops.fused_plan(Q, I, Kp, k)   # (the public plan is untouched by the new entry point)
+	assert 6 not in plan_codes["stage_pred"]
+	# unsupported operands are refused loudly, not routed elsewhere
+	with pytest.raises(Exception):
+		ops.eval_fused(Xp, Etp, A.float(), I, k)
+
+
 @pytest.mark.parametrize("Q,I,K,k", [(1000, 40000, 256, 10), (777, 50001, 200, 64), (513, 30000, 128, 32), (5, 20000, 256, 7), (2049, 123457, 256, 128), (4100, 200000, 128, 100)])
 def test_fused_ring_body_equals_the_barrier_body(ops, Q, I, K, k):
 	"""ANNCUR_TOPK_RING (round 4, csrc/score16r.hpp): 8-wave workgroups of 512 queries, the item tiles through a ring of four LDS slots

@@ -210,6 +210,62 @@ __global__ __launch_bounds__(256) void ivf_group_scores_kernel(const float *__re
 	}
 }
 
+// The same GEMM per list on the bf16 matrix cores (round 4: the index built with dtype = "bf16" keeps a bf16 copy of the list-ordered
+// vectors; the queries are rounded to bf16 per call): 64 x 64 output tiles as above, k-tiles of 32, v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation.  Staging: every thread moves ONE 16-byte chunk (8 bf16) of a pair's query row and one of a vector per k-tile -- 64 rows
+// x 4 chunks -- into a [64 rows][4 chunks] LDS image whose chunk index is XOR-ed with (row >> 2) & 3 (rows are 64 bytes apart: a
+// ds_read_b128 of 16 rows x one chunk column then touches every bank group once); the next k-tile's chunks are in flight during the MFMAs.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8g;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4g;
+__global__ __launch_bounds__(256) void ivf_group_scores_bf16_kernel(const uint16_t *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
+																	 const uint16_t *__restrict__ Q, int64_t ldq, int32_t nprobe, const int32_t *__restrict__ pair_ids,
+																	 const int32_t *__restrict__ pair_off, const int32_t *__restrict__ tiles, int64_t lmax,
+																	 float *__restrict__ S) {
+	__shared__ __attribute__((aligned(16))) u32x4g As[GT * 4], Bs[GT * 4];
+	__shared__ int32_t arow[GT];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+	const int32_t l = tiles[3 * blockIdx.x], qt = tiles[3 * blockIdx.x + 1], vt = tiles[3 * blockIdx.x + 2];
+	const int32_t p0 = pair_off[l] + qt * GT, p_end = pair_off[l + 1];
+	const int32_t v0 = offsets[l] + vt * GT, v_end = offsets[l + 1];
+	if (tid < GT) arow[tid] = p0 + tid < p_end ? pair_ids[p0 + tid] / nprobe : -1;
+	__syncthreads();
+	const int row = tid >> 2, ch = tid & 3;                 // this thread's chunk of the operand tiles
+	const int slot = row * 4 + (ch ^ ((row >> 2) & 3));
+	const int32_t qr = arow[row];
+	const uint16_t *ap = qr >= 0 ? Q + (int64_t)qr * ldq + ch * 8 : nullptr;
+	const uint16_t *bp = v0 + row < v_end ? Xs + (int64_t)(v0 + row) * ldx + ch * 8 : nullptr;
+	f32x16g acc;
+#pragma unroll
+	for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+	const u32x4g zero = {0u, 0u, 0u, 0u};
+	u32x4g ra, rb;
+	auto load = [&](int k0) {
+		const bool in = k0 + ch * 8 < dp;                   // (dp is a multiple of 16: a chunk is inside the row or past it)
+		ra = (ap && in) ? *reinterpret_cast<const u32x4g *>(ap + k0) : zero;
+		rb = (bp && in) ? *reinterpret_cast<const u32x4g *>(bp + k0) : zero;
+	};
+	load(0);
+	for (int k0 = 0; k0 < dp; k0 += 32) {
+		As[slot] = ra; Bs[slot] = rb;
+		__syncthreads();
+		if (k0 + 32 < dp) load(k0 + 32);
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks) {
+			const int ra_row = wm * 32 + r, rb_row = wn * 32 + r, c = 2 * ks + h;
+			const bf16x8g a = __builtin_bit_cast(bf16x8g, As[ra_row * 4 + (c ^ ((ra_row >> 2) & 3))]);
+			const bf16x8g b = __builtin_bit_cast(bf16x8g, Bs[rb_row * 4 + (c ^ ((rb_row >> 2) & 3))]);
+			acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+		}
+		__syncthreads();
+	}
+	// C/D layout: col = lane & 31 (vector), row = (e & 3) + 8 (e >> 2) + 4 h (pair)
+#pragma unroll
+	for (int e = 0; e < 16; ++e) {
+		const int m = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, n = wn * 32 + r;
+		if (p0 + m < p_end && v0 + n < v_end) S[(int64_t)pair_ids[p0 + m] * lmax + (vt * GT + n)] = acc[e];
+	}
+}
+
 // column of the [nq x nprobe * lmax] score matrix -> id of the vector: slot = col / lmax, position = col % lmax in list probe[q, slot]
 __global__ __launch_bounds__(256) void ivf_map_ids_kernel(const int32_t *__restrict__ col, int64_t n, int32_t k, int64_t lmax, const int32_t *__restrict__ probe,
 														   int32_t nprobe, const int32_t *__restrict__ offsets, const int32_t *__restrict__ ids, const float *__restrict__ val,
@@ -237,6 +293,20 @@ extern "C" int anncur_ivf_group_scores(const float *Xs, int64_t ldx, int32_t dp,
 	ANNCUR_REQUIRE(Xs && offsets && Q && pair_ids && pair_offsets && tiles && S, ANNCUR_E_INVALID, "ivf_group_scores: null pointer");
 	hipLaunchKernelGGL(ivf_group_scores_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, Xs, ldx, dp, offsets, Q, ldq, nprobe, pair_ids,
 					   pair_offsets, tiles, lmax, S);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_ivf_group_scores_bf16(const void *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const void *Q, int64_t ldq, int32_t nprobe,
+											const int32_t *pair_ids, const int32_t *pair_offsets, const int32_t *tiles, int32_t n_tiles, int64_t lmax, float *S,
+											void *stream) {
+	ANNCUR_REQUIRE(dp >= 16 && (dp % 16) == 0 && ldx >= dp && ldq >= dp && (ldx % 8) == 0 && (ldq % 8) == 0 && nprobe >= 1 && lmax >= 1 && n_tiles >= 0,
+				   ANNCUR_E_INVALID, "ivf_group_scores_bf16: bad sizes (rows zero-padded to a multiple of 16 elements, 16-byte aligned)");
+	if (n_tiles == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(Xs && offsets && Q && pair_ids && pair_offsets && tiles && S && ((uintptr_t)Xs % 16) == 0 && ((uintptr_t)Q % 16) == 0, ANNCUR_E_INVALID,
+				   "ivf_group_scores_bf16: null or misaligned pointer");
+	hipLaunchKernelGGL(ivf_group_scores_bf16_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)Xs, ldx, dp, offsets,
+					   (const uint16_t *)Q, ldq, nprobe, pair_ids, pair_offsets, tiles, lmax, S);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

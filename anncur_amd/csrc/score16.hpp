@@ -203,21 +203,31 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	bool ticket_pending = false;
 	const bool dyn = p.chunk_tiles > 0;
 	uint32_t ticket_slot = lds_addr(smem + C::TICKET_OFF);
+	// XCD-sliced tickets (score_fused.hip 'XCD-sliced tickets'): thread 0's slice state; unsliced = one counter per row block as in round 3
+	uint32_t *const ctr_rb = p.chunk_ctr + (p.sliced ? (size_t)rb * N_SLICES : (size_t)rb);
+	int slice = p.sliced ? xcc_id() : 0, tried = 0;
 	if (dyn) {
 		if (tid == 0) {
-			const uint32_t c = atomicAdd(p.chunk_ctr + rb, 2u);
-			if (p.chunk_owner) {
-				if (c < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c] = (uint8_t)split;
-				if (c + 1 < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c + 1] = (uint8_t)split;
+			uint32_t c0, c1;
+			if (p.sliced) {
+				c0 = slice_resolve(atomicAdd(ctr_rb + slice, 1u), ctr_rb, p.n_chunks, p.chunks_per_slice, slice, tried);
+				c1 = c0 < (uint32_t)p.n_chunks ? slice_resolve(atomicAdd(ctr_rb + slice, 1u), ctr_rb, p.n_chunks, p.chunks_per_slice, slice, tried) : (uint32_t)p.n_chunks;
+			} else {
+				c0 = atomicAdd(ctr_rb, 2u); c1 = c0 + 1u;
 			}
-			lds_store_u32(ticket_slot, c);
+			if (p.chunk_owner) {
+				if (c0 < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c0] = (uint8_t)split;
+				if (c1 < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + c1] = (uint8_t)split;
+			}
+			lds_store_u32(ticket_slot + 8u, c0);   // (the prologue's pair sits in the third and fourth ticket word)
+			lds_store_u32(ticket_slot + 12u, c1);
 			__builtin_amdgcn_s_waitcnt(0xC07F);
 		}
 		__syncthreads();
-		const uint32_t c = lds_load_u32_uniform(ticket_slot);
+		const uint32_t c = lds_load_u32_uniform(ticket_slot + 8u), c1 = lds_load_u32_uniform(ticket_slot + 12u);
 		t_cur = c < (uint32_t)p.n_chunks ? p.tile_begin + (int)c * p.chunk_tiles : -1;
 		t_cend = min(t_cur + p.chunk_tiles, p.tile_end);
-		t_next_chunk = c + 1 < (uint32_t)p.n_chunks ? p.tile_begin + (int)(c + 1) * p.chunk_tiles : -1;
+		t_next_chunk = c1 < (uint32_t)p.n_chunks ? p.tile_begin + (int)c1 * p.chunk_tiles : -1;
 	}
 	uint32_t dma_off[C::TILE_BYTES / 4096];
 	tile_dma_offsets<KP>(dma_off, wave_u, lane);
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		if (nx >= t_cend) { nx = t_next_chunk; crossed = dyn && nx >= 0; }                                                      \
 		if (nx >= 0) tile_dma_s<KP>(p.Et, nx, lds_base + ((CUR) ^ 1) * C::TILE_BYTES, wave_u, dma_off);                         \
 		uint32_t ticket = 0;                                                                                                    \
-		if (crossed && tid == 0) ticket_draw(ticket, p.chunk_ctr + rb);                                                         \
+		if (crossed && tid == 0) ticket_draw(ticket, ctr_rb + slice);                                                           \
 		PH16(0);                                                                                                                \
 		/* Scheduled drain: all four waves drain in the SAME step (a uniform countdown), whatever their fill -- see above */    \
 		if (--drain_in == 0) {                                                                                                  \
@@ -292,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		PH16(3);                                                                                                                \
 		if (crossed) {                                                                                                          \
 			if (tid == 0) {                                                                                                     \
+				if (p.sliced) ticket = slice_resolve(ticket, ctr_rb, p.n_chunks, p.chunks_per_slice, slice, tried);             \
 				lds_store_u32(ticket_slot, ticket);                                                                             \
 				if (p.chunk_owner && ticket < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + ticket] = (uint8_t)split; \
 				__builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \

@@ -2046,8 +2046,8 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			if (const char *dbg = getenv("ANNCUR_DEBUG_RB_MAJOR")) p.rb_major = atoi(dbg);
 #endif
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
-			// XCD-sliced tickets: the Kp = 512 queue bodies (the shape whose sweep is close to the fabric's bandwidth); [row block][slice] counters
-			p.sliced = (P.bodyq1 || P.bodyq16) ? 1 : 0;
+			// XCD-sliced tickets: the wave-queue bodies (Kp = 512: the shape whose sweep was close to the fabric's bandwidth; Kp <= 256: traffic only); [row block][slice] counters
+			p.sliced = (P.bodyq1 || P.bodyq16 || (P.body16 && !P.ring16)) ? 1 : 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 			if (const char *dbg = getenv("ANNCUR_DEBUG_SLICED")) p.sliced = p.sliced && atoi(dbg) != 0;
 #endif
@@ -2232,24 +2232,10 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 	{ const char *dbg = getenv("ANNCUR_DEBUG_TAU_BIAS"); p.tau_bias = dbg ? (float)atof(dbg) : 0.f; }
 #endif
 	int rc;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	const bool pingpong = getenv("ANNCUR_DEBUG_WIDE2") != nullptr;   // wide2_kernel (two wave groups one phase apart, 4-stage ring)
-#endif
 	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, 256, st));
 	EV(0);
 	// 1. prepass over the sampled block tiles
 	p.n_wg = P.n_rb * P.S0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (pingpong) {
-		if (P.group == 16) {
-			if ((rc = anncur_ensure_dyn_lds((const void *)wide2_kernel<0, 16>, W2_LDS_BYTES)) != ANNCUR_OK) return rc;
-			hipLaunchKernelGGL((wide2_kernel<0, 16>), dim3(p.n_wg), dim3(512), W2_LDS_BYTES, st, p);
-		} else {
-			if ((rc = anncur_ensure_dyn_lds((const void *)wide2_kernel<0, 4>, W2_LDS_BYTES)) != ANNCUR_OK) return rc;
-			hipLaunchKernelGGL((wide2_kernel<0, 4>), dim3(p.n_wg), dim3(512), W2_LDS_BYTES, st, p);
-		}
-	} else
-#endif
 	if (P.group == 16) {
 		if ((rc = anncur_ensure_dyn_lds((const void *)wide_kernel<0, 16>, W_LDS_TOTAL)) != ANNCUR_OK) return rc;
 		hipLaunchKernelGGL((wide_kernel<0, 16>), dim3(p.n_wg), dim3(512), W_LDS_TOTAL, st, p);
@@ -2270,12 +2256,6 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 	for (int stg = 0, prev = 0; stg < P.n_stages; prev = P.stage_end[stg], ++stg) {
 		EV(5 + 2 * stg);
 		p.bt_begin = prev; p.bt_end = P.stage_end[stg]; p.bt_per_split = P.stage_tps[stg]; p.carry = stg > 0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-		if (pingpong) {
-			if ((rc = anncur_ensure_dyn_lds((const void *)wide2_kernel<1, 16>, W2_LDS_BYTES)) != ANNCUR_OK) return rc;
-			hipLaunchKernelGGL((wide2_kernel<1, 16>), dim3(p.n_wg), dim3(512), W2_LDS_BYTES, st, p);
-		} else
-#endif
 		hipLaunchKernelGGL((wide_kernel<1, 16>), dim3(p.n_wg), dim3(512), W_LDS_TOTAL, st, p);
 		ANNCUR_LAUNCH_OK();
 		EV(6 + 2 * stg);

@@ -288,226 +288,9 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 	}
 }
 
-// ================================================================================================ ping-pong variant
-// (compiled into the timing-experiment library only: measured level with wide_kernel, 929-934 vs 944-947 TFLOP/s at
-//  10k x 100k x 1024 in one process, results identical -- the pipeline structure is not what limits the kernel; PMC of
-//  wide_kernel: L2 hit rate 78 % (82 % would be ideal for its XCD rectangles), 1.6-1.9 GB from beyond L2 per launch = 1.7 TB/s.)
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-// Same tile, operands, accumulators, epilogue and candidate layout as wide_kernel; different pipeline.
-//   * K is streamed in 32-wide HALF k-tiles through a ring of FOUR 32 KiB stages (items 16 KiB + queries 16 KiB, 256 rows of
-//     64 bytes each, 16-byte chunk XOR-ed with (row >> 2) & 3: conflict-free ds_read_b128 of 32 rows x one chunk column);
-//   * the eight waves form two groups -- waves 0..3 (item half 0) and 4..7 (item half 1): wave w and w + 4 share a SIMD --
-//     that run ONE PHASE apart: while one group issues its 16 MFMAs of a half k-tile, the other reads its 12 fragments of the
-//     next one and issues its four 1 KiB DMA pieces, then they swap; one s_barrier per phase.  The matrix pipe of every SIMD is
-//     then fed by one wave at a time, back to back, instead of two waves that read, wait and compute in lockstep
-//     (MI355X guide, 'Two waves per SIMD' item 9 / the 8-phase 256^2 template);
-//   * DMA lead: the pieces of half n + 3 are issued in the load phase of half n (stage (n + 3) & 3 was last read one phase
-//     earlier) and must have landed 5-6 phases later: before a barrier that precedes the first read of half m every wave waits
-//     until at most the pieces of halves m + 1, m + 2 are outstanding (counted vmcnt(8) / (4) / (0) towards the end) --
-//     "read a staged buffer one phase AFTER the wait that retires it".
-constexpr int W2_OP_BYTES = 256 * 64;          // one operand of one half k-tile
-constexpr int W2_STAGE_BYTES = 2 * W2_OP_BYTES;
-constexpr int W2_LDS_BYTES = 4 * W2_STAGE_BYTES;  // 128 KiB
-
-template <int MODE, int GROUP>
-__global__ __launch_bounds__(512, 2) void wide2_kernel(const WideParams p) {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int r = lane & 31, h = lane >> 5, wi = wave >> 2, wq = wave & 3;  // wi = wave group = item half
-	int rb, split;
-	wide_map(xcd_remap(blockIdx.x, p.n_wg), p.n_rb, MODE == 0 ? p.S0 : p.S, rb, split);
-	const int64_t qb = (int64_t)rb * WBN;
-	int j_begin, j_end;
-	if (MODE == 0) { j_begin = split * p.st_per_split; j_end = min(j_begin + p.st_per_split, p.n_st); }
-	else { j_begin = p.bt_begin + split * p.bt_per_split; j_end = min(j_begin + p.bt_per_split, p.bt_end); }
-#define bt_of(j) ((MODE == 0 && !p.sample_leading) ? (int)(((int64_t)(j) * p.n_bt_full) / p.n_st) : (j))
-	const int nh = p.Kp >> 5;                         // half k-tiles per block tile (multiple of 4)
-	const int64_t row_bytes = (int64_t)p.Kp * 2;
-	const int n_jt = j_end - j_begin;
-	const int NH = n_jt * nh;                         // halves of this workgroup
-	if (NH <= 0) return;                              // (uniform: no barrier has been executed)
-
-	// ---- DMA: the wave's 2 + 2 pieces of a half (16 rows x 64 B each); per-lane 32-bit offsets from a uniform base
-	const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.X) + qb * p.ldx * 2;
-	const int q_rows = (int)min((int64_t)WBN, p.Q - qb);
-	uint32_t boff[2];
-#pragma unroll
-	for (int i = 0; i < 2; ++i) {
-		const int prow = (wave * 2 + i) * 16 + (lane >> 2), pchunk = (lane & 3) ^ ((prow >> 2) & 3);
-		boff[i] = (uint32_t)min(prow, q_rows - 1) * (uint32_t)(p.ldx * 2) + (uint32_t)pchunk * 16u;
-	}
-	auto a_off = [&](int bt, int i) -> uint32_t {
-		const int rows = (int)min((int64_t)WBM, p.et_rows - (int64_t)bt * WBM);
-		const int prow = (wave * 2 + i) * 16 + (lane >> 2), pchunk = (lane & 3) ^ ((prow >> 2) & 3);
-		return (uint32_t)min(prow, rows - 1) * (uint32_t)row_bytes + (uint32_t)pchunk * 16u;
-	};
-	// issue the pieces of global half n (block tile n / nh, half n % nh) into stage `st`
-	auto dma_half = [&](int n, int st) {
-		const int jt = n / nh, kh = n - jt * nh;
-		const int bt = bt_of(j_begin + jt);
-		const unsigned char *ab = reinterpret_cast<const unsigned char *>(p.Et) + (int64_t)bt * WBM * row_bytes + kh * 64;
-		const unsigned char *xb_ = xbase + kh * 64;
-		unsigned char *sa = smem + st * W2_STAGE_BYTES, *sb = sa + W2_OP_BYTES;
-#pragma unroll
-		for (int i = 0; i < 2; ++i)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ab + a_off(bt, i)),
-											 (__attribute__((address_space(3))) void *)(sa + (wave * 2 + i) * 1024), 16, 0, 0);
-#pragma unroll
-		for (int i = 0; i < 2; ++i)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(xb_ + boff[i]),
-											 (__attribute__((address_space(3))) void *)(sb + (wave * 2 + i) * 1024), 16, 0, 0);
-	};
-
-	// ---- this lane's queries / candidate segments (as wide_kernel)
-	int64_t qv[2];
-	float tau[2];
-	uint32_t ncand[2], segoff[2];
-	const int nseg = 4 * p.S, sg = (h * 2 + wi) * p.S + split;
-	unsigned char *cbase = reinterpret_cast<unsigned char *>(p.cand + qb * nseg * (int64_t)p.capg);
-#pragma unroll
-	for (int t = 0; t < 2; ++t) {
-		qv[t] = qb + wq * 64 + 32 * t + r;
-		const bool ok = qv[t] < p.Q;
-		tau[t] = (MODE == 1 && ok) ? p.tau[qv[t] * p.tau_stride] + p.tau_bias : INFINITY;
-		ncand[t] = (MODE == 1 && p.carry && ok) ? p.seg_cnt[qv[t] * nseg + sg] : 0u;
-		segoff[t] = (uint32_t)(((wq * 64 + 32 * t + r) * nseg + sg) * p.capg) * 8u;
-	}
-
-	// ---- fragment addresses: row * 64 + ((2 s + h) ^ x) * 16, x = (row >> 2) & 3 = (r >> 2) & 3; stage >> 1 picks the base register,
-	// (stage & 1) * 32 KiB + operand + sub-tile are immediates
-	const int x = (r >> 2) & 3;
-	const uint32_t lds0 = lds_addr(smem);
-	uint32_t a_addr[2][2], b_addr[2][2];  // [stage >> 1][k-step]
-#pragma unroll
-	for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-		for (int s = 0; s < 2; ++s) {
-			const uint32_t c = (uint32_t)(((2 * s + h) ^ x) * 16);
-			a_addr[hi][s] = lds0 + (uint32_t)hi * 65536u + (uint32_t)(wi * 128 + r) * 64u + c;
-			b_addr[hi][s] = lds0 + (uint32_t)hi * 65536u + (uint32_t)W2_OP_BYTES + (uint32_t)(wq * 64 + r) * 64u + c;
-		}
-
-	// ---- prologue: halves 0..2 in flight, half 0 landed
-	dma_half(0, 0);
-	if (NH > 1) dma_half(1, 1);
-	if (NH > 2) dma_half(2, 2);
-	if (NH > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-	else if (NH > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-	else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__builtin_amdgcn_s_barrier();
-	asm volatile("" ::: "memory");
-	if (wi == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }  // group 1 runs one phase behind
-
-	f32x16 acc[4][2];
-	u32x4 fa[2][4], fb[2][2];
-	// wait until at most the pieces of the halves after m = n + 1 that exist are outstanding (see the header)
-#define W2_WAIT(n)                                                                                                \
-	do {                                                                                                          \
-		const int rem_ = NH - 2 - (n);  /* halves after n + 1 */                                                  \
-		if (rem_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                           \
-		else if (rem_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                      \
-		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
-	} while (0)
-#define W2_BARRIER() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-#define W2_LOAD(ST)                                                                                               \
-	do {                                                                                                          \
-		_Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                           \
-			_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                         \
-				lds_read_frag_at(fa[s][m], a_addr[(ST) >> 1][s], ((ST) & 1) * W2_STAGE_BYTES + m * 2048);         \
-			_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
-				lds_read_frag_at(fb[s][t], b_addr[(ST) >> 1][s], ((ST) & 1) * W2_STAGE_BYTES + t * 2048);         \
-		}                                                                                                         \
-	} while (0)
-#define W2_MFMA()                                                                                                 \
-	do {                                                                                                          \
-		_Pragma("unroll") for (int s = 0; s < 2; ++s)                                                             \
-			_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                         \
-				_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                     \
-					acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][m]),     \
-																		   __builtin_bit_cast(bf16x8, fb[s][t]), acc[m][t], 0, 0, 0); \
-	} while (0)
-	// one half k-tile of this wave: load phase | barrier | MFMA phase (+ epilogue after the tile's last half) | barrier
-#define W2_HALF(ST)                                                                                               \
-	do {                                                                                                          \
-		const int n = jt * nh + kq + (ST);                                                                        \
-		W2_LOAD(ST);                                                                                              \
-		if (n + 3 < NH) dma_half(n + 3, ((ST) + 3) & 3);                                                          \
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
-		_Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                           \
-			_Pragma("unroll") for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(fa[s][m]));                      \
-			_Pragma("unroll") for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(fb[s][t]));                      \
-		}                                                                                                         \
-		W2_WAIT(n);                                                                                               \
-		W2_BARRIER();                                                                                             \
-		W2_MFMA();                                                                                                \
-		if (kq + (ST) == nh - 1) { W2_EPILOGUE(); }                                                               \
-		W2_WAIT(n);                                                                                               \
-		W2_BARRIER();                                                                                             \
-	} while (0)
-
-	for (int jt = 0; jt < n_jt; ++jt) {
-		const int j = j_begin + jt, bt = bt_of(j);
-#pragma unroll
-		for (int m = 0; m < 4; ++m)
-#pragma unroll
-			for (int t = 0; t < 2; ++t)
-#pragma unroll
-				for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
-#define W2_EPILOGUE()                                                                                             \
-		do {                                                                                                      \
-			if (MODE == 0) {                                                                                      \
-				constexpr int GPB = (GROUP == 16) ? 16 : 64;                                                      \
-				_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                     \
-					_Pragma("unroll") for (int m = 0; m < 4; ++m) {                                               \
-						const int g = (wi * 4 + m) * 2 + h;                                                       \
-						if (GROUP == 16) {                                                                        \
-							float mx = acc[m][t][0];                                                              \
-							_Pragma("unroll") for (int e = 1; e < 16; ++e) mx = fmaxf(mx, acc[m][t][e]);          \
-							if (qv[t] < p.Q) p.gmax[qv[t] * p.n_groups + (int64_t)j * GPB + g] = mx;              \
-						} else {                                                                                  \
-							float4 mx;                                                                            \
-							mx.x = fmaxf(fmaxf(acc[m][t][0], acc[m][t][1]), fmaxf(acc[m][t][2], acc[m][t][3]));    \
-							mx.y = fmaxf(fmaxf(acc[m][t][4], acc[m][t][5]), fmaxf(acc[m][t][6], acc[m][t][7]));    \
-							mx.z = fmaxf(fmaxf(acc[m][t][8], acc[m][t][9]), fmaxf(acc[m][t][10], acc[m][t][11]));  \
-							mx.w = fmaxf(fmaxf(acc[m][t][12], acc[m][t][13]), fmaxf(acc[m][t][14], acc[m][t][15])); \
-							if (qv[t] < p.Q) *reinterpret_cast<float4 *>(p.gmax + qv[t] * p.n_groups + ((int64_t)j * GPB + g * 4)) = mx; \
-						}                                                                                         \
-					}                                                                                             \
-			} else {                                                                                              \
-				const uint32_t item_wave = (uint32_t)bt * WBM + (uint32_t)(wi * 128 + 4 * h);                     \
-				_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                     \
-					_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                 \
-						_Pragma("unroll") for (int e = 0; e < 16; ++e) {                                          \
-							const float v = acc[m][t][e];                                                         \
-							if (__builtin_expect(__ballot(v >= tau[t]) != 0ull, 0)) {                             \
-								uint32_t item = item_wave;                                                        \
-								asm volatile("" : "+v"(item));                                                    \
-								item += (uint32_t)(m * 32 + (e & 3) + 8 * (e >> 2));                              \
-								if (v >= tau[t] && item < (uint32_t)p.I) {                                        \
-									if (ncand[t] < (uint32_t)p.capg)                                              \
-										*reinterpret_cast<uint2 *>(cbase + (segoff[t] + ncand[t] * 8u)) = make_uint2(__float_as_uint(v), item); \
-									ncand[t]++;                                                                   \
-								}                                                                                 \
-							}                                                                                     \
-						}                                                                                         \
-			}                                                                                                     \
-		} while (0)
-		for (int kq = 0; kq < nh; kq += 4) {
-			W2_HALF(0); W2_HALF(1); W2_HALF(2); W2_HALF(3);
-		}
-	}
-	if (wi == 0) W2_BARRIER();  // group 0 ends one phase early
-#undef W2_EPILOGUE
-#undef W2_HALF
-#undef W2_MFMA
-#undef W2_LOAD
-#undef W2_BARRIER
-#undef W2_WAIT
-#undef bt_of
-	if (MODE == 1) {
-#pragma unroll
-		for (int t = 0; t < 2; ++t)
-			if (qv[t] < p.Q) p.seg_cnt[qv[t] * nseg + sg] = ncand[t];
-	}
-}
-#endif  // ANNCUR_TIMING_EXPERIMENTS
+// (Round 2-4: a ping-pong variant of this kernel -- two wave groups one phase apart over a 4-stage ring of 32-wide half k-tiles, counted
+//  vmcnt, the 8-phase 256^2 template of the MI355X guide -- was built, parity-exact, and measured level with wide_kernel twice: 929-934 vs
+//  944-947 TFLOP/s in round 2, 989-991 vs 969-990 in round 4 (profiles/r04_ab_wide_vs_pingpong.txt, one process, one device).  The
+//  pipeline structure is not what limits this kernel -- profiles/r04_pmc_summary_wide.json: matrix pipe busy 0.48 at 2.08 GHz, 43 % of the
+//  wave cycles in issue stalls (SQ_WAIT_INST_ANY: MFMA dependency / pipe), 37 % parked (SQ_WAIT_ANY), no LDS bank conflicts, L2 hit rate
+//  0.78 with 1.6 GB per launch from beyond L2 -- and the variant was deleted in round 4 instead of shipping as dead code.)

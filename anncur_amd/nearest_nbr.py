@@ -83,9 +83,12 @@ class IVFFlatIPIndex:
 	restores the plain means), an empty list re-seeded by splitting a large one.  FAISS' random draws cannot be reproduced, so parity is
 	unpinned and the index is judged on recall and list balance.  Results are deterministic for a given seed."""
 
-	def __init__(self, d, nlist, device=None, niter=10, seed=1234, max_points_per_centroid=256, spherical=True):
+	def __init__(self, d, nlist, device=None, niter=10, seed=1234, max_points_per_centroid=256, spherical=True, dtype="fp32"):
 		self.d, self.nlist = int(d), int(nlist)
 		self.spherical = bool(spherical)
+		if dtype not in ("fp32", "bf16"):
+			raise ValueError(f"dtype = {dtype} not supported")
+		self.dtype = dtype                          # "bf16": the batched search scores bf16 copies of the lists and queries on the bf16 matrix cores
 		self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 		self.niter, self.seed, self.max_points_per_centroid = niter, seed, max_points_per_centroid
 		self.nprobe = 1
@@ -95,6 +98,7 @@ class IVFFlatIPIndex:
 		self.centroids = None                       # [nlist x d] fp32
 		self._X = None                              # vectors in insertion order
 		self._Xs = self._offsets = self._ids = None  # vectors in list order (rows zero-padded to a multiple of 16 floats), list bounds, ids
+		self._Xs16 = None                            # dtype "bf16": the same rows rounded to bf16 (batched search)
 		self._dp = -(-self.d // 16) * 16
 
 	def _dev32(self, x):
@@ -152,22 +156,31 @@ class IVFFlatIPIndex:
 		self._sizes = counts.cpu().numpy().astype(np.int64)         # list lengths on the host: the batched search's tile worklist
 		self._Xs = torch.zeros((self.ntotal, self._dp), dtype=torch.float32, device=self.device)
 		self._Xs[:, :self.d] = ops.gather_rows(self._X, self._ids)
+		self._Xs16 = ops.convert(self._Xs, torch.bfloat16) if self.dtype == "bf16" else None
+
+	def search_device(self, q, k, profile=None):
+		"""search() on DEVICE-RESIDENT queries q [nq x d] fp32 -> (values f32 [nq x k_eff], ids int32 [nq x k_eff]) on the device, no host copy
+		(k_eff = min(k, MAX_TOPK); slots without a result hold (-inf, -1)).  What bench.py times as the kernels' own rate."""
+		assert self._Xs is not None, "index is empty"
+		nprobe = max(1, min(int(self.nprobe), self.nlist))
+		probe = ops.score_topk_dense(q, self.centroids, nprobe).indices        # the nprobe lists of largest <q, centroid>
+		if self._dp == self.d:
+			qp = q if q.is_contiguous() else q.contiguous()
+		else:
+			qp = torch.zeros((q.shape[0], self._dp), dtype=torch.float32, device=self.device)
+			qp[:, :self.d] = q
+		k_eff = min(k, ops._lib.MAX_TOPK)
+		if q.shape[0] >= self.batched_from:
+			# many queries (hard-negative mining: every mention): pairs grouped by list, each list one MFMA GEMM -- a list's vectors
+			# are read once per 64 queries instead of once per query (28 -> ~3 ms for 10^4 queries on 10^5 x 768 vectors)
+			return ops.ivf_scan_grouped(self._Xs, self._offsets, self._ids, self._sizes, qp, probe, k_eff, lists_bf16=self._Xs16, profile=profile)
+		return ops.ivf_scan(self._Xs, self._offsets, self._ids, qp, probe, k_eff)
 
 	def search(self, x, k):
 		assert self._Xs is not None, "index is empty"
 		q = self._dev32(x)
-		nprobe = max(1, min(int(self.nprobe), self.nlist))
-		probe = ops.score_topk_dense(q, self.centroids, nprobe).indices        # the nprobe lists of largest <q, centroid>
-		qp = torch.zeros((q.shape[0], self._dp), dtype=torch.float32, device=self.device)
-		qp[:, :self.d] = q
-		k_eff = min(k, ops._lib.MAX_TOPK)
-		if q.shape[0] >= self.batched_from:
-			# many queries (hard-negative mining: every mention): pairs grouped by list, each list one fp32-MFMA GEMM -- a list's vectors
-			# are read once per 64 queries instead of once per query (28 -> ~3 ms for 10^4 queries on 10^5 x 768 vectors)
-			v, i = ops.ivf_scan_grouped(self._Xs, self._offsets, self._ids, self._sizes, qp, probe, k_eff)
-		else:
-			v, i = ops.ivf_scan(self._Xs, self._offsets, self._ids, qp, probe, k_eff)
-		return _faiss_pad(v, i, q.shape[0], k, k_eff)
+		v, i = self.search_device(q, k)
+		return _faiss_pad(v, i, q.shape[0], k, min(k, ops._lib.MAX_TOPK))
 
 
 def build_flat_or_ivff_index(embeds, force_exact_search, probe_mult_factor=1, dtype="fp32", device=None):
@@ -181,7 +194,7 @@ def build_flat_or_ivff_index(embeds, force_exact_search, probe_mult_factor=1, dt
 	else:
 		nlist = int(math.floor(math.sqrt(n)))                                   # number of quantized cells (:41)
 		nprobe = int(math.floor(math.sqrt(nlist) * probe_mult_factor))          # number of the quantized cells to probe (:44)
-		index = IVFFlatIPIndex(d, nlist, device=device)
+		index = IVFFlatIPIndex(d, nlist, device=device, dtype=dtype)
 		index.train(embeds)
 		index.add(embeds)
 		index.nprobe = nprobe

@@ -762,10 +762,13 @@ def ivf_scan(Xs, offsets, ids, Q, probe, k):
 
 
 @_on_device
-def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 30):
+def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 30, lists_bf16=None, profile=None):
 	"""The same search as ivf_scan for MANY queries: pairs (query, probe slot) sorted by list, every list one small fp32-MFMA GEMM against
 	its pairs' queries (anncur_ivf_group_scores), then the exact scan over each query's nprobe lists side by side and the column -> id map.
-	sizes_host: the lists' lengths on the host (numpy int64, known since add()).  One small D2H (pairs per list) builds the tile worklist."""
+	sizes_host: the lists' lengths on the host (numpy int64, known since add()).  One small D2H (pairs per list) builds the tile worklist.
+	lists_bf16: a bf16 copy of Xs (same layout) -> the per-list GEMMs run on the bf16 matrix cores (queries rounded to bf16 here).
+	profile: a dict -> receives HIP events around the per-list GEMM launch and around the scan + id map ("events": [(e0, e1, e2), ...] per
+	query chunk; measurement only: bench.py's kernel-only IVF figure)."""
 	_dev(Xs, offsets, ids, Q, probe)
 	lib = _lib.load()
 	nq_all, dp = Q.shape
@@ -796,11 +799,23 @@ def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 3
 		S = _ScoreScratch.get(nq * nprobe * lmax, Q.device).view(nq, nprobe * lmax)   # grow-only scratch: a fresh 100s-of-MB allocation per call cost more than the search
 		S.fill_(float("-inf"))
 		Qc = Q[q0:q1]
-		check(lib.anncur_ivf_group_scores(_p(Xs), _ld(Xs), dp, _p(offsets), _p(Qc), _ld(Qc), nprobe, _p(pair_ids), _p(poff), _p(tiles_dev), tiles.shape[0], lmax,
-										  _p(S), _stream()), "ivf_group_scores")
+		if profile is not None:
+			evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+			profile.setdefault("events", []).append(evs)
+			profile.setdefault("tiles", []).append(int(tiles.shape[0]))
+			evs[0].record()
+		if lists_bf16 is not None:
+			Qb = convert(Qc, torch.bfloat16)
+			check(lib.anncur_ivf_group_scores_bf16(_p(lists_bf16), _ld(lists_bf16), dp, _p(offsets), _p(Qb), _ld(Qb), nprobe, _p(pair_ids), _p(poff), _p(tiles_dev),
+												   tiles.shape[0], lmax, _p(S), _stream()), "ivf_group_scores_bf16")
+		else:
+			check(lib.anncur_ivf_group_scores(_p(Xs), _ld(Xs), dp, _p(offsets), _p(Qc), _ld(Qc), nprobe, _p(pair_ids), _p(poff), _p(tiles_dev), tiles.shape[0], lmax,
+											  _p(S), _stream()), "ivf_group_scores")
+		if profile is not None: evs[1].record()
 		v, c = rowwise_topk(S, k_eff)
 		out_i = idx[q0:q1, :k_eff] if k_eff == k else torch.empty((nq, k_eff), dtype=torch.int32, device=Q.device)
 		check(lib.anncur_ivf_map_ids(_p(c), _p(v), nq, k_eff, lmax, _p(pr), nprobe, _p(offsets), _p(ids), _p(out_i), _stream()), "ivf_map_ids")
+		if profile is not None: evs[2].record()
 		val[q0:q1, :k_eff] = v
 		if k_eff < k:
 			idx[q0:q1, :k_eff] = out_i

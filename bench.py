@@ -78,33 +78,56 @@ def self_launch(args):
 
 def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 	"""models/nearest_nbr.py:40-52 at the size of the reference's hard-negative mining (utils/data_process.py:343-365: every mention queries
-	the entity index): n clustered vectors, nlist = floor(sqrt(n)), nprobe = floor(sqrt(nlist)); batched list-grouped search on the fp32
-	matrix cores.  Reported against the fp32 matrix peak (157 TFLOP/s): algorithmic flops = 2 x vectors scanned x d."""
+	the entity index): n clustered vectors, nlist = floor(sqrt(n)), nprobe = floor(sqrt(nlist)); batched list-grouped search on the matrix
+	cores.  Two figures per index dtype: the whole search() call with host numpy in / out like FAISS (probe, pair sort, host-built tile
+	worklist, copies), and the KERNELS alone on device-resident queries (HIP events around the per-list GEMM launch and around the exact scan
+	of the scores + id map) against the matrix peak of the operand type (fp32: 157 TFLOP/s; bf16 lists: 2500).  Algorithmic flops = 2 x
+	vectors scanned x d; the GEMM launch also multiplies the padding of its 64 x 64 tiles (reported as tile_flops_ratio)."""
 	from anncur_amd import ops
 	from anncur_amd.nearest_nbr import build_flat_or_ivff_index
 	g = torch.Generator(device=device).manual_seed(seed + 99)
 	C = torch.randn(200, d, generator=g, device=device)
 	X = (C[torch.randint(0, 200, (n,), generator=g, device=device)] + 0.7 * torch.randn(n, d, generator=g, device=device)).cpu().numpy()
 	Qv = (C[torch.randint(0, 200, (nq,), generator=g, device=device)] + 0.7 * torch.randn(nq, d, generator=g, device=device)).cpu().numpy()
-	t0 = time.perf_counter(); index = build_flat_or_ivff_index(X, force_exact_search=False); torch.cuda.synchronize(); build_s = time.perf_counter() - t0
-	for _ in range(2): index.search(Qv, k)
-	torch.cuda.synchronize()
-	times = []
-	for _ in range(5):
-		t0 = time.perf_counter(); D, I = index.search(Qv, k); torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-	search_s = float(np.median(times))
-	sizes = index._sizes
-	probe = ops.score_topk_dense(torch.as_tensor(Qv).to(device), index.centroids, index.nprobe).indices.cpu().numpy()
-	scanned = float(sizes[probe].sum())
-	pairs = np.bincount(probe.reshape(-1), minlength=index.nlist)
-	read_bytes = float((-(-pairs // 64) * sizes).sum()) * index._dp * 4       # a list's vectors are read once per 64-query tile
-	flops = 2.0 * scanned * d
-	return {"n": n, "d": d, "nq": nq, "k": k, "nlist": index.nlist, "nprobe": index.nprobe, "build_s": build_s, "search_ms": 1e3 * search_s,
-			"queries_per_s": nq / search_s, "vectors_scanned_per_query": scanned / nq,
-			"roofline": {"bound": "mfma", "kernel": "ivf_group_scores_kernel (fp32 MFMA, one GEMM per inverted list)", "achieved": flops / search_s / 1e12, "peak": 157.3,
-						 "unit": "TFLOP/s", "frac": flops / search_s / 1e12 / 157.3, "what": "whole search() call incl. probe, pair sort, exact scan of the scores, host copies"},
-			"list_bytes_read_model": read_bytes, "list_bytes_per_query_model_unbatched": scanned * index._dp * 4 / nq,
-			"data": "synthetic clustered vectors (200 centres), host numpy in / out like FAISS", "parity": "unpinned (FAISS absent): recall-judged in tests/"}
+	out = {"n": n, "d": d, "nq": nq, "k": k, "data": "synthetic clustered vectors (200 centres), host numpy in / out like FAISS",
+		   "parity": "unpinned (FAISS absent): recall-judged in tests/"}
+	for dtype, peak in (("fp32", 157.3), ("bf16", PEAK_BF16_TFLOPS)):
+		t0 = time.perf_counter(); index = build_flat_or_ivff_index(X, force_exact_search=False, dtype=dtype); torch.cuda.synchronize(); build_s = time.perf_counter() - t0
+		for _ in range(2): index.search(Qv, k)
+		torch.cuda.synchronize()
+		times = []
+		for _ in range(5):
+			t0 = time.perf_counter(); D, I = index.search(Qv, k); torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+		search_s = float(np.median(times))
+		sizes = index._sizes
+		q_dev = torch.as_tensor(Qv).to(device)
+		probe = ops.score_topk_dense(q_dev, index.centroids, index.nprobe).indices.cpu().numpy()
+		scanned = float(sizes[probe].sum())
+		flops = 2.0 * scanned * d
+		gemm_ms, scan_ms, tile_flops = [], [], 0.0
+		for _ in range(5):   # kernels alone: device-resident queries and results, events on the launch stream
+			prof = {}
+			index.search_device(q_dev, k, profile=prof)
+			torch.cuda.synchronize()
+			gemm_ms.append(sum(e[0].elapsed_time(e[1]) for e in prof["events"])); scan_ms.append(sum(e[1].elapsed_time(e[2]) for e in prof["events"]))
+			tile_flops = 2.0 * sum(prof["tiles"]) * 64 * 64 * index._dp
+		gm, sm = float(np.median(gemm_ms)), float(np.median(scan_ms))
+		row = {"nlist": index.nlist, "nprobe": index.nprobe, "build_s": build_s, "search_ms": 1e3 * search_s, "queries_per_s": nq / search_s,
+			   "vectors_scanned_per_query": scanned / nq,
+			   "kernels": {"group_gemm_ms": gm, "scan_and_id_map_ms": sm, "queries_per_s_kernels_only": nq / ((gm + sm) * 1e-3), "tile_flops_ratio": tile_flops / flops,
+						   "roofline": {"bound": "mfma", "kernel": "ivf_group_scores_bf16_kernel (bf16 MFMA)" if dtype == "bf16" else "ivf_group_scores_kernel (fp32 MFMA)",
+										"achieved": flops / (gm * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / (gm * 1e-3) / 1e12 / peak,
+										"what": "the per-list GEMM launch alone (HIP events), algorithmic flops = 2 x vectors scanned x d"}},
+			   "whole_call": {"achieved_tflops": flops / search_s / 1e12, "what": "search() incl. probe, pair sort, host-built worklist, exact scan of the scores, host copies"}}
+		if dtype == "fp32":
+			ref_I = I
+		else:
+			row["recall_vs_fp32_index"] = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(I.tolist(), ref_I.tolist())]))
+		out[dtype] = row
+	# (kept at the top level for readers of earlier rounds' lines: the fp32 index's whole-call figures)
+	out.update({kk: out["fp32"][kk] for kk in ("nlist", "nprobe", "build_s", "search_ms", "queries_per_s", "vectors_scanned_per_query")})
+	out["roofline"] = out["fp32"]["kernels"]["roofline"]
+	return out
 
 
 def run_config(args, cfg_name, ctx, light=False):

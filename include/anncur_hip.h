@@ -294,6 +294,11 @@ int anncur_ivf_scan(const float *Xs, int64_t ldx, int32_t dp, const int32_t *off
 int anncur_ivf_group_scores(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const float *Q, int64_t ldq, int32_t nprobe,
                             const int32_t *pair_ids, const int32_t *pair_offsets, const int32_t *tiles, int32_t n_tiles, int64_t lmax, float *S,
                             void *stream);
+/* The same on bf16 operands (Xs / Q: bf16 rows zero-padded to dp elements, dp a multiple of 16, 16-byte aligned; an index built with
+ * dtype = "bf16" keeps such a copy of its lists): v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 scores. */
+int anncur_ivf_group_scores_bf16(const void *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const void *Q, int64_t ldq, int32_t nprobe,
+                                 const int32_t *pair_ids, const int32_t *pair_offsets, const int32_t *tiles, int32_t n_tiles, int64_t lmax, float *S,
+                                 void *stream);
 int anncur_ivf_map_ids(const int32_t *col, const float *val, int64_t nq, int32_t k, int64_t lmax, const int32_t *probe, int32_t nprobe,
                        const int32_t *offsets, const int32_t *ids, int32_t *out_idx, void *stream);
 

@@ -265,6 +265,33 @@ def test_ivf_flat_index_branch(gpu):
 	assert torch.equal(again.centroids, index.centroids) and torch.equal(again._ids, index._ids)
 
 
+def test_ivf_bf16_lists_on_the_bf16_matrix_cores(gpu):
+	"""An index built with dtype = "bf16" keeps a bf16 copy of its list-ordered vectors; the batched search scores it against bf16-rounded
+	queries with one v_mfma_f32_32x32x16_bf16 GEMM per list (anncur_ivf_group_scores_bf16).  Same lists, same probes as the fp32 index;
+	on inputs that ARE bf16 values the scores are the exact fp32-accumulated products: equal to the fp32 index's to round-off, same ids.
+	Ragged sizes: d not a multiple of 32 (a partial k-tile), partial 64-tiles of pairs and of vectors, an empty list."""
+	from anncur_amd.nearest_nbr import IVFFlatIPIndex
+	g = np.random.default_rng(23)
+	n, d, nq, k = 20000, 200, 1000, 20
+	centers = g.standard_normal((40, d)).astype(np.float32) * 2
+	X = torch.tensor(centers[g.integers(0, 40, n)] + g.standard_normal((n, d)).astype(np.float32)).bfloat16().float().numpy()
+	q = torch.tensor(centers[g.integers(0, 40, nq)] + g.standard_normal((nq, d)).astype(np.float32)).bfloat16().float().numpy()
+	a = IVFFlatIPIndex(d, 100, niter=4, dtype="fp32"); a.train(X); a.add(X); a.nprobe = 7
+	b = IVFFlatIPIndex(d, 100, niter=4, dtype="bf16"); b.train(X); b.add(X); b.nprobe = 7
+	assert torch.equal(a.centroids, b.centroids) and torch.equal(a._ids, b._ids) and b._Xs16 is not None and b._Xs16.dtype == torch.bfloat16
+	Da, Ia = a.search(q, k)
+	Db, Ib = b.search(q, k)
+	np.testing.assert_allclose(Db, Da, rtol=2e-5, atol=2e-4)
+	assert np.mean([len(set(x) & set(y)) / k for x, y in zip(Ia.tolist(), Ib.tolist())]) > 0.999
+	np.testing.assert_allclose(Db, np.take_along_axis(q @ X.T, Ib, axis=1), rtol=2e-5, atol=2e-4)   # reported scores are the true inner products
+	# below the batching threshold the per-query kernel runs on the fp32 lists: same answer
+	Dc, Ic = b.search(q[:50], k)
+	np.testing.assert_allclose(Dc, Db[:50], rtol=2e-5, atol=2e-4)
+	# device-resident entry point: same results, tensors on the device
+	v, i = b.search_device(torch.as_tensor(q).cuda(), k)
+	assert v.is_cuda and i.is_cuda and np.array_equal(i.cpu().numpy().astype(np.int64), Ib)
+
+
 def test_ivf_spherical_kmeans_keeps_lists_balanced_on_varying_norms(gpu):
 	"""FAISS' IndexIVF trains its inner-product quantiser with cp.spherical = true: centroids are renormalised (fvec_renorm_L2) after
 	every update.  With arg-max inner-product assignment an unnormalised mean of large-norm points keeps attracting points: on vectors

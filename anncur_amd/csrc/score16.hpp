@@ -30,8 +30,7 @@ struct Fused16Cfg {
 	static constexpr int CPR = KP / 8;
 	static constexpr int TILE_BYTES = TILE_I * KP * 2;
 	static constexpr int QCAP = 1024;                // entries of a wave's queue
-	static constexpr int DRAIN_AT = 192;             // without a drain schedule (p.drain_tiles = 0): a step drains at its head from this fill on
-	static constexpr int DRAIN_HARD = 320;           // with one: the unscheduled drain of a wave whose queue ran ahead of the plan (<= QCAP - 640: see w.limit)
+	static constexpr int DRAIN_AT = 192;             // a step drains at its head from this fill on (three full passes; 128 / 320 measured: see DESIGN 4.1)
 	static constexpr int QUEUE_OFF = 2 * TILE_BYTES;
 	static constexpr int CNT_OFF = QUEUE_OFF + 4 * QCAP * 8;        // 256 per-query candidate counts of this item split
 	static constexpr int TICKET_OFF = CNT_OFF + 256 * 4;            // ticket words of the dynamic tile schedule (score_kernel)
@@ -144,6 +143,7 @@ __device__ __forceinline__ void stagger16_tile(const uint32_t (&aoff)[Fused16Cfg
 		for (int q = 0; q < 2; ++q) accP[ih][q] = accB[ih][q];
 }
 
+#define S16_SLICED (p.sliced)
 template <int KP>
 __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	using C = Fused16Cfg<KP>;
@@ -204,12 +204,12 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	const bool dyn = p.chunk_tiles > 0;
 	uint32_t ticket_slot = lds_addr(smem + C::TICKET_OFF);
 	// XCD-sliced tickets (score_fused.hip 'XCD-sliced tickets'): thread 0's slice state; unsliced = one counter per row block as in round 3
-	uint32_t *const ctr_rb = p.chunk_ctr + (p.sliced ? (size_t)rb * N_SLICES : (size_t)rb);
-	int slice = p.sliced ? xcc_id() : 0, tried = 0;
+	uint32_t *const ctr_rb = p.chunk_ctr + (S16_SLICED ? (size_t)rb * N_SLICES : (size_t)rb);
+	int slice = S16_SLICED ? xcc_id() : 0, tried = 0;
 	if (dyn) {
 		if (tid == 0) {
 			uint32_t c0, c1;
-			if (p.sliced) {
+			if (S16_SLICED) {
 				c0 = slice_resolve(atomicAdd(ctr_rb + slice, 1u), ctr_rb, p.n_chunks, p.chunks_per_slice, slice, tried);
 				c1 = c0 < (uint32_t)p.n_chunks ? slice_resolve(atomicAdd(ctr_rb + slice, 1u), ctr_rb, p.n_chunks, p.chunks_per_slice, slice, tried) : (uint32_t)p.n_chunks;
 			} else {
@@ -262,16 +262,12 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 #define PH16(i) do { } while (0)
 #define PH16_TILE() do { } while (0)
 #endif
-	// Scheduled drain (round 4).  Round 3 drained a wave's queue when IT held DRAIN_AT entries: every wave in a tile of its own, a few
-	// hundred to 1500 cycles each, while the other three waited at the tile's barrier -- the phase stamps charged the barrier with 633 of
-	// a first-stage tile's 4773 cycles and 308 of a second-stage tile's 2929 ("hit imbalance" in round 3's notes: it was drain imbalance:
-	// 4 waves x one drain every ~7 tiles x ~1400 cycles = 800 expected cycles of waiting per tile).  Now the plan gives the stage a drain
-	// period in tiles (expected fill ~160 entries, half of it in the norm-ordered leading quarter of the first stage) and the four waves
-	// count it down together; a wave whose queue runs ahead of the plan still drains on its own at DRAIN_HARD.
-	const int drain_tiles = p.drain_tiles > 0 ? p.drain_tiles : 0x40000000, drain_dense = p.drain_tiles > 1 ? (p.drain_tiles + 1) / 2 : drain_tiles;
-	const int dense_end = (p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
-	const uint32_t drain_level = w.base + (uint32_t)(p.drain_tiles > 0 ? C::DRAIN_HARD : C::DRAIN_AT) * 8u;
-	int drain_in = t_cur >= 0 && t_cur < dense_end ? drain_dense : drain_tiles;
+	// (Round 4 measured a SCHEDULED drain here -- all four waves of the workgroup draining in the same tile, by a uniform countdown planned for
+	//  ~160 entries, instead of each wave draining when ITS queue holds DRAIN_AT entries: sweep launches 0.4992 ms with it, 0.4893 without,
+	//  0.4888 at a period of 24 tiles; the per-tile barrier wait it was meant to remove is the waves' HIT imbalance, not their drains -- phase
+	//  stamps: barrier 546 -> 441 cycles per first-stage tile, drains 206 -> 274 -- and the countdown's own instructions cost 1.3 % of the
+	//  sweep even when switched off.  Removed; profiles/r04_ring_and_drain_experiments.txt.)
+#define R16_DRAIN_CHECK(J) do { if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill); } while (0)
 #define STAGGER16_STEP(CUR)                                                                                                     \
 	do {                                                                                                                        \
 		const int J = t_cur;                                                                                                    \
@@ -288,11 +284,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		uint32_t ticket = 0;                                                                                                    \
 		if (crossed && tid == 0) ticket_draw(ticket, ctr_rb + slice);                                                           \
 		PH16(0);                                                                                                                \
-		/* Scheduled drain: all four waves drain in the SAME step (a uniform countdown), whatever their fill -- see above */    \
-		if (--drain_in == 0) {                                                                                                  \
-			drain_in = J < dense_end ? drain_dense : drain_tiles;                                                               \
-			if (fill != w.base) wq_drain(w, fill);                                                                              \
-		} else if (fill >= drain_level) wq_drain(w, fill);                                                                      \
+		R16_DRAIN_CHECK(J);                                                                                                     \
 		const uint32_t item0 = ((uint32_t)J * TILE_I + 4 * g4) | lane_code;                                                     \
 		PH16(1);                                                                                                                \
 		stagger16_tile<KP, CUR>(aoff, xb, accP, tau, tau_prev, item0, item0_prev, w, fill);                                        \
@@ -302,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		PH16(3);                                                                                                                \
 		if (crossed) {                                                                                                          \
 			if (tid == 0) {                                                                                                     \
-				if (p.sliced) ticket = slice_resolve(ticket, ctr_rb, p.n_chunks, p.chunks_per_slice, slice, tried);             \
+				if (S16_SLICED) ticket = slice_resolve(ticket, ctr_rb, p.n_chunks, p.chunks_per_slice, slice, tried);             \
 				lds_store_u32(ticket_slot, ticket);                                                                             \
 				if (p.chunk_owner && ticket < (uint32_t)p.n_chunks) p.chunk_owner[(int64_t)rb * p.n_chunks + ticket] = (uint8_t)split; \
 				__builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \

@@ -99,7 +99,6 @@ struct FusedParams {
 	int nseg;                         // candidate segments per query (2 S: 32x32x16 body, lane halves; S: 16x16x32 body)
 	int rb_major;                     // work id -> (row block, split): 1 = row-block-major (dynamic tile schedule), 0 = split-major
 	int flush_tiles;                  // wave-cooperative queue flush period (tiles)
-	int drain_tiles;                  // wave-queue bodies: scheduled drain period in tiles (0: every wave on its own, by fill) -- score16.hpp
 	int debug_nostore;                // timing experiments only: candidates are counted but not stored
 	int debug_stamp;                  // timing experiments only: this launch writes the in-kernel clock stamps
 	float tau_bias;                   // 0 in production; ANNCUR_DEBUG_TAU_BIAS (timing experiments only: results become wrong)
@@ -1555,7 +1554,6 @@ struct FusedPlan {
 	bool ok;
 	int QT, BQ, n_rb, n_tiles, n_full, S, tiles_per_split, group, n_st, S0, st_per_split, n_groups, capg, kmax, flush_tiles;
 	int n_stages, stage_end[3], stage_tps[3], stage_flush[3], stage_pred[3];
-	int stage_drain[3];   // wave-queue bodies: the stage's scheduled drain period in tiles (score16.hpp 'Scheduled drain')
 	int leading;
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
 	bool body16;  // the sweep stages run score16_kernel
@@ -1644,11 +1642,6 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		// 0.84 vs 0.88; I = 10^6, Kp = 256 (P ~ 0.2 over most of the sweep) 2.80 vs 2.76 -> exec above P = 0.25.
 		// (staggered Kp <= 256 loop only: launch_fused ignores it elsewhere)
 		P.stage_pred[i] = (1.0 - exp(-4.0 * rate)) > 0.25 ? 1 : 0;
-		// Scheduled drain of the wave-queue bodies (score16.hpp): 0 = off.  Round 4 measured it (all four waves of a workgroup drain in the
-		// same tile, period planned for ~160 entries): cfg2 sweep launches 0.4992 ms with it, 0.4893 without, 0.4888 at a period of 24 tiles
-		// (same box, one process, interleaved) -- the per-tile barrier wait it was meant to remove is the waves' HIT imbalance, not their
-		// drains (phase stamps: barrier 546 -> 441 cycles per first-stage tile, but the drains themselves 206 -> 274: more, emptier passes).
-		P.stage_drain[i] = 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		if (const char *dbg = getenv("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = atoi(dbg) != 0;
 #endif
@@ -2033,10 +2026,6 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		EV(5 + 2 * stg);
 		p.tile_begin = prev; p.tile_end = P.stage_end[stg]; p.tiles_per_split = P.stage_tps[stg];
 		p.flush_tiles = P.stage_flush[stg]; p.carry = stg > 0;
-		p.drain_tiles = P.stage_drain[stg];
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-		if (const char *dbg = getenv("ANNCUR_DEBUG_DRAIN_TILES")) p.drain_tiles = atoi(dbg);   // 0: round 3's per-wave drain by fill
-#endif
 		p.tile_step = tile_step;
 		if (chunk > 0) {
 			// (row-block-major work ids -- the workgroups of a row block on ONE XCD -- were measured for the ticket schedule, round 3, one box:
@@ -2047,9 +2036,12 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 #endif
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
 			// XCD-sliced tickets: the wave-queue bodies (Kp = 512: the shape whose sweep was close to the fabric's bandwidth; Kp <= 256: traffic only); [row block][slice] counters
-			p.sliced = (P.bodyq1 || P.bodyq16 || (P.body16 && !P.ring16)) ? 1 : 0;
+			// (Kp <= 256: measured at cfg2, one process, interleaved -- sweep launches 0.5030 ms sliced vs 0.4914 unsliced, bare loops level:
+			//  there the fabric is nowhere near its limit and the steals' blocking atomics cost more than the traffic they save (328 -> 180 MB
+			//  per launch); the score16 body keeps the code path (ANNCUR_DEBUG_SLICED=2 in the experiments build) but runs unsliced)
+			p.sliced = (P.bodyq1 || P.bodyq16) ? 1 : 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-			if (const char *dbg = getenv("ANNCUR_DEBUG_SLICED")) p.sliced = p.sliced && atoi(dbg) != 0;
+			if (const char *dbg = getenv("ANNCUR_DEBUG_SLICED")) p.sliced = (atoi(dbg) == 2 && P.body16 && !P.ring16) ? 1 : (p.sliced && atoi(dbg) != 0);
 #endif
 			p.chunks_per_slice = (p.n_chunks + N_SLICES - 1) / N_SLICES;
 			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb * N_SLICES;

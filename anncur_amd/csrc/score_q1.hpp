@@ -150,10 +150,6 @@ __global__ __launch_bounds__(256, 2) void scoreq1_kernel(const FusedParams p) {
 	for (int s = 0; s < 8; ++s) aoff8[s] = lds_addr(smem) + (uint32_t)(r * CPR + ((2 * s + h) ^ (r & 15))) * 16u;
 	const uint32_t lane_code = (uint32_t)r << WQ_ITEM_BITS;
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger1q_tile() counts LDS reads
-	// scheduled drain (score16.hpp 'Scheduled drain'): the plan's period in tiles, halved in the norm-ordered leading quarter of the first stage
-	const int drain_tiles = p.drain_tiles > 0 ? p.drain_tiles : 0x40000000, drain_dense = p.drain_tiles > 1 ? (p.drain_tiles + 1) / 2 : drain_tiles;
-	const int dense_end = (p.sample_leading && !p.carry) ? p.tile_begin + (p.tile_end - p.tile_begin + 3) / 4 : p.tile_begin;
-	int drain_in = t_cur >= 0 && t_cur < dense_end ? drain_dense : drain_tiles;
 #define Q1_STEP(CUR, ACC, ACCP)                                                                                                 \
 	do {                                                                                                                        \
 		const int J = t_cur;                                                                                                    \
@@ -169,10 +165,7 @@ __global__ __launch_bounds__(256, 2) void scoreq1_kernel(const FusedParams p) {
 		if (nx >= 0) tile_dma_s<KP>(p.Et, nx, lds_base + ((CUR) ^ 1) * C::TILE_BYTES, wave_u, dma_off);                         \
 		uint32_t ticket = 0;                                                                                                    \
 		if (crossed && tid == 0) ticket_draw(ticket, ctr_rb + slice);                                                           \
-		if (--drain_in == 0) {  /* scheduled drain: the four waves together (score16.hpp) */                                     \
-			drain_in = J < dense_end ? drain_dense : drain_tiles;                                                               \
-			if (fill != w.base) wq_drain(w, fill);                                                                              \
-		} else if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                        \
+		if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                               \
 		stagger1q_tile<KP, CUR>(aoff8, xb, ACC, ACCP, tau_prev, item0_prev, w, fill);                                           \
 		tau_prev = tau; item0_prev = ((uint32_t)J * TILE_I + 4 * h) | lane_code;                                                \
 		ticket_wait(ticket);                                                                                                    \

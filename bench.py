@@ -509,6 +509,23 @@ def run_config(args, cfg_name, ctx, light=False):
 	CURApprox(rows=A_train, cols=ops.gather_cols(A_train, anc_dev), row_idxs=np.arange(cfg["Kq"]), col_idxs=anc,
 			  approx_preference="rows", compute_dtype="bf16", pinv_backend="numpy")
 	torch.cuda.synchronize(); index_build_numpy_s = time.perf_counter() - t0
+	# one grid cell of entry point A (crossenc.py:84-147: retrieval + per-row error terms): anncur_eval_fused (ONE sweep, round 4) against the
+	# two-kernel route (fused top-k + error kernel); HIP events, eager launches; the exact scan of the cell is exact_scan above
+	entry_a = None
+	if not light and ops.eval_fused_ok(Kp, A_test, Q, I, kr):
+		def _timed(fn, n=max(5, min(args.steps, 20))):
+			for _ in range(2): fn()
+			ev[0].record()
+			for _ in range(n): fn()
+			ev[1].record(); torch.cuda.synchronize()
+			return ev[0].elapsed_time(ev[1]) / n
+		one_ms = _timed(lambda: ops.eval_fused(Xq, cur._Etp, A_test, I, kr))
+		two_ms = _timed(lambda: (ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids), ops.approx_error_packed(Xq, cur._Etp, A_test, I)))
+		err_ms = _timed(lambda: ops.approx_error_packed(Xq, cur._Etp, A_test, I))
+		entry_a = {"eval_fused_ms": one_ms, "two_kernel_route_ms": two_ms, "error_kernel_alone_ms": err_ms, "exact_scan_ms": scan_ms,
+				   "cell_kernels_ms": one_ms + scan_ms, "cell_kernels_two_kernel_route_ms": two_ms + scan_ms,
+				   "what": "retrieval (prepass, threshold, sweep stages, refinement, select) + per-row sum (S_hat - A)^2, sum A^2 of one entry-A grid cell at this size; "
+						   "eval_fused = one S_hat GEMM per sweep stage (csrc/score_evalf.hpp), two-kernel route = the fused top-k and error_lds_kernel (two S_hat GEMMs)"}
 	plan_now = ops.fused_plan(Q, I, Kp, kr, leading_sample=True)
 	n_sweep = max(1, int(round(stage[5])))                 # the sweep runs as n_sweep launches of the same kernel (threshold refined in between)
 	sweep_flops = 2.0 * Q * Kp * I / n_sweep               # algorithmic flops per launch (average over the stages)
@@ -536,7 +553,7 @@ def run_config(args, cfg_name, ctx, light=False):
 			import csv
 			tot_ns = calls = 0
 			for r_ in csv.DictReader(open(sfile)):
-				if any(nm in r_["Name"] for nm in (f"score16_kernel<{Kp}>", f"scoreq16_kernel<{Kp}>", f"scoreq1_kernel<{Kp}>", f"score_kernel<{Kp}, 1, ")):
+				if any(nm in r_["Name"] for nm in (f"score16_kernel<{Kp}>", f"score16r_kernel<{Kp}>", f"scoreq16_kernel<{Kp}>", f"scoreq1_kernel<{Kp}>", f"score_kernel<{Kp}, 1, ")):
 					tot_ns += float(r_["TotalDurationNs"]); calls += int(r_["Calls"])
 			if calls:
 				rocprof_ms, rocprof_src = tot_ns / calls / 1e6, os.path.basename(sfile)
@@ -561,7 +578,7 @@ def run_config(args, cfg_name, ctx, light=False):
 					   "parallelism": f"row-sharded x{world}, index replicated (one RCCL all-gather of anchor rows at build time)"},
 			"recall": recall,
 			"roofline": {"bound": "mfma", "kernel": "sweep stages (fused S_hat GEMM + threshold filter): " + " + ".join(
-							 ({2: f"score16_kernel<{Kp}>", 3: f"scoreq1_kernel<{Kp}>", 4: f"scoreq16_kernel<{Kp}>"}.get(b, f"score_kernel<{Kp},sweep>")) for b in plan_now["stage_pred"]),
+							 ({2: f"score16_kernel<{Kp}>", 3: f"scoreq1_kernel<{Kp}>", 4: f"scoreq16_kernel<{Kp}>", 5: f"score16r_kernel<{Kp}>"}.get(b, f"score_kernel<{Kp},sweep>")) for b in plan_now["stage_pred"]),
 						 "achieved": sweep_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": sweep_tflops / PEAK_BF16_TFLOPS,
 						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(sweep_ms), "launches_per_step": n_sweep,
 						 "frac_rocprof": (sweep_flops / (rocprof_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if rocprof_ms else None), "avg_launch_ms_rocprof": rocprof_ms,
@@ -571,7 +588,12 @@ def run_config(args, cfg_name, ctx, light=False):
 							  "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
 							  "frac": scan_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
 			"stage_ms": {"gather_cols": gath_ms, "prepass": float(stage[0]), "threshold": float(stage[1]), "sweep": float(stage[2]), "sweep_kernels_only": float(stage[4]),
-						 "select": float(stage[3]), "exact_scan": scan_ms},
+						 "select": float(stage[3]), "exact_scan": scan_ms,
+						 # the retrieval chain's launches one after the other vs the step as timed: what the scan's placement and the pipelining of
+						 # consecutive steps actually hide (chain + scan - step; the overlap count and the D2H ride in the step only)
+						 "chain_sum": float(gath_ms + stage[0] + stage[1] + stage[2] + stage[3]), "chain_plus_scan": float(gath_ms + stage[0] + stage[1] + stage[2] + stage[3] + scan_ms),
+						 "hidden_by_overlap": float(gath_ms + stage[0] + stage[1] + stage[2] + stage[3] + scan_ms - ms_per_step)},
+			"entry_A_cell": entry_a,
 			# the sweep launch by launch: tiles swept, duration and MFMA rate of each stage (the first one runs against the prepass threshold)
 			"sweep_stages": [{"tiles": int(t1 - t0), "ms": float(stage[6 + g]), "tflops": 2.0 * Q * Kp * 32.0 * (t1 - t0) / (max(float(stage[6 + g]), 1e-9) * 1e-3) / 1e12}
 							 for g, (t0, t1) in enumerate(zip([0] + plan_now["stage_end"][:-1], plan_now["stage_end"]))],

@@ -4,7 +4,7 @@
 # (the program itself follows `--`: no env / bash -c hop under rocprofv3; counters are collected in their own runs with
 #  --kernel-trace only, one counter group per pass)
 set -e
-tag=${1:-r03x}
+tag=${1:-r04x}
 cfg=${2:-cfg2}
 out=gpurun_out/prof_$tag
 mkdir -p $out

@@ -23,8 +23,10 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int KP>
+template <int KP, int NW = 4>
 struct Fused16Cfg {
+	static constexpr int WAVES = NW;                 // waves per workgroup: 4 (256 queries, two workgroups per CU) or 8 (512 queries, one per CU: the tile is staged
+	                                                 // once per 512 queries -- half the DMA pieces per wave and half the L2 -> LDS traffic; round 4, see score16_kernel)
 	static constexpr int KS32 = KP / 32;             // MFMA k-steps
 	static constexpr int K = KP / 16;                // stagger steps per half = (k-step, item half) pairs
 	static constexpr int CPR = KP / 8;
@@ -32,10 +34,12 @@ struct Fused16Cfg {
 	static constexpr int QCAP = 1024;                // entries of a wave's queue
 	static constexpr int DRAIN_AT = 192;             // a step drains at its head from this fill on (three full passes; 128 / 320 measured: see DESIGN 4.1)
 	static constexpr int QUEUE_OFF = 2 * TILE_BYTES;
-	static constexpr int CNT_OFF = QUEUE_OFF + 4 * QCAP * 8;        // 256 per-query candidate counts of this item split
-	static constexpr int TICKET_OFF = CNT_OFF + 256 * 4;            // ticket words of the dynamic tile schedule (score_kernel)
+	static constexpr int CNT_OFF = QUEUE_OFF + NW * QCAP * 8;       // 64 NW per-query candidate counts of this item split
+	static constexpr int TICKET_OFF = CNT_OFF + NW * 64 * 4;        // ticket words of the dynamic tile schedule (score_kernel)
+	static constexpr int PIECES = TILE_BYTES / 1024 / NW;           // DMA pieces per wave and tile
+	static_assert(PIECES >= 1, "a tile holds at least one 1 KB piece per wave");
 	static constexpr int LDS_BYTES = TICKET_OFF + 16;
-	static constexpr int BQ = 256;
+	static constexpr int BQ = 64 * NW;
 };
 constexpr uint32_t WQ_ITEM_BITS = 26, WQ_ITEM_MASK = (1u << WQ_ITEM_BITS) - 1u;
 
@@ -144,9 +148,9 @@ __device__ __forceinline__ void stagger16_tile(const uint32_t (&aoff)[Fused16Cfg
 }
 
 #define S16_SLICED (p.sliced)
-template <int KP>
-__global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
-	using C = Fused16Cfg<KP>;
+template <int KP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p) {
+	using C = Fused16Cfg<KP, NW>;
 	constexpr int K = C::K, KS32 = C::KS32, CPR = C::CPR;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -229,9 +233,25 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		t_cend = min(t_cur + p.chunk_tiles, p.tile_end);
 		t_next_chunk = c1 < (uint32_t)p.n_chunks ? p.tile_begin + (int)c1 * p.chunk_tiles : -1;
 	}
-	uint32_t dma_off[C::TILE_BYTES / 4096];
-	tile_dma_offsets<KP>(dma_off, wave_u, lane);
-	if (t_cur >= 0) tile_dma_s<KP>(p.Et, t_cur, lds_base, wave_u, dma_off);
+	// DMA: piece wave * PIECES + i of a tile covers LDS chunks piece * 64 + lane of the tile image (swizzle on the source address: tile_dma_offsets)
+	uint32_t dma_off[C::PIECES];
+#pragma unroll
+	for (int i = 0; i < C::PIECES; ++i) {
+		const int pch = (wave_u * C::PIECES + i) * 64 + lane;
+		const int row = pch / CPR, cs = pch % CPR;
+		dma_off[i] = (uint32_t)(row * CPR + swz<CPR>(row, cs)) * 16u;
+	}
+	auto tile_dma_w = [&](int tile, uint32_t lds_buf) {
+		const unsigned char *src = reinterpret_cast<const unsigned char *>(p.Et) + (int64_t)tile * C::TILE_BYTES;  // (uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+		for (int i = 0; i < C::PIECES; ++i) {
+			const uint32_t m0v = lds_buf + (uint32_t)(wave_u * C::PIECES + i) * 1024u;
+			asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(dma_off[i]), "s"(src) : "memory", "m0");
+		}
+#endif
+	};
+	if (t_cur >= 0) tile_dma_w(t_cur, lds_base);
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
 
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 		int nx = J + 1;                                                                                                         \
 		bool crossed = false;                                                                                                   \
 		if (nx >= t_cend) { nx = t_next_chunk; crossed = dyn && nx >= 0; }                                                      \
-		if (nx >= 0) tile_dma_s<KP>(p.Et, nx, lds_base + ((CUR) ^ 1) * C::TILE_BYTES, wave_u, dma_off);                         \
+		if (nx >= 0) tile_dma_w(nx, lds_base + ((CUR) ^ 1) * C::TILE_BYTES);                                                    \
 		uint32_t ticket = 0;                                                                                                    \
 		if (crossed && tid == 0) ticket_draw(ticket, ctr_rb + slice);                                                           \
 		PH16(0);                                                                                                                \
@@ -319,8 +339,8 @@ __global__ __launch_bounds__(256, 2) void score16_kernel(const FusedParams p) {
 	}
 #undef STAGGER16_STEP
 #ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (lane == 0 && d_sweep_stamps && p.debug_stamp && blockIdx.x * 4 + wave < 8192) {
-		unsigned long long *ph = d_sweep_stamps + 5 * 8192 + (size_t)(blockIdx.x * 4 + wave) * 8;
+	if (lane == 0 && d_sweep_stamps && p.debug_stamp && blockIdx.x * NW + wave < 8192) {
+		unsigned long long *ph = d_sweep_stamps + 5 * 8192 + (size_t)(blockIdx.x * NW + wave) * 8;
 		for (int i = 0; i < 5; ++i) ph[i] = ph_acc[i];
 		ph[5] = ph_tiles;
 	}

@@ -1558,6 +1558,7 @@ struct FusedPlan {
 	int lg;   // candidate segments per query and item split: 2 (32x32x16 sweep: lane halves), 1 (16x16x32 sweep: wave-level queue)
 	bool body16;  // the sweep stages run score16_kernel
 	bool bodyef;  // the sweep stages run evalf_kernel (anncur_eval_fused: candidates + error sums in one pass; 32x32x16, wave queue, static shares)
+	bool wg8;     // ... score16_kernel<Kp, 8>: the same body in 8-wave workgroups of BQ_s = 512 queries, one per CU (half the DMA pieces per wave)
 	bool ring16;  // ... score16r_kernel: 8-wave workgroups of BQ_s = 512 queries, flag-synchronised tile ring (score16r.hpp)
 	int BQ_s, n_rb_s;   // query rows per sweep workgroup and the sweep's row blocks (the prepass keeps BQ / n_rb)
 	bool bodyq1;  // the sweep stages run scoreq1_kernel (Kp = 512)
@@ -1710,9 +1711,13 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_RING16")) P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && atoi(dbg) != 0;
 #endif
-	P.BQ_s = P.ring16 ? 512 : P.BQ;
+	P.wg8 = false;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_WG8")) P.wg8 = P.body16 && !P.ring16 && KP >= 128 && atoi(dbg) != 0;
+#endif
+	P.BQ_s = (P.ring16 || P.wg8) ? 512 : P.BQ;
 	P.n_rb_s = (int)ceil_div64(Q, P.BQ_s);
-	const int slots_s = P.ring16 ? num_cu() : slots;   // sweep workgroups resident at once
+	const int slots_s = (P.ring16 || P.wg8) ? num_cu() : slots;   // sweep workgroups resident at once
 	int S = P.chunk > 0 ? (slots_s + P.n_rb_s - 1) / P.n_rb_s : slots_s / P.n_rb_s;
 	if (P.chunk > 0 && k <= WQ_K2 && S > WAVE / 2) S = WAVE / 2;
 	if (S < 1) S = 1;
@@ -2088,6 +2093,19 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 				launched = true;
 			}
 		}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		// score16_kernel<Kp, 8>: the barrier body in 8-wave workgroups (512 queries, one per CU: half the DMA pieces per wave).  Measured (round 4,
+		// one process): sweep launches 0.5125 vs 0.4874 ms, bare 0.436 vs 0.395 -- with both waves of a SIMD in ONE workgroup the partners run in
+		// lockstep through DMA issue, barrier and MFMA section; two independent 4-wave workgroups per CU are 10 % faster.  Experiments build only.
+		if constexpr (KP >= 128 && KP <= 256 && QTV == 2) {
+			if (!launched && P.body16 && P.wg8) {
+				constexpr int lds8 = Fused16Cfg<KP, 8>::LDS_BYTES;
+				if ((rc = anncur_ensure_dyn_lds((const void *)score16_kernel<KP, 8>, lds8)) != ANNCUR_OK) return rc;
+				hipLaunchKernelGGL((score16_kernel<KP, 8>), dim3(p.n_wg), dim3(512), lds8, st, p);
+				launched = true;
+			}
+		}
+#endif
 		if constexpr (KP <= 256 && QTV == 2) {  // 16x16x32 sweep (score16.hpp): one segment per (query, item split)
 			if (!launched && P.body16) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score16_kernel<KP>, Fused16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;

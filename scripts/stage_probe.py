@@ -19,10 +19,10 @@ Kp = ops.padded_k(K)
 Etp, ids = _norm_sorted_pack(E.t().contiguous().float(), Kp)
 Xp = ops.pack_bf16(X, Kp)
 del Z, E
-KNOBS = ["ANNCUR_DEBUG_CHUNK", "ANNCUR_DEBUG_STAGES", "ANNCUR_DEBUG_ALL_PRED", "ANNCUR_DEBUG_TAU_BIAS", "ANNCUR_DEBUG_FLUSH_TILES", "ANNCUR_DEBUG_NOSTORE", "ANNCUR_DEBUG_CONTIG", "ANNCUR_DEBUG_RING_STAGGER", "ANNCUR_DEBUG_RING_SLEEP", "ANNCUR_DEBUG_SLICED"]
+KNOBS = ["ANNCUR_DEBUG_CHUNK", "ANNCUR_DEBUG_STAGES", "ANNCUR_DEBUG_ALL_PRED", "ANNCUR_DEBUG_TAU_BIAS", "ANNCUR_DEBUG_FLUSH_TILES", "ANNCUR_DEBUG_NOSTORE", "ANNCUR_DEBUG_CONTIG", "ANNCUR_DEBUG_RING_STAGGER", "ANNCUR_DEBUG_RING_SLEEP", "ANNCUR_DEBUG_SLICED", "ANNCUR_DEBUG_WG8"]
 def S(name, flags=None, **env):
 	return (name, {("ANNCUR_DEBUG_" + a.upper()): str(b) for a, b in env.items()}, flags or {})
-settings = [S("default"), S("unsliced", sliced=0), S("bare unsliced", sliced=0, tau_bias="1e30"), S("stag=10", {"ring": True}, ring_stagger=10), S("stag=20", {"ring": True}, ring_stagger=20), S("stag=30", {"ring": True}, ring_stagger=30), S("stag=20 nosleep", {"ring": True}, ring_stagger=20, ring_sleep=0), S("nosleep", {"ring": True}, ring_sleep=0), S("bare stag=20", {"ring": True}, ring_stagger=20, tau_bias="1e30"), S("ring", {"ring": True}), S("bare ring", {"ring": True}, tau_bias="1e30"), S("mfma32", {"mfma32": True}), S("bare mfma32", {"mfma32": True}, tau_bias="1e30"), S("static", chunk=0), S("chunk=3", chunk=3), S("chunk=5", chunk=5), S("chunk=6", chunk=6), S("chunk=8", chunk=8), S("mfma16", {"mfma16": True}), S("qt1", {"qt1": True}),
+settings = [S("default"), S("wg8", wg8=1), S("bare wg8", wg8=1, tau_bias="1e30"), S("unsliced", sliced=0), S("bare unsliced", sliced=0, tau_bias="1e30"), S("stag=10", {"ring": True}, ring_stagger=10), S("stag=20", {"ring": True}, ring_stagger=20), S("stag=30", {"ring": True}, ring_stagger=30), S("stag=20 nosleep", {"ring": True}, ring_stagger=20, ring_sleep=0), S("nosleep", {"ring": True}, ring_sleep=0), S("bare stag=20", {"ring": True}, ring_stagger=20, tau_bias="1e30"), S("ring", {"ring": True}), S("bare ring", {"ring": True}, tau_bias="1e30"), S("mfma32", {"mfma32": True}), S("bare mfma32", {"mfma32": True}, tau_bias="1e30"), S("static", chunk=0), S("chunk=3", chunk=3), S("chunk=5", chunk=5), S("chunk=6", chunk=6), S("chunk=8", chunk=8), S("mfma16", {"mfma16": True}), S("qt1", {"qt1": True}),
 			S("static f=.22 p0", chunk=0, stages="0.22", all_pred=0), S("static bare", chunk=0, tau_bias="1e30"),
 			S("pred=0", all_pred=0), S("pred=1", all_pred=1),
 			S("1 stage", stages="1"), S("f=.06", stages="0.06"), S("f=.10", stages="0.10"), S("f=.15", stages="0.15"), S("f=.22", stages="0.22"), S("f=.30", stages="0.30"),

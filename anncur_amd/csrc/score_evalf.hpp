@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 		__builtin_amdgcn_s_barrier();                                                                                           \
 		asm volatile("" ::: "memory");                                                                                          \
 	} while (0)
+	ANNCUR_PAD_HERE();
 	for (int j = j_begin; j < j_end; j += 2) {
 		EVALF_STEP(0, j);
 		if (j + 1 < j_end) EVALF_STEP(1, j + 1);

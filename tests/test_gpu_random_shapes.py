@@ -99,7 +99,7 @@ def test_rowwise_topk_gather_random(ops, Q, I, kfrac, bf16, nfrac, kind, pad, se
 
 @settings(max_examples=(_N // 4) or 25, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(Q=st.integers(1, 300), I=st.integers(2500, 90000), K=st.integers(8, 512), k=st.integers(1, 200), rank=st.integers(2, 48),
-	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), variant=st.sampled_from(["", "", "mfma16", "qt1", "mfma32"]))
+	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), variant=st.sampled_from(["", "", "mfma16", "qt1", "mfma32", "ring"]))
 def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	g = torch.Generator().manual_seed(seed)
 	X = torch.randn(Q, K, generator=g).bfloat16()
@@ -108,9 +108,11 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	if not ops.fused_supported(Q, I, Kp, k):
 		return
 	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
-	kw = dict(mfma16=variant == "mfma16", qt1=variant == "qt1", mfma32=variant == "mfma32")
+	kw = dict(mfma16=variant == "mfma16", qt1=variant == "qt1", mfma32=variant == "mfma32", ring=variant == "ring")
 	plan = ops.fused_plan(Q, I, Kp, k, **kw)
-	if Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = 16x16x32 up to k = 128)
+	if variant == "ring":   # (round 4) the tile-ring body runs where the 16x16x32 body would: Kp = 128 / 256, k <= 128
+		assert all(b == 5 for b in plan["stage_pred"]) == (Kp in (128, 256) and k <= 128), plan
+	elif Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = 16x16x32 up to k = 128)
 		want_lg = {"mfma16": (1,), "mfma32": (2,), "qt1": (2,) if Kp >= 128 else (1, 2), "": (1, 2)}[variant]   # (qt1 at Kp = 64: no such body, the default runs)
 		assert plan["lg"] in want_lg and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
 	v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)   # (sweep variants: same answer)
@@ -124,6 +126,37 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	assert ((v[:, :-1] >= v[:, 1:]).all())                       # sorted descending
 	# every selected item beats (up to fp32 round-off) the true k-th score
 	assert (torch.gather(S, 1, got).min(dim=1).values >= rv[:, -1] - 1e-4 * scale).all()
+
+
+@settings(max_examples=(_N // 6) or 16, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(Q=st.integers(1, 700), I=st.integers(2500, 90000), K=st.integers(8, 256), k=st.integers(1, 300), rank=st.integers(2, 48),
+	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), pad=st.integers(0, 3))
+def test_eval_fused_random(ops, Q, I, K, k, rank, noise, seed, pad):
+	"""anncur_eval_fused (round 4: candidates + error sums of entry A's cell in ONE sweep) on random shapes, pitches and score
+	distributions, against fp64: the top-k as the fused top-k's fuzz checks it, the two sums to 1e-4."""
+	g = torch.Generator().manual_seed(seed)
+	X = torch.randn(Q, K, generator=g).bfloat16()
+	E = (torch.randn(K, rank, generator=g) @ torch.randn(rank, I, generator=g) / rank ** 0.5 + noise * torch.randn(K, I, generator=g)).bfloat16()
+	A = (X.float() @ E.float() + 0.5 * torch.randn(Q, I, generator=g)).bfloat16()
+	Kp = ops.padded_k(K)
+	lda = -(-I // 8) * 8 + 8 * pad
+	Ap = torch.zeros((Q, lda), dtype=torch.bfloat16, device="cuda"); Ap[:, :I] = A.cuda(); Ad = Ap[:, :I]
+	if not ops.eval_fused_ok(Kp, Ad, Q, I, k):
+		return
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	(v, i), err, nrm, nfb = ops.eval_fused(Xp, Etp, Ad, I, k, return_fallbacks=True)
+	assert nfb.item() < (1 << 30)
+	S = X.double() @ E.double()
+	rv, ri = torch.topk(S, k, dim=1)
+	scale = float(S.abs().max()) + 1e-30
+	got = i.cpu().long()
+	assert (got >= 0).all() and (got < I).all() and all(len(set(r.tolist())) == k for r in got)
+	assert (v.cpu().double() - rv).abs().max() <= 1e-4 * scale
+	assert ((v[:, :-1] >= v[:, 1:]).all())
+	assert (torch.gather(S, 1, got).min(dim=1).values >= rv[:, -1] - 1e-4 * scale).all()
+	A64 = A.double()
+	torch.testing.assert_close(err.cpu().double(), ((S - A64) ** 2).sum(1), rtol=1e-4, atol=1e-4 * scale * scale)
+	torch.testing.assert_close(nrm.cpu().double(), (A64 ** 2).sum(1), rtol=1e-4, atol=1e-6)
 
 
 @settings(max_examples=(_N // 8) or 12, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])

@@ -162,16 +162,66 @@ __global__ __launch_bounds__(SEL_THREADS) void ivf_scan_kernel(const float *__re
 // S[pair][position in its list] (row pitch lmax, the caller pre-fills -inf), i.e. query q's row of S holds its nprobe lists side by
 // side: anncur_rowwise_topk over [nq x nprobe * lmax] + ivf_map_ids_kernel finish the search.
 constexpr int GT = 64, GK = 16, GP = GT + 1;   // tile edge, k-tile depth, LDS pitch (k-major tiles as in gemm.hip)
+
+// Device-built tile worklist (round 4).  Round 3 copied the pairs-per-list counts to the host, enumerated the (list, query tile, vector tile)
+// triples there and copied them back: a device synchronisation in the middle of every search.  Now tile_start[l] = number of tiles of the
+// lists before l (ivf_tile_starts_kernel: one workgroup, nlist is ~sqrt(n)); the GEMM is launched with an upper bound on the tile count
+// that the host knows without looking at the counts, and workgroup b finds its triple by a binary search (b >= tile_start[nlist]: exit).
+__global__ __launch_bounds__(256) void ivf_tile_starts_kernel(const int32_t *__restrict__ pair_off, const int32_t *__restrict__ offsets, int32_t nlist,
+															   int32_t *__restrict__ tile_start) {
+	__shared__ int32_t carry;
+	__shared__ int32_t wsum[4];
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int32_t b = 0; b < nlist; b += 256) {
+		const int32_t l = b + threadIdx.x;
+		int32_t c = 0;
+		if (l < nlist) {
+			const int32_t qt = (pair_off[l + 1] - pair_off[l] + GT - 1) / GT, vt = (offsets[l + 1] - offsets[l] + GT - 1) / GT;
+			c = qt * vt;
+		}
+		int32_t inc = c;
+		for (int d = 1; d < WAVE; d <<= 1) {
+			const int32_t t = __shfl_up(inc, d);
+			if (lane_id() >= d) inc += t;
+		}
+		if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
+		__syncthreads();
+		int32_t base = carry;
+		for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
+		if (l < nlist) tile_start[l] = base + inc - c;
+		__syncthreads();
+		if (threadIdx.x == 255) carry = base + inc;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) tile_start[nlist] = carry;
+}
+// workgroup b -> (list, query tile, vector tile) from the host-built triples (nlist = 0) or the device-built starts; false: nothing to do
+__device__ __forceinline__ bool ivf_tile_of(const int32_t *__restrict__ tiles, int32_t nlist, const int32_t *__restrict__ offsets, int32_t &l, int32_t &qt, int32_t &vt) {
+	const int32_t b = blockIdx.x;
+	if (nlist <= 0) { l = tiles[3 * b]; qt = tiles[3 * b + 1]; vt = tiles[3 * b + 2]; return true; }
+	if (b >= tiles[nlist]) return false;
+	int32_t lo = 0, hi = nlist;   // largest l with tiles[l] <= b (empty lists repeat their start: the search lands past them)
+	while (hi - lo > 1) {
+		const int32_t mid = (lo + hi) >> 1;
+		if (tiles[mid] <= b) lo = mid; else hi = mid;
+	}
+	l = lo;
+	const int32_t vcnt = (offsets[l + 1] - offsets[l] + GT - 1) / GT, within = b - tiles[l];
+	qt = within / vcnt; vt = within - qt * vcnt;
+	return true;
+}
 typedef __attribute__((ext_vector_type(16))) float f32x16g;
 
 __global__ __launch_bounds__(256) void ivf_group_scores_kernel(const float *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
 																const float *__restrict__ Q, int64_t ldq, int32_t nprobe, const int32_t *__restrict__ pair_ids,
-																const int32_t *__restrict__ pair_off, const int32_t *__restrict__ tiles, int64_t lmax,
+																const int32_t *__restrict__ pair_off, const int32_t *__restrict__ tiles, int32_t nlist, int64_t lmax,
 																float *__restrict__ S) {
 	__shared__ float As[GK * GP], Bs[GK * GP];
 	__shared__ int32_t arow[GT];   // query row of each pair of the tile (-1 past the list's pairs)
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-	const int32_t l = tiles[3 * blockIdx.x], qt = tiles[3 * blockIdx.x + 1], vt = tiles[3 * blockIdx.x + 2];
+	int32_t l, qt, vt;
+	if (!ivf_tile_of(tiles, nlist, offsets, l, qt, vt)) return;   // (uniform: before any barrier)
 	const int32_t p0 = pair_off[l] + qt * GT, p_end = pair_off[l + 1];
 	const int32_t v0 = offsets[l] + vt * GT, v_end = offsets[l + 1];
 	if (tid < GT) arow[tid] = p0 + tid < p_end ? pair_ids[p0 + tid] / nprobe : -1;
@@ -219,12 +269,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8g;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4g;
 __global__ __launch_bounds__(256) void ivf_group_scores_bf16_kernel(const uint16_t *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
 																	 const uint16_t *__restrict__ Q, int64_t ldq, int32_t nprobe, const int32_t *__restrict__ pair_ids,
-																	 const int32_t *__restrict__ pair_off, const int32_t *__restrict__ tiles, int64_t lmax,
+																	 const int32_t *__restrict__ pair_off, const int32_t *__restrict__ tiles, int32_t nlist, int64_t lmax,
 																	 float *__restrict__ S) {
 	__shared__ __attribute__((aligned(16))) u32x4g As[GT * 4], Bs[GT * 4];
 	__shared__ int32_t arow[GT];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-	const int32_t l = tiles[3 * blockIdx.x], qt = tiles[3 * blockIdx.x + 1], vt = tiles[3 * blockIdx.x + 2];
+	int32_t l, qt, vt;
+	if (!ivf_tile_of(tiles, nlist, offsets, l, qt, vt)) return;   // (uniform: before any barrier)
 	const int32_t p0 = pair_off[l] + qt * GT, p_end = pair_off[l + 1];
 	const int32_t v0 = offsets[l] + vt * GT, v_end = offsets[l + 1];
 	if (tid < GT) arow[tid] = p0 + tid < p_end ? pair_ids[p0 + tid] / nprobe : -1;
@@ -292,7 +343,7 @@ extern "C" int anncur_ivf_group_scores(const float *Xs, int64_t ldx, int32_t dp,
 	if (n_tiles == 0) return ANNCUR_OK;
 	ANNCUR_REQUIRE(Xs && offsets && Q && pair_ids && pair_offsets && tiles && S, ANNCUR_E_INVALID, "ivf_group_scores: null pointer");
 	hipLaunchKernelGGL(ivf_group_scores_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, Xs, ldx, dp, offsets, Q, ldq, nprobe, pair_ids,
-					   pair_offsets, tiles, lmax, S);
+					   pair_offsets, tiles, 0, lmax, S);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }
@@ -306,7 +357,29 @@ extern "C" int anncur_ivf_group_scores_bf16(const void *Xs, int64_t ldx, int32_t
 	ANNCUR_REQUIRE(Xs && offsets && Q && pair_ids && pair_offsets && tiles && S && ((uintptr_t)Xs % 16) == 0 && ((uintptr_t)Q % 16) == 0, ANNCUR_E_INVALID,
 				   "ivf_group_scores_bf16: null or misaligned pointer");
 	hipLaunchKernelGGL(ivf_group_scores_bf16_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)Xs, ldx, dp, offsets,
-					   (const uint16_t *)Q, ldq, nprobe, pair_ids, pair_offsets, tiles, lmax, S);
+					   (const uint16_t *)Q, ldq, nprobe, pair_ids, pair_offsets, tiles, 0, lmax, S);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+extern "C" int anncur_ivf_group_scores_dev(const void *Xs, int dtype, int64_t ldx, int32_t dp, const int32_t *offsets, int32_t nlist, const void *Q, int64_t ldq,
+										   int32_t nprobe, const int32_t *pair_ids, const int32_t *pair_offsets, int32_t *tile_start, int32_t max_tiles, int64_t lmax,
+										   float *S, void *stream) {
+	ANNCUR_REQUIRE(dtype_ok(dtype) && dp >= 1 && ldx >= dp && ldq >= dp && nprobe >= 1 && lmax >= 1 && nlist >= 1 && max_tiles >= 0, ANNCUR_E_INVALID,
+				   "ivf_group_scores_dev: bad sizes");
+	ANNCUR_REQUIRE(dtype == ANNCUR_F32 || ((dp % 16) == 0 && (ldx % 8) == 0 && (ldq % 8) == 0 && ((uintptr_t)Xs % 16) == 0 && ((uintptr_t)Q % 16) == 0), ANNCUR_E_INVALID,
+				   "ivf_group_scores_dev: bf16 rows must be zero-padded to a multiple of 16 elements and 16-byte aligned");
+	ANNCUR_REQUIRE(Xs && offsets && Q && pair_ids && pair_offsets && tile_start && S, ANNCUR_E_INVALID, "ivf_group_scores_dev: null pointer");
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL(ivf_tile_starts_kernel, dim3(1), dim3(256), 0, st, pair_offsets, offsets, nlist, tile_start);
+	ANNCUR_LAUNCH_OK();
+	if (max_tiles == 0) return ANNCUR_OK;
+	if (dtype == ANNCUR_F32)
+		hipLaunchKernelGGL(ivf_group_scores_kernel, dim3((unsigned)max_tiles), dim3(256), 0, st, (const float *)Xs, ldx, dp, offsets, (const float *)Q, ldq, nprobe,
+						   pair_ids, pair_offsets, tile_start, nlist, lmax, S);
+	else
+		hipLaunchKernelGGL(ivf_group_scores_bf16_kernel, dim3((unsigned)max_tiles), dim3(256), 0, st, (const uint16_t *)Xs, ldx, dp, offsets, (const uint16_t *)Q, ldq,
+						   nprobe, pair_ids, pair_offsets, tile_start, nlist, lmax, S);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -765,7 +765,8 @@ def ivf_scan(Xs, offsets, ids, Q, probe, k):
 def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 30, lists_bf16=None, profile=None):
 	"""The same search as ivf_scan for MANY queries: pairs (query, probe slot) sorted by list, every list one small fp32-MFMA GEMM against
 	its pairs' queries (anncur_ivf_group_scores), then the exact scan over each query's nprobe lists side by side and the column -> id map.
-	sizes_host: the lists' lengths on the host (numpy int64, known since add()).  One small D2H (pairs per list) builds the tile worklist.
+	sizes_host: the lists' lengths on the host (numpy int64, known since add()); they bound the tile count of the launch, the worklist itself is
+	built on the device (no synchronisation inside the call: the search is stream-ordered like every other op).
 	lists_bf16: a bf16 copy of Xs (same layout) -> the per-list GEMMs run on the bf16 matrix cores (queries rounded to bf16 here).
 	profile: a dict -> receives HIP events around the per-list GEMM launch and around the scan + id map ("events": [(e0, e1, e2), ...] per
 	query chunk; measurement only: bench.py's kernel-only IVF figure)."""
@@ -781,36 +782,33 @@ def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 3
 	idx = torch.empty((nq_all, k), dtype=torch.int32, device=Q.device)
 	step = max(64, min(nq_all, max_bytes // (nprobe * lmax * 4)))
 	vt = -(-sizes_host // 64)                                        # 64-vector tiles per list
+	vt_sum, vt_max = int(vt.sum()), int(max(int(vt.max()), 1))
 	for q0 in range(0, nq_all, step):
 		q1 = min(nq_all, q0 + step)
 		nq = q1 - q0
 		pr = probe[q0:q1].contiguous()
 		cnt, poff, pair_ids = ivf_build_lists(pr.reshape(-1).clamp(min=0), nlist)     # (probe slots are valid list ids here: nprobe <= nlist)
-		cp = cnt.cpu().numpy().astype(np.int64)
-		qt = -(-cp // 64)
-		lists = np.repeat(np.arange(nlist), qt * vt)
-		if lists.size:
-			start = np.cumsum(qt * vt) - qt * vt
-			within = np.arange(lists.size) - np.repeat(start, qt * vt)
-			tiles = np.stack([lists, within // np.repeat(vt, qt * vt), within % np.repeat(vt, qt * vt)], axis=1).astype(np.int32)
-		else:
-			tiles = np.zeros((0, 3), dtype=np.int32)
-		tiles_dev = torch.as_tensor(tiles).to(Q.device)
+		# tile worklist built on the device (round 4: round 3 copied the pairs-per-list counts to the host here -- a synchronisation in the
+		# middle of every search -- and built the triples in numpy): the launch takes an upper bound on the number of 64 x 64 tiles that
+		# needs no look at the counts, sum_l ceil(pairs_l / 64) vt_l <= (pairs / 64) max vt + sum vt; workgroups past the last tile exit
+		max_tiles = (nq * nprobe // 64) * vt_max + vt_sum
+		tile_start = torch.empty(nlist + 1, dtype=torch.int32, device=Q.device)
 		S = _ScoreScratch.get(nq * nprobe * lmax, Q.device).view(nq, nprobe * lmax)   # grow-only scratch: a fresh 100s-of-MB allocation per call cost more than the search
 		S.fill_(float("-inf"))
 		Qc = Q[q0:q1]
 		if profile is not None:
 			evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 			profile.setdefault("events", []).append(evs)
-			profile.setdefault("tiles", []).append(int(tiles.shape[0]))
+			profile.setdefault("max_tiles", []).append(int(max_tiles))
+			profile.setdefault("tile_starts", []).append(tile_start)
 			evs[0].record()
 		if lists_bf16 is not None:
 			Qb = convert(Qc, torch.bfloat16)
-			check(lib.anncur_ivf_group_scores_bf16(_p(lists_bf16), _ld(lists_bf16), dp, _p(offsets), _p(Qb), _ld(Qb), nprobe, _p(pair_ids), _p(poff), _p(tiles_dev),
-												   tiles.shape[0], lmax, _p(S), _stream()), "ivf_group_scores_bf16")
+			check(lib.anncur_ivf_group_scores_dev(_p(lists_bf16), BF16, _ld(lists_bf16), dp, _p(offsets), nlist, _p(Qb), _ld(Qb), nprobe, _p(pair_ids), _p(poff),
+												  _p(tile_start), max_tiles, lmax, _p(S), _stream()), "ivf_group_scores_dev")
 		else:
-			check(lib.anncur_ivf_group_scores(_p(Xs), _ld(Xs), dp, _p(offsets), _p(Qc), _ld(Qc), nprobe, _p(pair_ids), _p(poff), _p(tiles_dev), tiles.shape[0], lmax,
-											  _p(S), _stream()), "ivf_group_scores")
+			check(lib.anncur_ivf_group_scores_dev(_p(Xs), F32, _ld(Xs), dp, _p(offsets), nlist, _p(Qc), _ld(Qc), nprobe, _p(pair_ids), _p(poff),
+												  _p(tile_start), max_tiles, lmax, _p(S), _stream()), "ivf_group_scores_dev")
 		if profile is not None: evs[1].record()
 		v, c = rowwise_topk(S, k_eff)
 		out_i = idx[q0:q1, :k_eff] if k_eff == k else torch.empty((nq, k_eff), dtype=torch.int32, device=Q.device)

@@ -80,7 +80,7 @@ def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 	"""models/nearest_nbr.py:40-52 at the size of the reference's hard-negative mining (utils/data_process.py:343-365: every mention queries
 	the entity index): n clustered vectors, nlist = floor(sqrt(n)), nprobe = floor(sqrt(nlist)); batched list-grouped search on the matrix
 	cores.  Two figures per index dtype: the whole search() call with host numpy in / out like FAISS (probe, pair sort, host-built tile
-	worklist, copies), and the KERNELS alone on device-resident queries (HIP events around the per-list GEMM launch and around the exact scan
+	copies), and the KERNELS alone on device-resident queries (HIP events around the per-list GEMM launch and around the exact scan
 	of the scores + id map) against the matrix peak of the operand type (fp32: 157 TFLOP/s; bf16 lists: 2500).  Algorithmic flops = 2 x
 	vectors scanned x d; the GEMM launch also multiplies the padding of its 64 x 64 tiles (reported as tile_flops_ratio)."""
 	from anncur_amd import ops
@@ -110,7 +110,7 @@ def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 			index.search_device(q_dev, k, profile=prof)
 			torch.cuda.synchronize()
 			gemm_ms.append(sum(e[0].elapsed_time(e[1]) for e in prof["events"])); scan_ms.append(sum(e[1].elapsed_time(e[2]) for e in prof["events"]))
-			tile_flops = 2.0 * sum(prof["tiles"]) * 64 * 64 * index._dp
+			tile_flops = 2.0 * sum(int(t[-1].item()) for t in prof["tile_starts"]) * 64 * 64 * index._dp   # (the device-built worklist's tile count)
 		gm, sm = float(np.median(gemm_ms)), float(np.median(scan_ms))
 		row = {"nlist": index.nlist, "nprobe": index.nprobe, "build_s": build_s, "search_ms": 1e3 * search_s, "queries_per_s": nq / search_s,
 			   "vectors_scanned_per_query": scanned / nq,
@@ -118,7 +118,7 @@ def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 						   "roofline": {"bound": "mfma", "kernel": "ivf_group_scores_bf16_kernel (bf16 MFMA)" if dtype == "bf16" else "ivf_group_scores_kernel (fp32 MFMA)",
 										"achieved": flops / (gm * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / (gm * 1e-3) / 1e12 / peak,
 										"what": "the per-list GEMM launch alone (HIP events), algorithmic flops = 2 x vectors scanned x d"}},
-			   "whole_call": {"achieved_tflops": flops / search_s / 1e12, "what": "search() incl. probe, pair sort, host-built worklist, exact scan of the scores, host copies"}}
+			   "whole_call": {"achieved_tflops": flops / search_s / 1e12, "what": "search() incl. host numpy in / out (30 MB of queries over PCIe), probe, pair sort, exact scan of the scores"}}
 		if dtype == "fp32":
 			ref_I = I
 		else:
@@ -128,6 +128,14 @@ def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 	out.update({kk: out["fp32"][kk] for kk in ("nlist", "nprobe", "build_s", "search_ms", "queries_per_s", "vectors_scanned_per_query")})
 	out["roofline"] = out["fp32"]["kernels"]["roofline"]
 	return out
+
+
+def _mark(msg):
+	"""Progress marker on stderr (ANNCUR_BENCH_DEBUG): where a run was when it died -- the GPU is synchronised first, so a fault is
+	attributed to the phase before the last marker printed."""
+	if os.environ.get("ANNCUR_BENCH_DEBUG"):
+		torch.cuda.synchronize()
+		print(f"[bench mark] {msg}", file=sys.stderr, flush=True)
 
 
 def run_config(args, cfg_name, ctx, light=False):
@@ -148,10 +156,12 @@ def run_config(args, cfg_name, ctx, light=False):
 	# assembled the way a row-sharded score matrix delivers it: each rank contributes Kq/N anchor rows, one all-gather.
 	# one score model for the whole job (item factors from --seed); every rank draws its own queries and its own share of the anchor rows
 	A_train, A_test = synth_device(cfg, device, args.seed, row_seed=None if world == 1 else args.seed * 1000 + rank + 1)
+	_mark(f"{cfg_name}: data synthesised")
 	allgather_ms = None
 	if use_dist:
 		# the path's ONE collective: every rank owns Kq / N of the anchor rows, an all-gather assembles R [Kq x I] everywhere
 		allgather_anchor_rows(A_train, cfg["Kq"], rank, world)   # warm-up (communicator set-up, buffers)
+		_mark("all-gather warm-up done")
 		torch.distributed.barrier(); torch.cuda.synchronize()
 		t0 = time.perf_counter()
 		A_train = allgather_anchor_rows(A_train, cfg["Kq"], rank, world)
@@ -159,6 +169,7 @@ def run_config(args, cfg_name, ctx, light=False):
 		t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
 		torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
 		allgather_ms = 1e3 * t.item()
+		_mark("timed all-gather + all-reduce done")
 	rng = np.random.default_rng(args.seed)
 	anc = sorted(rng.choice(cfg["I"], size=cfg["Ki"], replace=False))
 	anc_dev = ops.as_index(anc, device)
@@ -171,6 +182,7 @@ def run_config(args, cfg_name, ctx, light=False):
 	cur = build_index()
 	torch.cuda.synchronize()
 	index_build_s = time.perf_counter() - t0
+	_mark("index built")
 	Kp = cur._Etp.shape[1]
 	Q, I, k, kr = cfg["Q"], cfg["I"], cfg["k"], cfg["k_retvr"]
 	assert ops.fused_supported(Q, I, Kp, kr), "headline config must run on the fused path"
@@ -408,14 +420,17 @@ def run_config(args, cfg_name, ctx, light=False):
 			torch.distributed.barrier()
 		torch.cuda.synchronize()
 
+	_mark(f"launcher built ({scan_mode})")
 	launch, graphed = launchers[scan_mode]
 	scan_mode_used = scan_mode
 	res = run_steps(args.warmup)
 	barrier()
+	_mark("warm-up steps done")
 	t0 = time.perf_counter()
 	res = run_steps(args.steps)      # every one of the K steps is launched AND its statistics finished inside the timed region
 	barrier()
 	elapsed = time.perf_counter() - t0
+	_mark("timed steps done")
 	if os.environ.get("ANNCUR_BENCH_DEBUG"):
 		print(f"[bench debug] per step: launch {1e3 * prof['launch'] / (args.steps + args.warmup):.3f} ms, "
 			  f"finish {1e3 * prof['finish'] / (args.steps + args.warmup):.3f} ms (of which event wait {1e3 * prof.get('wait', 0) / (args.steps + args.warmup):.3f} ms, pinned memcpy {1e3 * prof.get('memcpy', 0) / (args.steps + args.warmup):.3f} ms)", file=sys.stderr)
@@ -423,18 +438,31 @@ def run_config(args, cfg_name, ctx, light=False):
 		t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
 		torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
 		elapsed = t.item()
+		_mark("max-over-ranks of the step time done")
 	ms_per_step = 1e3 * elapsed / args.steps
 	value = world * Q * args.steps / elapsed
+	if os.environ.get("ANNCUR_BENCH_NULL_PROBE"):
+		# the repro without RCCL: the NULL-stream work of one device-side reduction (8-byte H2D, D2H, a fill) between two batches of steps
+		with torch.cuda.stream(torch.cuda.default_stream(device)):
+			t = torch.tensor([elapsed], device=device, dtype=torch.float64); t.item()
+			torch.zeros(1, device=device)
+		torch.cuda.synchronize()
+		_mark("null-stream probe: copies done")
+		run_steps(args.steps); torch.cuda.synchronize()
+		_mark("null-stream probe: steps done")
 
 	# the same K steps on rank 0 ALONE (the other ranks wait): the single-GPU rate of this very workload inside the same job, so that
 	# weak-scaling efficiency = value / (N x solo) can be read off one line
 	solo = None
 	if use_dist:
 		barrier()
+		_mark("solo: barrier passed")
 		if rank == 0:
 			t0 = time.perf_counter(); run_steps(args.steps); torch.cuda.synchronize()
 			solo = Q * args.steps / (time.perf_counter() - t0)
+		_mark("solo: steps done")
 		barrier()
+	_mark("solo section done")
 	# sustained: the same step looped for >= 10 s (the timed region above is a burst of K steps; under a long MFMA load the chip
 	# lowers its clock -- MI355X_MICROARCH.md 'DVFS give-back'; long enough for a 5 s utilisation sampler to see the GPU busy)
 	sustained = None
@@ -455,6 +483,7 @@ def run_config(args, cfg_name, ctx, light=False):
 			sus_step = sus_s / n_sus
 		sustained = {"value": world * Q / sus_step, "unit": "queries/s", "ms_per_step": 1e3 * sus_step, "seconds": sus_s, "steps": n_sus}
 
+	_mark("sustained section done")
 	# ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
 	stage = np.zeros(9)
 	Xq = ops.gather_cols(A_test, anc_dev)
@@ -526,6 +555,7 @@ def run_config(args, cfg_name, ctx, light=False):
 				   "cell_kernels_ms": one_ms + scan_ms, "cell_kernels_two_kernel_route_ms": two_ms + scan_ms,
 				   "what": "retrieval (prepass, threshold, sweep stages, refinement, select) + per-row sum (S_hat - A)^2, sum A^2 of one entry-A grid cell at this size; "
 						   "eval_fused = one S_hat GEMM per sweep stage (csrc/score_evalf.hpp), two-kernel route = the fused top-k and error_lds_kernel (two S_hat GEMMs)"}
+	_mark("per-kernel timings done")
 	plan_now = ops.fused_plan(Q, I, Kp, kr, leading_sample=True)
 	n_sweep = max(1, int(round(stage[5])))                 # the sweep runs as n_sweep launches of the same kernel (threshold refined in between)
 	sweep_flops = 2.0 * Q * Kp * I / n_sweep               # algorithmic flops per launch (average over the stages)
@@ -728,6 +758,27 @@ def main():
 	# rank, anchor rows assembled by the one all-gather) whatever N is -- value(N) / value(1) is then a weak-scaling curve of one workload,
 	# and the N = 1 point is the single-GPU bench line.  BASELINE cfg4's per-GPU shape (6 250 x 10^6, 512 anchors) rides along at N > 1 as
 	# the "cfg4" sub-object with its own value, roofline, allgather_ms and solo_rank0.  (--config X: that workload alone, at any N.)
+	# The whole measurement runs with a NON-default stream current.  The scan's CU-masked stream is a blocking stream (the only kind
+	# hipExtStreamCreateWithCUMask makes): anything issued on the NULL stream -- the tiny H2D / D2H copies and the barrier tensor of the
+	# RCCL max-over-ranks reductions between two batches of steps -- synchronises with it implicitly, and graph replays on the masked stream
+	# right after such NULL-stream work ended in a GPU memory access fault (single-rank RCCL run, round 4: 5 of 5 runs; never with the
+	# second-stream placement, never with gloo whose reductions stay on the host).  With a pool stream current, the collectives, their
+	# copies and the per-kernel timings never touch the NULL stream.  ANNCUR_BENCH_DEFAULT_STREAM=1: the old behaviour (for the repro).
+	work_stream = torch.cuda.default_stream(device) if os.environ.get("ANNCUR_BENCH_DEFAULT_STREAM") else torch.cuda.Stream(device=device)
+	torch.cuda.synchronize()
+	with torch.cuda.stream(work_stream):
+		out = _run_all(args, ctx, world, rank)
+	torch.cuda.synchronize()
+	if rank == 0:
+		sys.stdout.flush()
+		os.write(result_fd, (json.dumps(out) + "\n").encode())
+	_mark("result line written")
+	if use_dist:
+		torch.distributed.destroy_process_group()
+	_mark("process group destroyed")
+
+
+def _run_all(args, ctx, world, rank):
 	out = run_config(args, args.config or "cfg2", ctx)
 	if world > 1 and args.config is None:
 		import gc
@@ -737,11 +788,7 @@ def main():
 			out["cfg4"] = {kk: sub.get(kk) for kk in ("value", "unit", "ms_per_step", "n_gpus", "steps", "warmup", "scaling", "config", "recall", "roofline", "roofline_scan",
 														"stage_ms", "sweep_stages", "allgather_ms", "solo_rank0", "scan_mode", "launch_mode", "index_build_s")}
 			out["cfg4"]["what"] = "BASELINE configs[3] (50k x 1M bf16, 512 anchors, 8 GPUs) at its per-GPU shape on every rank, same job, same ranks; weak scaling like the top level"
-	if rank == 0:
-		sys.stdout.flush()
-		os.write(result_fd, (json.dumps(out) + "\n").encode())
-	if use_dist:
-		torch.distributed.destroy_process_group()
+	return out
 
 
 if __name__ == "__main__":

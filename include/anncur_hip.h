@@ -299,6 +299,14 @@ int anncur_ivf_group_scores(const float *Xs, int64_t ldx, int32_t dp, const int3
 int anncur_ivf_group_scores_bf16(const void *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const void *Q, int64_t ldq, int32_t nprobe,
                                  const int32_t *pair_ids, const int32_t *pair_offsets, const int32_t *tiles, int32_t n_tiles, int64_t lmax, float *S,
                                  void *stream);
+/* The same with the tile worklist built ON THE DEVICE (no host look at the pairs-per-list counts, no synchronisation inside a search):
+ * tile_start int32[nlist + 1] is filled here (tile_start[l] = tiles of the lists before l, a tile = 64 pairs x 64 vectors), the GEMM is
+ * launched with max_tiles workgroups -- any upper bound on sum_l ceil(pairs_l / 64) ceil(size_l / 64), e.g.
+ * (n_pairs / 64) * max_l ceil(size_l / 64) + sum_l ceil(size_l / 64) -- and workgroup b finds its (list, pair tile, vector tile) by binary
+ * search; workgroups past the last tile exit.  dtype ANNCUR_F32 (Xs / Q fp32) or ANNCUR_BF16 (bf16 rows as anncur_ivf_group_scores_bf16). */
+int anncur_ivf_group_scores_dev(const void *Xs, int dtype, int64_t ldx, int32_t dp, const int32_t *offsets, int32_t nlist, const void *Q, int64_t ldq,
+                                int32_t nprobe, const int32_t *pair_ids, const int32_t *pair_offsets, int32_t *tile_start, int32_t max_tiles, int64_t lmax,
+                                float *S, void *stream);
 int anncur_ivf_map_ids(const int32_t *col, const float *val, int64_t nq, int32_t k, int64_t lmax, const int32_t *probe, int32_t nprobe,
                        const int32_t *offsets, const int32_t *ids, int32_t *out_idx, void *stream);
 

@@ -79,6 +79,25 @@ def test_bench_default_config_is_one_workload_at_every_n():
 	assert 0.5 < c4["recall"]["recall@100"] <= 1.0
 
 
+def test_bench_rccl_code_path_with_one_rank():
+	"""RCCL itself (backend "nccl") on the one GPU a builder's box has: a torchrun-style environment with WORLD_SIZE = 1 and
+	ANNCUR_BENCH_FORCE_DIST takes bench.py through init_process_group("nccl", device_id=...), the anchor-row all-gather on device tensors, the
+	barriers, the MAX all-reduce of the step time and destroy_process_group -- every collective call the N > 1 line makes, with one rank.
+	(N > 1 over xGMI stays unmeasured on the builder's side.)"""
+	import socket
+	with socket.socket() as sk:
+		sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+	env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "ANNCUR_BENCH_FORCE_DIST": "1",
+		   "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+	p = _run(env, args=["--gpus", "1", "--backend", "nccl", "--config", "small", "--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--cpu-sample-queries", "0",
+						"--no-k500", "--no-ivf"])
+	assert p.returncode == 0, p.stderr[-3000:]
+	lines = [l for l in p.stdout.splitlines() if l.strip()]
+	assert len(lines) == 1, p.stdout[-2000:]
+	out = json.loads(lines[0])
+	assert out["backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1 and out["allgather_ms"] > 0 and out["solo_rank0"]["value"] > 0
+
+
 def test_bench_fails_loudly_when_a_rank_raises():
 	p = _run({"ANNCUR_BENCH_FAIL_RANK": "1"})
 	assert p.returncode != 0

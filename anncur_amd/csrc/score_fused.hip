@@ -1090,8 +1090,37 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
 	uint32_t dma_off[Cfg::TILE_BYTES / 4096];
 	tile_dma_offsets<KP>(dma_off, wave_u, lane);
+	const int j_begin = split * p.tiles_per_split, j_end = min(j_begin + p.tiles_per_split, p.n_tiles);
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	// ANNCUR_DEBUG_ERR_MODE (p.ring_stagger here): 1 = every exact-tile DMA re-reads the split's first tile (L2-hot: no HBM latency, same
+	// instruction stream), 2 = no sums (DMAs and MFMAs only), 3 = one dword per row of the exact tile PF tiles ahead (an L2 prefetch)
+	const int dbg_mode = p.ring_stagger;
+	constexpr int PF = 3;
+	uint32_t pf_dummy = 0;
+	uint32_t pf_off;
+	{
+		const int row = wave * (Cfg::BQ / 4) + lane;
+		const int64_t last = p.Q - 1 - (int64_t)rb * Cfg::BQ;
+		pf_off = (uint32_t)(((int64_t)row < last ? (int64_t)row : last) * lda * 2);
+	}
+#endif
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (dbg_mode == 4) {   // 4 = the same bytes from CONTIGUOUS memory (tile j of the row block = 16 KB in one piece; wrong values, timing only)
+#pragma unroll
+		for (int i = 0; i < PA; ++i) {
+			const int ch = (wave * PA + i) * 64 + lane, row = ch >> 2, pos = ch & 3;
+			asrc[i] = (uint32_t)(row * 64 + 16 * (pos ^ ((row >> 2) & 3)));
+		}
+	}
+#endif
 	auto adma = [&](int j, int buf) {
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (dbg_mode == 1) j = j_begin;
+#endif
 		const unsigned char *src = abase + (int64_t)j * (TILE_I * 2);   // (uniform)
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (dbg_mode == 4) src = reinterpret_cast<const unsigned char *>(Aex) + ((int64_t)rb * p.n_tiles + j) * ATILE;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 		for (int i = 0; i < PA; ++i) {
@@ -1102,7 +1131,6 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 	};
 	__builtin_amdgcn_s_waitcnt(0x0F70);  // see score_kernel: keeps vmcnt(0) out of the tile loop
 
-	const int j_begin = split * p.tiles_per_split, j_end = min(j_begin + p.tiles_per_split, p.n_tiles);
 	float se[QT], sn[QT];
 #pragma unroll
 	for (int t = 0; t < QT; ++t) { se[t] = 0.f; sn[t] = 0.f; }
@@ -1116,12 +1144,29 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 #pragma unroll
 	for (int s = 0; s < Cfg::NAOFF; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): error_mfma_tile() counts LDS reads
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+#define ERRL_SUMS_ON (dbg_mode != 2)
+#define ERRL_PREFETCH(J)                                                                                                        \
+	do {                                                                                                                        \
+		if (dbg_mode == 3) {                                                                                                    \
+			const int jp = min((J) + PF, j_end - 1);                                                                            \
+			const unsigned char *psrc = abase + (int64_t)jp * (TILE_I * 2);                                                     \
+			asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_dummy) : "v"(pf_off), "s"(psrc) : "memory");                 \
+		}                                                                                                                       \
+	} while (0)
+#define ERRL_WAIT_LANDED() do { if (dbg_mode == 3) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
+#else
+#define ERRL_SUMS_ON true
+#define ERRL_PREFETCH(J) do { } while (0)
+#define ERRL_WAIT_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
 #define ERRL_STEP(CUR, J)                                                                                                       \
 	do {                                                                                                                        \
 		if ((J) + 1 < j_end) {                                                                                                  \
 			tile_dma_s<KP>(p.Et, (J) + 1, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);                                      \
 			adma((J) + 1, (CUR) ^ 1);                                                                                           \
 		}                                                                                                                       \
+		ERRL_PREFETCH(J);                                                                                                       \
 		f32x16 acc[QT];                                                                                                         \
 		error_mfma_tile<KP, CUR>(aoff, xb, acc);                                                                                \
 		ExactQuad<uint16_t> ex[QT][4];  /* items 32 j + 8 g + 4 h + {0..3}, g = 0..3, of the lane's query */                   \
@@ -1131,6 +1176,7 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                      \
 		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
 			_Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));                                  \
+		if (ERRL_SUMS_ON)                                                                                                       \
 		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
 			_Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                    \
 				const float x = ex[t][e >> 2].get(e & 3);                                                                       \
@@ -1138,8 +1184,9 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 				se[t] = fmaf(d, d, se[t]);                                                                                      \
 				sn[t] = fmaf(x, x, sn[t]);                                                                                      \
 			}                                                                                                                   \
+		else { _Pragma("unroll") for (int t = 0; t < QT; ++t) { se[t] += acc[t][0]; sn[t] += ex[t][0].get(0); } }              \
 		/* this wave's parts of the next item tile and exact tile have landed; the barrier orders LDS only */                   \
-		__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                     \
+		ERRL_WAIT_LANDED();                                                                                                     \
 		asm volatile("" ::: "memory");                                                                                          \
 		__builtin_amdgcn_s_barrier();                                                                                           \
 		asm volatile("" ::: "memory");                                                                                          \
@@ -1149,6 +1196,12 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 		if (j + 1 < j_end) ERRL_STEP(1, j + 1);
 	}
 #undef ERRL_STEP
+#undef ERRL_SUMS_ON
+#undef ERRL_PREFETCH
+#undef ERRL_WAIT_LANDED
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (dbg_mode == 3) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::"v"(pf_dummy)); }
+#endif
 #pragma unroll
 	for (int t = 0; t < QT; ++t)
 		if (qv[t] < p.Q) {
@@ -2442,6 +2495,20 @@ extern "C" int anncur_score_topk_timed(const void *X, int64_t ldx, const void *E
 	return rc;
 }
 
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+/* experiments build only (scripts/r4/timeline_probe.py): the same launches with the CALLER's 11 events recorded at the stage boundaries
+ * (0 start, 1 after the prepass, 2 after the threshold, 5 + 2 g / 6 + 2 g around sweep launch g, 3 after the last stage, 4 after the
+ * select) and no synchronisation -- for a timeline of several calls in flight on several streams against one base event */
+extern "C" int anncur_score_topk_events(const void *X, int64_t ldx, const void *Et, int64_t lde, int64_t Q, int64_t I, int32_t Kp,
+										int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
+										int32_t flags, const int32_t *item_ids, void *stream, void *const *events11) {
+	ANNCUR_REQUIRE(events11, ANNCUR_E_INVALID, "score_topk_events: events is null");
+	hipEvent_t ev[11];
+	for (int i = 0; i < 11; ++i) ev[i] = (hipEvent_t)events11[i];
+	return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, ev, flags, item_ids);
+}
+#endif
+
 /* plan introspection for benchmarks / DESIGN.md: n_sample_tiles, n_tiles, S, capg, group (tiles of 32 items, or of 256 for Kp > 512) */
 extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t *out5) {
 	const FusedPlan P = plan_any(Q, I, Kp, k);
@@ -2520,6 +2587,9 @@ extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void
 	p.tiles_per_split = (p.n_tiles + S - 1) / S;
 	S = (p.n_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
 	p.n_wg = n_rb * S;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_ERR_MODE")) p.ring_stagger = atoi(dbg);
+#endif
 #define LAUNCH_ERR(KPV, TA)                                                                                                   \
 	hipLaunchKernelGGL((error_kernel<KPV, TA>), dim3(p.n_wg), dim3(256), 2 * FusedCfg<KPV>::TILE_BYTES, st, p, (const TA *)A, lda, err_sq, norm_sq)
 #define LAUNCH_ERR_K(TA)                                                                                                      \

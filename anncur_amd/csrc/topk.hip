@@ -164,7 +164,9 @@ template <typename T> struct ScanPre;
 template <> struct ScanPre<float> {  // fp32 rows: plain float compares
 	float pre;
 	bool all;  // (wave-uniform) no threshold yet: every real number is a candidate, -inf included
+	static constexpr bool pos = false;   // (no separate path for positive thresholds: the float compare is already three instructions)
 	__device__ __forceinline__ void set(float tau) { pre = tau; all = !(tau > -INFINITY); }
+	__device__ __forceinline__ bool any_pos(const u32x4 &c) const { return any(c); }
 	__device__ __forceinline__ u32x4 xform(const u32x4 &c) const { return c; }
 	__device__ __forceinline__ bool any(const u32x4 &y) const {
 		return all || fmaxf(fmaxf(fmaxf(__uint_as_float(y[0]), __uint_as_float(y[1])), __uint_as_float(y[2])), __uint_as_float(y[3])) > pre;
@@ -177,7 +179,12 @@ template <> struct ScanPre<float> {  // fp32 rows: plain float compares
 };
 template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer compares on y = x ^ M
 	uint32_t mask, pre_pk;  // wave-uniform
+	uint32_t pre_s;         // (pos) the threshold's own 16 bits in both halves
 	bool all;               // (wave-uniform) no threshold yet: every real number is a candidate, -inf included
+	bool pos;               // (wave-uniform) a threshold >= +0: x > tau iff x's bits exceed tau's as SIGNED 16-bit integers (negative
+	                        // values are negative integers, positive floats order like their bits; NaN patterns with the sign clear pass and
+	                        // are dropped at the push) -- the stream's steps then skip the xor: three packed maxima, one more against the
+	                        // threshold, one compare (round 4: the scan on part of the chip is bound by instruction issue, not by loads in flight)
 	__device__ __forceinline__ void set(float tau) {
 		const uint32_t b = __builtin_amdgcn_readfirstlane(__float_as_uint(tau));
 		all = b == 0xff800000u || (b & 0x7fffffffu) > 0x7f800000u;  // -inf (or, defensively, a NaN threshold)
@@ -188,6 +195,17 @@ template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer comp
 		mask = m16 | (m16 << 16);
 		const uint32_t p16 = t16 ^ m16;
 		pre_pk = p16 | (p16 << 16);
+		pos = !neg && !all;
+		pre_s = t16 | (t16 << 16);
+	}
+	__device__ __forceinline__ bool any_pos(const u32x4 &c) const {
+		typedef short i16x8 __attribute__((ext_vector_type(8)));
+		typedef short i16x4 __attribute__((ext_vector_type(4)));
+		typedef short i16x2 __attribute__((ext_vector_type(2)));
+		const i16x8 v = __builtin_bit_cast(i16x8, c);
+		const i16x4 a = __builtin_elementwise_max(v.lo, v.hi);
+		const i16x2 m = __builtin_elementwise_max(a.lo, a.hi);
+		return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(m, __builtin_bit_cast(i16x2, pre_s))) != pre_s;
 	}
 	__device__ __forceinline__ u32x4 xform(const u32x4 &c) const { return c ^ mask; }
 	__device__ __forceinline__ bool any(const u32x4 &y) const {
@@ -260,7 +278,7 @@ struct ScanGather {
 	void *cq;                // [Q x ldo] of A's element type
 	int64_t ldo;
 };
-template <typename T, bool GATHER = false>
+template <typename T, bool GATHER = false, bool BUF = true>
 __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
 																 uint32_t trig, float *__restrict__ out_val, int32_t *__restrict__ out_idx,
 																 const ScanGather gt = ScanGather{}) {
@@ -270,6 +288,9 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
 	if (q >= Q) return;
+	// (A start stagger -- the workgroups resident at launch sleeping hashed offsets of up to 8..48 us so that the select phases of a CU's waves
+	//  do not coincide -- was measured in round 4 and dropped: 0.580 -> 0.589..0.621 ms on 96 CUs, 0.330 -> 0.337..0.340 on the chip.  The
+	//  phases are not what holds a part of the chip at 35 GB/s per CU: see DESIGN.md 4.4, 'what bounds the scan on part of the chip'.)
 	WaveSel w = wsel_init<WS_CAP>(smem + wave * WaveSelLayout<WS_CAP>::BYTES);
 	const T *row = A + q * lda;
 	constexpr int VEC = VecOf<T>::N;
@@ -282,6 +303,11 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	const u32x4 *vp = reinterpret_cast<const u32x4 *>(row + head);
 	const int64_t vlast = nvec > 0 ? nvec - 1 : 0;
 	const int64_t nsteps = (nvec + WAVE - 1) / WAVE;
+	// (BUF, round 4) the stream's loads as raw buffer loads: the row's vectors behind a resource in scalar registers, the lane's 16 bytes as
+	// a 32-bit offset, the step as an immediate and the block as a scalar offset -- no per-lane 64-bit address arithmetic (three to four
+	// VALU instructions per step of the pointer form: a fifth of the loop).  Rows under 2 GB (the launcher picks the pointer form otherwise).
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(vp), 0, BUF ? (int)(nvec * 16) : 0, 0x00027000);
+	const uint32_t voff = (uint32_t)lane * 16u;
 
 	// the first WS_PF vectors of every lane: they seed the threshold AND are the first prefetch set of the stream
 	u32x4 pf[WS_PF];
@@ -345,15 +371,17 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		__builtin_amdgcn_wave_barrier();                                                                                        \
 		if (w.cnt > trig) wsel_compact_call<WS_CAP, HP, true>(w, k, tie_limit);                                                 \
 	}
-#define SCAN_STEP(d, FULL)                                                                                                      \
+#define SCAN_STEP(d, FULL, POS)                                                                                                 \
 	{                                                                                                                           \
 		const u32x4 cur = pf[d];                                                                                                \
 		const uint32_t mcur = GATHER ? pm[GATHER ? (d) : 0] : 0u;                                                               \
-		const u32x4 y = sp.xform(cur);                                                                                          \
-		bool pass = sp.any(y);                                                                                                  \
+		bool pass;                                                                                                              \
+		if (POS) pass = sp.any_pos(cur);                                                                                        \
+		else pass = sp.any(sp.xform(cur));                                                                                      \
 		if (FULL) {  /* the block and its prefetch lie inside the row: wave-uniform base + lane, nothing to clamp */            \
 			if (GATHER) pm[GATHER ? (d) : 0] = mblk[((d) + WS_PF) * WAVE + lane];                                     \
-			pf[d] = __builtin_nontemporal_load(blk + ((d) + WS_PF) * WAVE + lane);                                              \
+			if (BUF) pf[d] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (uint32_t)(((d) & 3) * 1024), soff + (((d) & 4) ? 4096u : 0u), 2); \
+			else pf[d] = __builtin_nontemporal_load(blk + ((d) + WS_PF) * WAVE + lane);                                         \
 		} else {  /* the last blocks: prefetches clamped, steps past the row masked (never branched around) */                  \
 			const int64_t iv = (s0 + (d)) * WAVE + lane;                                                                        \
 			const int64_t ivn = iv + (int64_t)WS_PF * WAVE;                                                                     \
@@ -391,15 +419,21 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		sp.set(w.tau);  // frozen for the block
 		const u32x4 *blk = vp + s0 * WAVE;  // (uniform)
 		const uint32_t *mblk = GATHER ? gt.vtab + s0 * WAVE : nullptr;
-		(void)mblk;
-		SCAN_STEP(0, true) SCAN_STEP(1, true) SCAN_STEP(2, true) SCAN_STEP(3, true) SCAN_STEP(4, true) SCAN_STEP(5, true) SCAN_STEP(6, true) SCAN_STEP(7, true)
+		const uint32_t soff = (uint32_t)((s0 + WS_PF) * (WAVE * 16));  // (uniform) byte offset of the block the steps prefetch
+		(void)mblk; (void)blk; (void)soff;
+		if (sp.pos) {
+			SCAN_STEP(0, true, true) SCAN_STEP(1, true, true) SCAN_STEP(2, true, true) SCAN_STEP(3, true, true) SCAN_STEP(4, true, true) SCAN_STEP(5, true, true) SCAN_STEP(6, true, true) SCAN_STEP(7, true, true)
+		} else {
+			SCAN_STEP(0, true, false) SCAN_STEP(1, true, false) SCAN_STEP(2, true, false) SCAN_STEP(3, true, false) SCAN_STEP(4, true, false) SCAN_STEP(5, true, false) SCAN_STEP(6, true, false) SCAN_STEP(7, true, false)
+		}
 	}
 	for (; s0 < nsteps; s0 += WS_PF) {
 		sp.set(w.tau);
 		const u32x4 *blk = vp;  // (unused)
 		const uint32_t *mblk = nullptr;
-		(void)blk; (void)mblk;
-		SCAN_STEP(0, false) SCAN_STEP(1, false) SCAN_STEP(2, false) SCAN_STEP(3, false) SCAN_STEP(4, false) SCAN_STEP(5, false) SCAN_STEP(6, false) SCAN_STEP(7, false)
+		const uint32_t soff = 0u;
+		(void)blk; (void)mblk; (void)soff;
+		SCAN_STEP(0, false, false) SCAN_STEP(1, false, false) SCAN_STEP(2, false, false) SCAN_STEP(3, false, false) SCAN_STEP(4, false, false) SCAN_STEP(5, false, false) SCAN_STEP(6, false, false) SCAN_STEP(7, false, false)
 	}
 	if (scnt > 0u) SCAN_DRAIN()
 #undef SCAN_STEP
@@ -703,10 +737,14 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 			if (t > k && t <= 512) trig = (uint32_t)t;
 		}
 #endif
-		if (dtype == ANNCUR_F32)
-			hipLaunchKernelGGL((rowwise_topk_wave_kernel<float>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
-		else
-			hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
+		const bool buf = I * (int64_t)dtype_size(dtype) < ((int64_t)1 << 31);   // the stream's loads through a buffer resource (32-bit offsets)
+		if (dtype == ANNCUR_F32) {
+			if (buf) hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
+			else hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, false>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
+		} else {
+			if (buf) hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, false, true>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
+			else hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, false, false>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
+		}
 		ANNCUR_LAUNCH_OK();
 		return ANNCUR_OK;
 	}
@@ -748,9 +786,9 @@ extern "C" int anncur_rowwise_topk_gather(const void *A, int dtype, int64_t Q, i
 	const uint32_t trig = ws_trigger((uint32_t)k);
 	ScanGather gt{vec_tab, col_idx, n_idx, cq, ldo};
 	if (dtype == ANNCUR_F32)
-		hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx, gt);
+		hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, true, false>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx, gt);
 	else
-		hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, true>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx, gt);
+		hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, true, false>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx, gt);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -583,7 +583,7 @@ def run_config(args, cfg_name, ctx, light=False):
 			import csv
 			tot_ns = calls = 0
 			for r_ in csv.DictReader(open(sfile)):
-				if any(nm in r_["Name"] for nm in (f"score16_kernel<{Kp}>", f"score16r_kernel<{Kp}>", f"scoreq16_kernel<{Kp}>", f"scoreq1_kernel<{Kp}>", f"score_kernel<{Kp}, 1, ")):
+				if any(nm in r_["Name"] for nm in (f"score16_kernel<{Kp}>", f"score16_kernel<{Kp},", f"score16r_kernel<{Kp}>", f"scoreq16_kernel<{Kp}>", f"scoreq1_kernel<{Kp}>", f"score_kernel<{Kp}, 1, ")):
 					tot_ns += float(r_["TotalDurationNs"]); calls += int(r_["Calls"])
 			if calls:
 				rocprof_ms, rocprof_src = tot_ns / calls / 1e6, os.path.basename(sfile)

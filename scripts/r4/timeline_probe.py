@@ -86,6 +86,10 @@ def main():
 		if variant in ("disj", "disj2"):
 			# the retrieval chains on two streams masked to the other CUs
 			mains = [masked_stream(n_scan, 256), masked_stream(n_scan, 256)] if variant == "disj" else [masked_stream(0, n_scan), masked_stream(0, n_scan)]
+		elif variant.startswith("ovl"):
+			# the retrieval chains masked to CUs lo .. 255 with lo < n_scan: the scan keeps lo CUs to itself and shares the rest of its own
+			lo = int(variant[3:])
+			mains = [masked_stream(lo, 256), masked_stream(lo, 256)]
 		elif variant.startswith("after"):
 			m = torch.cuda.Stream(device=device); mains = [m, m]
 			s_st = torch.cuda.Stream(device=device) if variant == "after" else masked_stream(0, int(variant[5:]))   # afterN: the scan on N CUs

@@ -15,7 +15,7 @@ kp = shape["Kp"]
 qt = 2 if kp <= 256 else 1
 # the sweep runs as one of four bodies (32x32x16 with the ballot / exec-mask filter, 16x16x32, Kp = 512 with the wave queue -- chosen by the plan): all of them
 # are "the sweep kernel" of the roofline, whose per-launch figures average over the launches of a step
-sweep_variants = [f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 1, 16, true, false, {qt}>", f"score16_kernel<{kp}>", f"score16r_kernel<{kp}>", f"scoreq1_kernel<{kp}>", f"scoreq16_kernel<{kp}>"]
+sweep_variants = [f"score_kernel<{kp}, 1, 16, false, false, {qt}>", f"score_kernel<{kp}, 1, 16, true, false, {qt}>", f"score16_kernel<{kp}", f"score16r_kernel<{kp}", f"scoreq1_kernel<{kp}>", f"scoreq16_kernel<{kp}>"]
 sweep, prepass = f"score_kernel<{kp}, sweep>", f"score_kernel<{kp}, 0, 16, false, false, {qt}>"
 names = sweep_variants + [prepass, f"score_kernel<{kp}, 1, 16, false, false, 1>", "rowwise_topk_wave_kernel<unsigned short", "select_wave_kernel<false", "select_wave_kernel<true", "select_stream_kernel<false",
 		 "select_stream_kernel<true", "select_candidates_kernel", "kth_value_wave_kernel", "gather_cols_kernel", "overlap_wave_kernel", "copy_bytes_kernel", "wide_kernel", "gemm_f64_kernel"]

@@ -354,6 +354,9 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	u32x4 *stage_vec = reinterpret_cast<u32x4 *>(w.sort_buf);
 	uint32_t *stage_idx = w.hist;
 	uint32_t scnt = 0;  // staged vectors (wave-uniform)
+	// (Round 4, measured and dropped: a threshold-only refresh -- the k-th select without the pass that rewrites the buffer -- every 16 / 32 / 50 /
+	//  64 / 100 candidates, compaction only when the buffer runs out of room at 512: 0.578 -> 0.674 / 0.664 / 0.631 / 0.599 / 0.594 ms on 96 CUs,
+	//  0.331 -> 0.367 ... 0.335 on the chip.  The select IS the cost of a compaction, and a buffer that is not trimmed makes every later one longer.)
 #define SCAN_DRAIN()                                                                                                            \
 	{                                                                                                                           \
 		__builtin_amdgcn_wave_barrier();                                                                                        \

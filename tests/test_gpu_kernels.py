@@ -109,6 +109,25 @@ def test_rowwise_topk_adversarial_and_strided(ops):
 	assert i[0, 0].item() == 5 and v[0, 1].item() == -float("inf")
 
 
+@pytest.mark.parametrize("I", [(1 << 30) + 4099, (1 << 30) - 4093])
+def test_rowwise_topk_rows_of_2gb_and_more_take_the_pointer_loads(ops, I):
+	"""The stream loop issues raw buffer loads with 32-bit offsets for rows under 2 GB; longer rows keep the 64-bit pointer form
+	(csrc/topk.hip: `buf`).  One bf16 row just past 2 GB and one just under it (the buffer form at its largest offsets), built on the
+	device: small noise with 24 distinct planted values, the last of them in the row's final, partial block."""
+	A = torch.empty((1, I), dtype=torch.bfloat16, device="cuda")
+	A.normal_(0.0, 0.01, generator=torch.Generator(device="cuda").manual_seed(5))
+	pos = torch.tensor([7, 4096 * 3 + 1, 1 << 20, (1 << 29) + 13, I - 4000, I - 513, I - 2] + [97 * 1000003 * (j + 1) % I for j in range(17)], dtype=torch.long)
+	assert len(set(pos.tolist())) == 24
+	vals = torch.arange(24, dtype=torch.float32).mul(0.5).add(10.0).to(torch.bfloat16)    # 10.0, 10.5, ...: distinct in bf16
+	A[0, pos.cuda()] = vals.cuda()
+	v, i = ops.rowwise_topk(A, 24)
+	order = torch.argsort(vals.float(), descending=True)
+	assert torch.equal(i.cpu().long()[0], pos[order]) and torch.equal(v.cpu()[0], vals.float()[order])
+	v10, i10 = ops.rowwise_topk(A, 10)
+	assert torch.equal(i10.cpu().long()[0], pos[order][:10])
+	del A
+
+
 # ------------------------------------------------------------------ rerank + overlap vs the oracle loop
 def test_rerank_and_overlap_match_reference_loop(ops):
 	from oracle import cur_oracle as O

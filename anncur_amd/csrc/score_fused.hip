@@ -1043,12 +1043,16 @@ __device__ __forceinline__ void error_mfma_tile(const uint32_t (&aoff)[FusedCfg<
 // XOR-swizzled with (row >> 2) & 3 on the DMA's source address: two-way bank conflicts instead of eight-way).
 // (The sweep's stagger with the sums in the filter's place -- sub-tile 0's sums in the shadow of sub-tile 1's chain -- was built and
 //  measured: no gain at Kp = 128 (0.460 vs 0.459 ms), 16 spilled registers at Kp = 256 (1.28 ms): the epilogue is not what bounds it.)
+// exact-tile buffers of error_lds_kernel: three (two tiles ahead) where two item tiles + three exact tiles fit in 80 KB (two workgroups per CU),
+// i.e. Kp <= 256 (Kp = 256: exactly 80 KB); Kp = 512 (64 KB of item tiles) keeps two
+template <int KP> struct ErrLdsBuffers { static constexpr int N = (2 * FusedCfg<KP>::TILE_BYTES + 3 * FusedCfg<KP>::BQ * 64 <= 80 * 1024) ? 3 : 2; };
 template <int KP>
 __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, const uint16_t *__restrict__ Aex, int64_t lda,
 															float *__restrict__ err_sq, float *__restrict__ norm_sq) {
 	using Cfg = FusedCfg<KP>;
 	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
 	constexpr int ATILE = Cfg::BQ * 64, PA = ATILE / 4096, AOFF = 2 * Cfg::TILE_BYTES;   // exact tile bytes, DMA pieces per wave, LDS offset
+	constexpr int NAB = ErrLdsBuffers<KP>::N;                                            // exact-tile buffers (ring depth)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r = lane & 31, h = lane >> 5;
@@ -1093,25 +1097,18 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 	const int j_begin = split * p.tiles_per_split, j_end = min(j_begin + p.tiles_per_split, p.n_tiles);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	// ANNCUR_DEBUG_ERR_MODE (p.ring_stagger here): 1 = every exact-tile DMA re-reads the split's first tile (L2-hot: no HBM latency, same
-	// instruction stream), 2 = no sums (DMAs and MFMAs only), 3 = one dword per row of the exact tile PF tiles ahead (an L2 prefetch)
+	// instruction stream), 2 = no sums (DMAs and MFMAs only), 4 = the same bytes from CONTIGUOUS memory (wrong values, timing only)
 	const int dbg_mode = p.ring_stagger;
-	constexpr int PF = 3;
-	uint32_t pf_dummy = 0;
-	uint32_t pf_off;
-	{
-		const int row = wave * (Cfg::BQ / 4) + lane;
-		const int64_t last = p.Q - 1 - (int64_t)rb * Cfg::BQ;
-		pf_off = (uint32_t)(((int64_t)row < last ? (int64_t)row : last) * lda * 2);
-	}
-#endif
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (dbg_mode == 4) {   // 4 = the same bytes from CONTIGUOUS memory (tile j of the row block = 16 KB in one piece; wrong values, timing only)
+	if (dbg_mode == 4) {
 #pragma unroll
 		for (int i = 0; i < PA; ++i) {
 			const int ch = (wave * PA + i) * 64 + lane, row = ch >> 2, pos = ch & 3;
 			asrc[i] = (uint32_t)(row * 64 + 16 * (pos ^ ((row >> 2) & 3)));
 		}
 	}
+#define ERRL_SUMS_ON (dbg_mode != 2)
+#else
+#define ERRL_SUMS_ON true
 #endif
 	auto adma = [&](int j, int buf) {
 #ifdef ANNCUR_TIMING_EXPERIMENTS
@@ -1134,9 +1131,16 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 	float se[QT], sn[QT];
 #pragma unroll
 	for (int t = 0; t < QT; ++t) { se[t] = 0.f; sn[t] = 0.f; }
+	// The exact tiles run NAB - 1 tiles ahead of the MFMAs (round 4: a ring of three where it fits).  A tile's rows come from 256 different
+	// 200 KB rows of the matrix, 64 bytes each: one HBM round trip, and with ONE tile ahead that round trip had to fit inside one tile's
+	// MFMA chain -- it did not (profiles/r04_error_kernel_modes.txt: 0.67 ms, 0.50 with the exact tile L2-hot; at Kp = 128 the step was
+	// shorter than the round trip and the time did not move with Kp).  The exact tile's rows are wave-private (a wave's DMA pieces fill the
+	// rows its lanes read), so the ring needs no barrier of its own: the wave that read tile j - 1 in its last step refills that buffer.
+	// Loads return in issue order: `s_waitcnt vmcnt(PA)` at the end of a step leaves only the PA pieces of the newest exact tile in flight.
 	if (j_begin < j_end) {
 		tile_dma_s<KP>(p.Et, j_begin, lds_base, wave_u, dma_off);
 		adma(j_begin, 0);
+		if (NAB == 3 && j_begin + 1 < j_end) adma(j_begin + 1, 1);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
@@ -1144,35 +1148,18 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 #pragma unroll
 	for (int s = 0; s < Cfg::NAOFF; ++s) aoff[s] = lds_addr(smem) + (uint32_t)(r * CPR + swz<CPR>(r, 2 * s + h)) * 16u;
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): error_mfma_tile() counts LDS reads
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-#define ERRL_SUMS_ON (dbg_mode != 2)
-#define ERRL_PREFETCH(J)                                                                                                        \
+	static_assert(PA <= 15, "vmcnt immediate");
+#define ERRL_STEP(ECUR, ACUR, J)                                                                                                \
 	do {                                                                                                                        \
-		if (dbg_mode == 3) {                                                                                                    \
-			const int jp = min((J) + PF, j_end - 1);                                                                            \
-			const unsigned char *psrc = abase + (int64_t)jp * (TILE_I * 2);                                                     \
-			asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_dummy) : "v"(pf_off), "s"(psrc) : "memory");                 \
-		}                                                                                                                       \
-	} while (0)
-#define ERRL_WAIT_LANDED() do { if (dbg_mode == 3) __builtin_amdgcn_s_waitcnt(0x0F71); else __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
-#else
-#define ERRL_SUMS_ON true
-#define ERRL_PREFETCH(J) do { } while (0)
-#define ERRL_WAIT_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70)
-#endif
-#define ERRL_STEP(CUR, J)                                                                                                       \
-	do {                                                                                                                        \
-		if ((J) + 1 < j_end) {                                                                                                  \
-			tile_dma_s<KP>(p.Et, (J) + 1, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);                                      \
-			adma((J) + 1, (CUR) ^ 1);                                                                                           \
-		}                                                                                                                       \
-		ERRL_PREFETCH(J);                                                                                                       \
+		if ((J) + 1 < j_end) tile_dma_s<KP>(p.Et, (J) + 1, lds_base + ((ECUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);         \
+		const bool ahead = (J) + NAB - 1 < j_end;   /* (uniform) */                                                             \
+		if (ahead) adma((J) + NAB - 1, ((ACUR) + NAB - 1) % NAB);                                                               \
 		f32x16 acc[QT];                                                                                                         \
-		error_mfma_tile<KP, CUR>(aoff, xb, acc);                                                                                \
+		error_mfma_tile<KP, ECUR>(aoff, xb, acc);                                                                               \
 		ExactQuad<uint16_t> ex[QT][4];  /* items 32 j + 8 g + 4 h + {0..3}, g = 0..3, of the lane's query */                   \
 		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
 			_Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                       \
-				asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ex[t][g].w) : "v"(aread[t] + (((uint32_t)g << 4) ^ asw[t])), "n"((CUR) * ATILE)); \
+				asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ex[t][g].w) : "v"(aread[t] + (((uint32_t)g << 4) ^ asw[t])), "n"((ACUR) * ATILE)); \
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                      \
 		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
 			_Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));                                  \
@@ -1185,23 +1172,30 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 				sn[t] = fmaf(x, x, sn[t]);                                                                                      \
 			}                                                                                                                   \
 		else { _Pragma("unroll") for (int t = 0; t < QT; ++t) { se[t] += acc[t][0]; sn[t] += ex[t][0].get(0); } }              \
-		/* this wave's parts of the next item tile and exact tile have landed; the barrier orders LDS only */                   \
-		ERRL_WAIT_LANDED();                                                                                                     \
+		/* this wave's parts of the next item tile and of the next exact tile have landed; the barrier orders LDS only */        \
+		if (NAB == 3 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA) : "memory");                                        \
+		else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                                \
 		asm volatile("" ::: "memory");                                                                                          \
 		__builtin_amdgcn_s_barrier();                                                                                           \
 		asm volatile("" ::: "memory");                                                                                          \
 	} while (0)
-	for (int j = j_begin; j < j_end; j += 2) {
-		ERRL_STEP(0, j);
-		if (j + 1 < j_end) ERRL_STEP(1, j + 1);
+	if constexpr (NAB == 3) {
+		for (int j = j_begin; j < j_end; j += 6) {
+			ERRL_STEP(0, 0, j);
+			if (j + 1 < j_end) ERRL_STEP(1, 1, j + 1);
+			if (j + 2 < j_end) ERRL_STEP(0, 2, j + 2);
+			if (j + 3 < j_end) ERRL_STEP(1, 0, j + 3);
+			if (j + 4 < j_end) ERRL_STEP(0, 1, j + 4);
+			if (j + 5 < j_end) ERRL_STEP(1, 2, j + 5);
+		}
+	} else {
+		for (int j = j_begin; j < j_end; j += 2) {
+			ERRL_STEP(0, 0, j);
+			if (j + 1 < j_end) ERRL_STEP(1, 1, j + 1);
+		}
 	}
 #undef ERRL_STEP
 #undef ERRL_SUMS_ON
-#undef ERRL_PREFETCH
-#undef ERRL_WAIT_LANDED
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (dbg_mode == 3) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::"v"(pf_dummy)); }
-#endif
 #pragma unroll
 	for (int t = 0; t < QT; ++t)
 		if (qv[t] < p.Q) {
@@ -2606,7 +2600,7 @@ extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void
 	if (lds_exact) {
 #define LAUNCH_ERRL(KPV)                                                                                                      \
 		do {                                                                                                                  \
-			const int lds_ = 2 * FusedCfg<KPV>::TILE_BYTES + 2 * FusedCfg<KPV>::BQ * 64;                                      \
+			const int lds_ = 2 * FusedCfg<KPV>::TILE_BYTES + ErrLdsBuffers<KPV>::N * FusedCfg<KPV>::BQ * 64;                  \
 			{ const int rc_ = anncur_ensure_dyn_lds((const void *)error_lds_kernel<KPV>, lds_); if (rc_ != ANNCUR_OK) return rc_; } \
 			hipLaunchKernelGGL((error_lds_kernel<KPV>), dim3(p.n_wg), dim3(256), lds_, st, p, (const uint16_t *)A, lda, err_sq, norm_sq); \
 		} while (0)

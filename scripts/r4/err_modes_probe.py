@@ -16,7 +16,7 @@ def main():
 		X = torch.randn(Q, Kp, device=dev).to(torch.bfloat16)
 		Et = (torch.randn(I, Kp, device=dev) / Kp ** 0.5).to(torch.bfloat16)
 		ref = None
-		for mode in (0, 1, 2, 3, 4):
+		for mode in (0, 1, 2, 4):
 			os.environ["ANNCUR_DEBUG_ERR_MODE"] = str(mode)
 			for _ in range(3): out = ops.approx_error_packed(X, Et, A, I)
 			ev[0].record()
@@ -25,7 +25,7 @@ def main():
 			ms = ev[0].elapsed_time(ev[1]) / 10
 			note = ""
 			if mode == 0: ref = [o.clone() for o in out]
-			if mode == 3: note = "  equal to mode 0: %s" % all(torch.equal(a, b) for a, b in zip(ref, out))
+			if mode == 99: note = "  equal to mode 0: %s" % all(torch.equal(a, b) for a, b in zip(ref, out))
 			print(f"Kp {Kp} mode {mode}: {ms:.3f} ms  ({2e-9 * Q * I * Kp / ms:.0f} TFLOP/s){note}", flush=True)
 
 if __name__ == "__main__":

@@ -74,7 +74,21 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 	const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(smem));
 	uint32_t dma_off[Cfg::TILE_BYTES / 4096];
 	tile_dma_offsets<KP>(dma_off, wave_u, lane);
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	// experiments build, ANNCUR_DEBUG_RING_STAGGER (p.ring_stagger; the ring body is not in play here): 1 = every exact-tile DMA re-reads the
+	// split's first tile (L2-hot), 2 = no error sums, 3 = neither sums nor filter (DMAs and MFMAs only)
+	const int dbg_mode = p.ring_stagger;
+	const int dbg_j0 = p.tile_begin + split * p.tiles_per_split;
+#define EVALF_SUMS_ON (dbg_mode < 2)
+#define EVALF_FILTER_ON (dbg_mode != 3)
+#else
+#define EVALF_SUMS_ON true
+#define EVALF_FILTER_ON true
+#endif
 	auto adma = [&](int j, int buf) {
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (dbg_mode == 1) j = dbg_j0;
+#endif
 		const unsigned char *src = abase + (int64_t)j * (TILE_I * 2);   // (uniform)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -105,9 +119,18 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 	float se[QT], sn[QT];
 #pragma unroll
 	for (int t = 0; t < QT; ++t) { se[t] = 0.f; sn[t] = 0.f; }
+	// The exact tiles run up to two tiles ahead in TWO buffers (round 4): a tile's rows are wave-private (a wave's DMA pieces fill the rows its
+	// lanes read), so the wave refills a buffer as soon as its own reads of it have returned -- tile J + 2 goes out in the middle of step J,
+	// behind the reads of tile J -- and the end of the step waits with a COUNTED vmcnt that leaves those pieces in flight.  With one tile
+	// ahead and vmcnt(0) the exact tile's HBM round trip (256 rows x 64 bytes) had to fit inside one step and did not
+	// (profiles/r04_error_kernel_modes.txt, scripts/r4/evalf_modes_probe.py: the call 1.06 ms, 0.875 with the exact tile L2-hot).  Loads return
+	// in issue order among themselves; the queue's stores may complete in any order, which the count tolerates: while an item-tile load is
+	// outstanding so are the PA younger exact-tile loads, i.e. more than PA operations -- vmcnt(PA) cannot pass before the item tile landed.
+	const int a_end = min(j_end, p.n_full_tiles);   // exact tiles exist for the full tiles only
 	if (j_begin < j_end) {
 		tile_dma_s<KP>(p.Et, j_begin, lds_base, wave_u, dma_off);
-		if (j_begin < p.n_full_tiles) adma(j_begin, 0);
+		if (j_begin < a_end) adma(j_begin, 0);
+		if (j_begin + 1 < a_end) adma(j_begin + 1, 1);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
@@ -118,10 +141,8 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): error_mfma_tile() counts LDS reads
 #define EVALF_STEP(CUR, J)                                                                                                      \
 	do {                                                                                                                        \
-		if ((J) + 1 < j_end) {                                                                                                  \
-			tile_dma_s<KP>(p.Et, (J) + 1, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);                           \
-			if ((J) + 1 < p.n_full_tiles) adma((J) + 1, (CUR) ^ 1);                                                             \
-		}                                                                                                                       \
+		if ((J) + 1 < j_end) tile_dma_s<KP>(p.Et, (J) + 1, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);          \
+		bool counted = false;   /* (uniform) the newest VMEM instructions of this step are the PA pieces of exact tile J + 2, and no store */ \
 		if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                               \
 		f32x16 acc[QT];                                                                                                         \
 		error_mfma_tile<KP, CUR>(aoff, xb, acc);                                                                                \
@@ -134,6 +155,8 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                  \
 			_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                      \
 				_Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));                              \
+			if ((J) + 2 < a_end) { adma((J) + 2, (CUR)); counted = true; }   /* this wave's rows of buffer CUR are in registers now */ \
+			if (EVALF_SUMS_ON)                                                                                                  \
 			_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                      \
 				_Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                \
 					const float x = ex[t][e >> 2].get(e & 3);                                                                   \
@@ -141,15 +164,18 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 					se[t] = fmaf(d, d, se[t]);                                                                                  \
 					sn[t] = fmaf(x, x, sn[t]);                                                                                  \
 				}                                                                                                               \
+			else { _Pragma("unroll") for (int t = 0; t < QT; ++t) { se[t] += acc[t][0]; sn[t] += ex[t][0].get(0); } }          \
 		}                                                                                                                       \
 		/* the sweep's filter on the accumulator at hand: survivors to the wave's queue (element e of sub-tile t: item row (e & 3) + 8 (e >> 2)) */ \
+		if (EVALF_FILTER_ON)                                                                                                    \
 		_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                          \
 			_Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                    \
 				filter16_one(acc[t][e], (uint32_t)(((e) & 3) + 8 * ((e) >> 2)) | ((uint32_t)t << 31), tau[t], item0c, w, fill); \
 				if ((e % C::CHECK_PUSHES) == C::CHECK_PUSHES - 1 && __builtin_expect(fill > w.limit, 0)) wq_drain(w, fill);     \
 			}                                                                                                                   \
-		/* this wave's parts of the next item tile and exact tile have landed; the barrier orders LDS only */                   \
-		__builtin_amdgcn_s_waitcnt(0x0F70);                                                                                     \
+		/* this wave's parts of the next item tile (and of exact tile J + 1) have landed; the barrier orders LDS only */        \
+		if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA) : "memory");                                                  \
+		else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                                \
 		asm volatile("" ::: "memory");                                                                                          \
 		__builtin_amdgcn_s_barrier();                                                                                           \
 		asm volatile("" ::: "memory");                                                                                          \
@@ -160,6 +186,8 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 		if (j + 1 < j_end) EVALF_STEP(1, j + 1);
 	}
 #undef EVALF_STEP
+#undef EVALF_SUMS_ON
+#undef EVALF_FILTER_ON
 	wq_drain(w, fill);
 	{
 		const int64_t q = q_wave0 + lane;

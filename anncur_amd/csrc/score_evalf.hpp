@@ -127,10 +127,15 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 	// in issue order among themselves; the queue's stores may complete in any order, which the count tolerates: while an item-tile load is
 	// outstanding so are the PA younger exact-tile loads, i.e. more than PA operations -- vmcnt(PA) cannot pass before the item tile landed.
 	const int a_end = min(j_end, p.n_full_tiles);   // exact tiles exist for the full tiles only
+#ifdef ANNCUR_V_EVALF1   // (A/B variant build: one tile ahead, issued at the start of the step, vmcnt(0) at its end)
+	constexpr bool AHEAD2 = false;
+#else
+	constexpr bool AHEAD2 = true;
+#endif
 	if (j_begin < j_end) {
 		tile_dma_s<KP>(p.Et, j_begin, lds_base, wave_u, dma_off);
 		if (j_begin < a_end) adma(j_begin, 0);
-		if (j_begin + 1 < a_end) adma(j_begin + 1, 1);
+		if (AHEAD2 && j_begin + 1 < a_end) adma(j_begin + 1, 1);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
@@ -142,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 #define EVALF_STEP(CUR, J)                                                                                                      \
 	do {                                                                                                                        \
 		if ((J) + 1 < j_end) tile_dma_s<KP>(p.Et, (J) + 1, lds_base + ((CUR) ^ 1) * Cfg::TILE_BYTES, wave_u, dma_off);          \
+		if (!AHEAD2 && (J) + 1 < a_end) adma((J) + 1, (CUR) ^ 1);                                                               \
 		bool counted = false;   /* (uniform) the newest VMEM instructions of this step are the PA pieces of exact tile J + 2, and no store */ \
 		if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill);                                                               \
 		f32x16 acc[QT];                                                                                                         \
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void evalf_kernel(const FusedParams p, cons
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                  \
 			_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                      \
 				_Pragma("unroll") for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ex[t][g].w));                              \
-			if ((J) + 2 < a_end) { adma((J) + 2, (CUR)); counted = true; }   /* this wave's rows of buffer CUR are in registers now */ \
+			if (AHEAD2 && (J) + 2 < a_end) { adma((J) + 2, (CUR)); counted = true; }   /* this wave's rows of buffer CUR are in registers now */ \
 			if (EVALF_SUMS_ON)                                                                                                  \
 			_Pragma("unroll") for (int t = 0; t < QT; ++t)                                                                      \
 				_Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                \

@@ -1043,16 +1043,13 @@ __device__ __forceinline__ void error_mfma_tile(const uint32_t (&aoff)[FusedCfg<
 // XOR-swizzled with (row >> 2) & 3 on the DMA's source address: two-way bank conflicts instead of eight-way).
 // (The sweep's stagger with the sums in the filter's place -- sub-tile 0's sums in the shadow of sub-tile 1's chain -- was built and
 //  measured: no gain at Kp = 128 (0.460 vs 0.459 ms), 16 spilled registers at Kp = 256 (1.28 ms): the epilogue is not what bounds it.)
-// exact-tile buffers of error_lds_kernel: three (two tiles ahead) where two item tiles + three exact tiles fit in 80 KB (two workgroups per CU),
-// i.e. Kp <= 256 (Kp = 256: exactly 80 KB); Kp = 512 (64 KB of item tiles) keeps two
-template <int KP> struct ErrLdsBuffers { static constexpr int N = (2 * FusedCfg<KP>::TILE_BYTES + 3 * FusedCfg<KP>::BQ * 64 <= 80 * 1024) ? 3 : 2; };
 template <int KP>
 __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, const uint16_t *__restrict__ Aex, int64_t lda,
 															float *__restrict__ err_sq, float *__restrict__ norm_sq) {
 	using Cfg = FusedCfg<KP>;
 	constexpr int KSTEPS = Cfg::KSTEPS, QT = Cfg::QT, CPR = Cfg::CPR;
 	constexpr int ATILE = Cfg::BQ * 64, PA = ATILE / 4096, AOFF = 2 * Cfg::TILE_BYTES;   // exact tile bytes, DMA pieces per wave, LDS offset
-	constexpr int NAB = ErrLdsBuffers<KP>::N;                                            // exact-tile buffers (ring depth)
+	constexpr int NAB = 2;                                                               // exact-tile buffers
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r = lane & 31, h = lane >> 5;
@@ -1131,16 +1128,13 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 	float se[QT], sn[QT];
 #pragma unroll
 	for (int t = 0; t < QT; ++t) { se[t] = 0.f; sn[t] = 0.f; }
-	// The exact tiles run NAB - 1 tiles ahead of the MFMAs (round 4: a ring of three where it fits).  A tile's rows come from 256 different
-	// 200 KB rows of the matrix, 64 bytes each: one HBM round trip, and with ONE tile ahead that round trip had to fit inside one tile's
-	// MFMA chain -- it did not (profiles/r04_error_kernel_modes.txt: 0.67 ms, 0.50 with the exact tile L2-hot; at Kp = 128 the step was
-	// shorter than the round trip and the time did not move with Kp).  The exact tile's rows are wave-private (a wave's DMA pieces fill the
-	// rows its lanes read), so the ring needs no barrier of its own: the wave that read tile j - 1 in its last step refills that buffer.
-	// Loads return in issue order: `s_waitcnt vmcnt(PA)` at the end of a step leaves only the PA pieces of the newest exact tile in flight.
+	// (Round 4, measured and dropped: the exact tiles TWO tiles ahead in a ring of three buffers -- 80 KB at Kp = 256 -- with a counted vmcnt at
+	//  the end of a step.  Same box, warm, round robin: 0.617 vs 0.615 ms at Kp = 256, 0.472 vs 0.468 at Kp = 128.  What the exact tile costs is
+	//  not its round trip: with every DMA re-reading one L2-hot tile the kernel takes 0.505 / 0.32 ms, with the same bytes from contiguous
+	//  memory 0.59 / 0.40 -- profiles/r04_error_kernel_modes.txt.)
 	if (j_begin < j_end) {
 		tile_dma_s<KP>(p.Et, j_begin, lds_base, wave_u, dma_off);
 		adma(j_begin, 0);
-		if (NAB == 3 && j_begin + 1 < j_end) adma(j_begin + 1, 1);
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
 	__syncthreads();
@@ -1179,20 +1173,9 @@ __global__ __launch_bounds__(256, 2) void error_lds_kernel(const FusedParams p, 
 		__builtin_amdgcn_s_barrier();                                                                                           \
 		asm volatile("" ::: "memory");                                                                                          \
 	} while (0)
-	if constexpr (NAB == 3) {
-		for (int j = j_begin; j < j_end; j += 6) {
-			ERRL_STEP(0, 0, j);
-			if (j + 1 < j_end) ERRL_STEP(1, 1, j + 1);
-			if (j + 2 < j_end) ERRL_STEP(0, 2, j + 2);
-			if (j + 3 < j_end) ERRL_STEP(1, 0, j + 3);
-			if (j + 4 < j_end) ERRL_STEP(0, 1, j + 4);
-			if (j + 5 < j_end) ERRL_STEP(1, 2, j + 5);
-		}
-	} else {
-		for (int j = j_begin; j < j_end; j += 2) {
-			ERRL_STEP(0, 0, j);
-			if (j + 1 < j_end) ERRL_STEP(1, 1, j + 1);
-		}
+	for (int j = j_begin; j < j_end; j += 2) {
+		ERRL_STEP(0, 0, j);
+		if (j + 1 < j_end) ERRL_STEP(1, 1, j + 1);
 	}
 #undef ERRL_STEP
 #undef ERRL_SUMS_ON
@@ -2600,7 +2583,7 @@ extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void
 	if (lds_exact) {
 #define LAUNCH_ERRL(KPV)                                                                                                      \
 		do {                                                                                                                  \
-			const int lds_ = 2 * FusedCfg<KPV>::TILE_BYTES + ErrLdsBuffers<KPV>::N * FusedCfg<KPV>::BQ * 64;                  \
+			const int lds_ = 2 * FusedCfg<KPV>::TILE_BYTES + 2 * FusedCfg<KPV>::BQ * 64;                                      \
 			{ const int rc_ = anncur_ensure_dyn_lds((const void *)error_lds_kernel<KPV>, lds_); if (rc_ != ANNCUR_OK) return rc_; } \
 			hipLaunchKernelGGL((error_lds_kernel<KPV>), dim3(p.n_wg), dim3(256), lds_, st, p, (const uint16_t *)A, lda, err_sq, norm_sq); \
 		} while (0)

@@ -196,6 +196,9 @@ template <> struct ScanPre<uint16_t> {  // bf16 rows: packed 16-bit integer comp
 		const uint32_t p16 = t16 ^ m16;
 		pre_pk = p16 | (p16 << 16);
 		pos = !neg && !all;
+#ifdef ANNCUR_V_SCANPTR
+		pos = false;
+#endif
 		pre_s = t16 | (t16 << 16);
 	}
 	__device__ __forceinline__ bool any_pos(const u32x4 &c) const {
@@ -740,7 +743,10 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 			if (t > k && t <= 512) trig = (uint32_t)t;
 		}
 #endif
-		const bool buf = I * (int64_t)dtype_size(dtype) < ((int64_t)1 << 31);   // the stream's loads through a buffer resource (32-bit offsets)
+		bool buf = I * (int64_t)dtype_size(dtype) < ((int64_t)1 << 31);   // the stream's loads through a buffer resource (32-bit offsets)
+#ifdef ANNCUR_V_SCANPTR   // (A/B variant build: round 3's stream loop -- pointer loads, xor prefilter)
+		buf = false;
+#endif
 		if (dtype == ANNCUR_F32) {
 			if (buf) hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);
 			else hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, false>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I, lda, (uint32_t)k, trig, out_val, out_idx);

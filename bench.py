@@ -201,7 +201,13 @@ def run_config(args, cfg_name, ctx, light=False):
 		# Measured on MI355X, one box (round 3): cfg2 (Kp = 256) 0.939 ms per step with the partition, 1.007 with "side"; the cfg4 per-GPU
 		# shape (Kp = 512: static tile shares, and a scan a third of the step) 9.00 vs 7.42 -- a workgroup that shares its CU with the scan
 		# for the whole launch holds a static share back, the dynamic schedule just hands it fewer tiles.
-		scan_mode = "partition" if Kp <= 256 else "side"
+		# Late round 4, one box, alternating runs: with the tiles of the Kp = 512 body drawn as XCD-sliced tickets the partition wins at the cfg4
+		# per-GPU shape too -- 7.01 ms per step with "side", 6.69-6.76 with the scan on 96 CUs, 6.49-6.51 on 64 (7.8 on 32; 6.71 with one
+		# retrieval stream): 12.5 GB of scan on 64 CUs and 6.4 TFLOP of sweep on the rest end together (gpurun_out/r4_cfg4_scan_modes.txt).
+		scan_mode = "partition"
+	# CUs of the scan's stream in the partition: the split that lets the scan and the sweeps end together -- 96 of 256 where the scan is a third
+	# of the step's CU-time (cfg2: 64 CUs 1.041 ms, 96 0.939, 128 0.955), 64 where it is a quarter (cfg4 per-GPU shape, above)
+	scan_cus = args.scan_cus if args.scan_cus else (96 if Kp <= 256 else 64)
 	rounds_rows = int(os.environ.get("ANNCUR_BENCH_ROUND_ROWS", "4096"))
 
 	def retrieve(workspace=None):
@@ -267,7 +273,7 @@ def run_config(args, cfg_name, ctx, light=False):
 			# last read its result buffers (two steps back).
 			# (neither piece on the default stream: hipExtStreamCreateWithCUMask makes a BLOCKING stream, which the NULL stream synchronises
 			#  with implicitly -- with the retrieval there the two ran strictly one after the other: 1.41 ms per step)
-			_, s_st = ops.cu_partition_streams(device, args.scan_cus)
+			_, s_st = ops.cu_partition_streams(device, scan_cus)
 			# --retr-streams 2 (default): the retrievals of consecutive steps on two streams with a workspace each -- the latency-bound tail of
 			# one chain (refinement, select, overlap count: most CUs idle) overlaps the head of the next (gather, prepass)
 			n_rs = 2 if args.retr_streams == 2 else 1
@@ -638,7 +644,7 @@ def run_config(args, cfg_name, ctx, light=False):
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
 			"fused_plan": plan_now,
 			"launch_mode": "eager" if not graphed else "hipGraph replay (the step's launches captured once per result slot)",
-			"scan_mode": {"used": scan_mode_used, "scan_cus": args.scan_cus if scan_mode_used == "partition" else None,
+			"scan_mode": {"used": scan_mode_used, "scan_cus": scan_cus if scan_mode_used == "partition" else None,
 						  "retrieval_streams": args.retr_streams if scan_mode_used == "partition" else 1, "gather_folded_into_scan": bool(scan_mode_used == "partition" and args.fold_gather and ops.rowwise_topk_gather_ok(A_test, k) and Kp == len(anc))},
 			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
 			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),
@@ -708,7 +714,7 @@ def main():
 	ap.add_argument("--no-ivf", action="store_true", help="skip the ivf_search side-line (the IVF-flat branch of build_flat_or_ivff_index at the hard-negative-mining size)")
 	ap.add_argument("--seed", type=int, default=0)
 	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
-	ap.add_argument("--scan-cus", type=int, default=96, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD)")
+	ap.add_argument("--scan-cus", type=int, default=None, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD); default 96 for Kp <= 256, 64 above")
 	ap.add_argument("--scan-mode", default=None, choices=["side", "partition", "tail", "chunks", "serial"],
 					help="how the exact scan is scheduled against the retrieval: partition = on a stream whose CU mask leaves it --scan-cus CUs, beside the "
 						 "retrieval on all of them (default where the retrieval's sweep draws its tiles dynamically: Kp <= 256); side = on a second stream "

@@ -405,6 +405,7 @@ def run_config(args, cfg_name, ctx, light=False):
 		return {t: flatten_overlap(stats[j]) for j, (t, _) in enumerate(cells)}
 
 	step_no = [0]   # the result slots alternate across ALL calls of run_steps (the partition launcher issues the next slot's scan ahead)
+	step_trace = [] if os.environ.get("ANNCUR_BENCH_STEP_TRACE") else None   # (debug) host time at the end of every loop iteration
 	def run_steps(n):
 		res, pending = None, None
 		for i in range(n):
@@ -416,6 +417,7 @@ def run_config(args, cfg_name, ctx, light=False):
 				res = finish(pending)
 			prof["launch"] += t_b - t_a
 			prof["finish"] += time.perf_counter() - t_b
+			if step_trace is not None: step_trace.append((time.perf_counter(), t_b - t_a, prof.get("wait", 0.0)))
 			pending = cur_slot
 		if pending is not None:
 			res = finish(pending)
@@ -437,6 +439,11 @@ def run_config(args, cfg_name, ctx, light=False):
 	barrier()
 	elapsed = time.perf_counter() - t0
 	_mark("timed steps done")
+	if step_trace is not None and len(step_trace) > 1:
+		tr = np.array(step_trace)
+		print("[bench step trace] ms between loop iterations (warm-up + timed): " + " ".join(f"{x:.3f}" for x in np.diff(tr[:, 0]) * 1e3), file=sys.stderr)
+		print("[bench step trace] host ms in launch(): " + " ".join(f"{x:.3f}" for x in tr[1:, 1] * 1e3), file=sys.stderr)
+		print("[bench step trace] host ms spinning on the previous step's event: " + " ".join(f"{x:.3f}" for x in np.diff(tr[:, 2]) * 1e3), file=sys.stderr)
 	if os.environ.get("ANNCUR_BENCH_DEBUG"):
 		print(f"[bench debug] per step: launch {1e3 * prof['launch'] / (args.steps + args.warmup):.3f} ms, "
 			  f"finish {1e3 * prof['finish'] / (args.steps + args.warmup):.3f} ms (of which event wait {1e3 * prof.get('wait', 0) / (args.steps + args.warmup):.3f} ms, pinned memcpy {1e3 * prof.get('memcpy', 0) / (args.steps + args.warmup):.3f} ms)", file=sys.stderr)

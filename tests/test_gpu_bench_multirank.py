@@ -77,6 +77,9 @@ def test_bench_default_config_is_one_workload_at_every_n():
 	assert c4["n_gpus"] == 2 and c4["value"] == pytest.approx(2 * 6250 * 2 / (c4["ms_per_step"] * 2e-3), rel=1e-6)
 	assert c4["allgather_ms"] > 0 and c4["solo_rank0"]["value"] > 0 and c4["roofline"]["bound"] == "mfma" and c4["roofline"]["achieved"] > 0
 	assert 0.5 < c4["recall"]["recall@100"] <= 1.0
+	# the scan's placement: the CU partition at both shapes, 96 scan CUs where the scan is a third of the step, 64 where it is a quarter
+	assert two["scan_mode"]["used"] == "partition" and two["scan_mode"]["scan_cus"] == 96
+	assert c4["scan_mode"]["used"] == "partition" and c4["scan_mode"]["scan_cus"] == 64
 
 
 def test_bench_rccl_code_path_with_one_rank():

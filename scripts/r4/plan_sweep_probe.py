@@ -8,7 +8,7 @@ from anncur_amd import ops   # noqa: E402
 from anncur_amd.cur import CURApprox   # noqa: E402
 import bench   # noqa: E402
 dev = torch.device("cuda", 0)
-cfg = bench.CONFIGS["cfg2"]
+cfg = bench.CONFIGS[os.environ.get("PLAN_CFG", "cfg2")]
 A_train, A = bench.synth_device(cfg, dev, 0, row_seed=None)
 rng = np.random.default_rng(0)
 anc = sorted(rng.choice(cfg["I"], size=cfg["Ki"], replace=False))
@@ -19,10 +19,16 @@ I, kr = cfg["I"], cfg["k_retvr"]
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 KN = ("ANNCUR_DEBUG_STAGES", "ANNCUR_DEBUG_SAMPLE_GROUPS")
 configs = [("default", {})]
-for f1 in ("0.10", "0.15", "0.18", "0.26", "0.32"): configs.append((f"stage1 {f1}", {"ANNCUR_DEBUG_STAGES": f1}))
-for f in ("0.08,0.30", "0.10,0.40"): configs.append((f"3 stages {f}", {"ANNCUR_DEBUG_STAGES": f}))
-for g in ("256", "384", "768", "1024"): configs.append((f"sample groups {g}", {"ANNCUR_DEBUG_SAMPLE_GROUPS": g}))
-for g, f1 in (("768", "0.18"), ("1024", "0.15"), ("384", "0.26")): configs.append((f"groups {g} + stage1 {f1}", {"ANNCUR_DEBUG_SAMPLE_GROUPS": g, "ANNCUR_DEBUG_STAGES": f1}))
+if os.environ.get("PLAN_CFG", "cfg2") == "cfg2":
+	for f1 in ("0.10", "0.15", "0.18", "0.26", "0.32"): configs.append((f"stage1 {f1}", {"ANNCUR_DEBUG_STAGES": f1}))
+	for f in ("0.08,0.30", "0.10,0.40"): configs.append((f"3 stages {f}", {"ANNCUR_DEBUG_STAGES": f}))
+	for g in ("256", "384", "768", "1024"): configs.append((f"sample groups {g}", {"ANNCUR_DEBUG_SAMPLE_GROUPS": g}))
+	for g, f1 in (("768", "0.18"), ("1024", "0.15"), ("384", "0.26")): configs.append((f"groups {g} + stage1 {f1}", {"ANNCUR_DEBUG_SAMPLE_GROUPS": g, "ANNCUR_DEBUG_STAGES": f1}))
+else:   # the cfg4 per-GPU shape: three stages by default (0.06, 0.26)
+	for f in ("0.04,0.20", "0.04,0.26", "0.06,0.20", "0.06,0.35", "0.09,0.30", "0.03,0.15", "0.10"):
+		configs.append((f"stages {f}", {"ANNCUR_DEBUG_STAGES": f}))
+	for g in ("384", "768", "1024", "2048"): configs.append((f"sample groups {g}", {"ANNCUR_DEBUG_SAMPLE_GROUPS": g}))
+	for g, f in (("1024", "0.04,0.20"), ("2048", "0.04,0.20"), ("1024", "0.03,0.15")): configs.append((f"groups {g} + stages {f}", {"ANNCUR_DEBUG_SAMPLE_GROUPS": g, "ANNCUR_DEBUG_STAGES": f}))
 def call(): return ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
 ref = call().indices.clone()
 res = {}
@@ -30,11 +36,11 @@ for rep in range(3):
 	for name, env in configs:
 		for k_ in KN: os.environ.pop(k_, None)
 		os.environ.update(env)
-		for _ in range(15): out = call()
+		for _ in range(6): out = call()
 		ev[0].record()
-		for _ in range(20): out = call()
+		for _ in range(8): out = call()
 		ev[1].record(); torch.cuda.synchronize()
-		res.setdefault(name, []).append(ev[0].elapsed_time(ev[1]) / 20)
+		res.setdefault(name, []).append(ev[0].elapsed_time(ev[1]) / 8)
 		if rep == 0: assert torch.equal(torch.sort(out.indices, 1).values, torch.sort(ref, 1).values), name
 for name, v in res.items():
 	print(f"{name:32s} " + " ".join(f"{x:.4f}" for x in v) + " ms", flush=True)

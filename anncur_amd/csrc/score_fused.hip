@@ -1733,11 +1733,14 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 #endif
 	// Body of the sweep stages, decided here because the ring body changes the decomposition (512-query workgroups, one per CU)
 	const bool can16 = KP <= 256 && P.QT == 2 && I < (int64_t)(1 << 26);
-	P.body16 = can16 && !mfma32 && !evalf && (mfma16 || k <= WSEL_K);
+	// (default up to k = 384 since late round 4: same process, warm, round robin at cfg2 size -- k = 150: 0.733 vs 0.738 ms for the 32x32x16 body,
+	//  200: 0.779 vs 0.827, 256: 0.829 vs 0.878, 300: 0.909 vs 0.942, 384: 0.951 vs 0.968; level from 500 on: 1.04 / 1.04, 1000: 1.50 / 1.50)
+	constexpr int BODY16_MAX_K = 384;
+	P.body16 = can16 && !mfma32 && !evalf && (mfma16 || k <= BODY16_MAX_K);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_MFMA16") && !evalf) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
 #endif
-	P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && ring;   // opt-in (ANNCUR_TOPK_RING): measured slower than the barrier body, see score16r.hpp
+	P.ring16 = P.body16 && k <= WSEL_K && KP >= 128 && P.chunk == CHUNK_TILES && ring;   // opt-in (ANNCUR_TOPK_RING): measured slower than the barrier body, see score16r.hpp
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_RING16")) P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && atoi(dbg) != 0;
 #endif

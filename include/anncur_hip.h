@@ -190,7 +190,7 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
 #define ANNCUR_TOPK_LEADING_SAMPLE 1
 /*  The sweep has two bodies for Kp <= 256: v_mfma_f32_32x32x16_bf16 with per-lane candidate rings, and v_mfma_f32_16x16x32_bf16 with one
  *    candidate queue per wave (I < 2^26; the chip holds a higher clock on that shape).  Same products and fp32 sums: the result is the
- *    same bit for bit up to the order of exact score ties.  Default: the 16x16x32 body for k <= 128, the 32x32x16 body above.
+ *    same bit for bit up to the order of exact score ties.  Default: the 16x16x32 body for k <= 384, the 32x32x16 body above.
  *  ANNCUR_TOPK_MFMA16 / ANNCUR_TOPK_MFMA32: force the 16x16x32 / the 32x32x16 body (A/B variants).  Kp = 512 has one MFMA shape and two
  *    candidate paths: one queue per wave with the dynamic tile schedule on 16x16x32 MFMAs (default, I < 2^26), per-lane rings with
  *    static shares on 32x32x16 MFMAs (ANNCUR_TOPK_MFMA32). */

@@ -98,7 +98,7 @@ def test_rowwise_topk_gather_random(ops, Q, I, kfrac, bf16, nfrac, kind, pad, se
 
 
 @settings(max_examples=(_N // 4) or 25, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
-@given(Q=st.integers(1, 300), I=st.integers(2500, 90000), K=st.integers(8, 512), k=st.integers(1, 200), rank=st.integers(2, 48),
+@given(Q=st.integers(1, 300), I=st.integers(2500, 90000), K=st.integers(8, 512), k=st.integers(1, 400), rank=st.integers(2, 48),
 	   noise=st.floats(0.0, 0.3), seed=st.integers(0, 10 ** 6), variant=st.sampled_from(["", "", "mfma16", "qt1", "mfma32", "ring"]))
 def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	g = torch.Generator().manual_seed(seed)

@@ -17,9 +17,14 @@ cur = CURApprox(rows=A_train, cols=ops.gather_cols(A_train, anc_dev), row_idxs=n
 Xq = ops.gather_cols(A, anc_dev)
 I, kr = cfg["I"], cfg["k_retvr"]
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-KN = ("ANNCUR_DEBUG_STAGES", "ANNCUR_DEBUG_SAMPLE_GROUPS")
+KN = ("ANNCUR_DEBUG_STAGES", "ANNCUR_DEBUG_SAMPLE_GROUPS", "ANNCUR_DEBUG_CHUNK", "ANNCUR_DEBUG_CAPG", "ANNCUR_DEBUG_FLUSH_TILES", "ANNCUR_DEBUG_F1_SHRINK")
 configs = [("default", {})]
-if os.environ.get("PLAN_CFG", "cfg2") == "cfg2":
+if os.environ.get("PLAN_KNOBS") == "schedule":   # ticket chunk, segment capacity, flush period, first-stage shrink
+	for c in ("4", "8", "16", "32", "64"): configs.append((f"chunk {c}", {"ANNCUR_DEBUG_CHUNK": c}))
+	for c in ("512", "2048"): configs.append((f"capg {c}", {"ANNCUR_DEBUG_CAPG": c}))
+	for c in ("1", "2", "8"): configs.append((f"flush tiles {c}", {"ANNCUR_DEBUG_FLUSH_TILES": c}))
+	for c in ("0.5", "0.8", "1.0"): configs.append((f"f1 shrink {c}", {"ANNCUR_DEBUG_F1_SHRINK": c}))
+elif os.environ.get("PLAN_CFG", "cfg2") == "cfg2":
 	for f1 in ("0.10", "0.15", "0.18", "0.26", "0.32"): configs.append((f"stage1 {f1}", {"ANNCUR_DEBUG_STAGES": f1}))
 	for f in ("0.08,0.30", "0.10,0.40"): configs.append((f"3 stages {f}", {"ANNCUR_DEBUG_STAGES": f}))
 	for g in ("256", "384", "768", "1024"): configs.append((f"sample groups {g}", {"ANNCUR_DEBUG_SAMPLE_GROUPS": g}))

@@ -18,6 +18,7 @@ TOPK_MFMA16 = 2
 TOPK_QT1 = 4
 TOPK_MFMA32 = 8
 TOPK_RING = 16
+TOPK_STAGED = 32
 MAX_TOPK = 2048
 
 _p32 = POINTER(c_int32)

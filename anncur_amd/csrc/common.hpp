@@ -9,7 +9,9 @@
 void anncur_set_error(const char *fmt, ...);
 // internal cross-file helper (topk.hip): out[q*out_stride] = k-th largest of G[q, :n] (n <= 2048), one wave per row
 // coarse: a lower bound within one bf16 ulp of the exact value (two histogram passes instead of four)
-int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st, int coarse = 0);
+constexpr int LADDER_LEVELS = 8;   // threshold ladder of the 16x16x32 sweep (score16.hpp): levels per query, counted in eight 16-bit fields
+int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int k, float *out, int64_t out_stride, hipStream_t st, int coarse = 0,
+							  float *ladder = nullptr, int k2 = 1, float *tau2 = nullptr);
 // internal cross-file helper (gemm.hip): anncur_approx_error without zeroing the sums (adds a column range to them)
 int anncur_internal_approx_error_acc(const void *X, int x_dtype, int64_t ldx, const void *Et, int e_dtype, int64_t lde, const void *Aex, int a_dtype,
 									 int64_t lda, int64_t Q, int64_t I, int64_t K, float *err_sq, float *norm_sq, void *stream);

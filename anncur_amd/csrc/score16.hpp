@@ -19,6 +19,18 @@
 // goes to the segment of (query, item split): ONE segment per (query, split), S per query.  The queue cannot overflow: the tile
 // function checks the fill a few times per tile (every 8 pushes of at most 64 entries) and drains on the spot (cold path) while the
 // next pushes might not fit, and a step drains at its head when the queue holds DRAIN_AT entries or more.
+//
+// Threshold LADDER (round 5).  The prepass bounds a query's k-th best score from below by tau0 = the k-th largest group maximum of an 8 % sample;
+// against tau0 about 1.3 % of the leading tiles' scores pass (one 64-lane compare in two takes the hit branch), and rounds 1-4 raised the
+// threshold only BETWEEN sweep launches (a wave-per-query refinement kernel, 38 us, for one exact update at 22 % of the tiles).  Now the
+// threshold kernel also leaves eight LEVELS per query above tau0 (value-linear between the sample's k-th and a higher order statistic:
+// roughly geometric in rank), and the sweep counts what it keeps: the drain adds every candidate at or above a level the wave has not
+// reached yet to that level's 16-bit field of the query's four counter words (one no-return global_atomic_add per candidate, device scope).
+// Every fourth tile a wave fetches its 64 queries' counter words (one LDS-DMA piece, sc1) and, a tile later, moves each query's threshold up
+// to the highest level at or above which k candidates have been counted by ANY workgroup -- k distinct items score >= that level, so it is a
+// valid lower bound on the k-th best, whatever the timing (a stale count only means a later move).  One launch sweeps all the tiles: no
+// stage boundary, no refinement launch.  cfg2 (model: scripts/r5/survivor_model.py): 442 -> ~340 candidates per query; a field cannot
+// overflow (a wave stops counting a level once its own threshold is there; between two refreshes it adds <= 128 per query).
 #pragma once
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -38,9 +50,19 @@ struct Fused16Cfg {
 	static constexpr int TICKET_OFF = CNT_OFF + NW * 64 * 4;        // ticket words of the dynamic tile schedule (score_kernel)
 	static constexpr int PIECES = TILE_BYTES / 1024 / NW;           // DMA pieces per wave and tile
 	static_assert(PIECES >= 1, "a tile holds at least one 1 KB piece per wave");
-	static constexpr int LDS_BYTES = TICKET_OFF + 16;
+	// threshold ladder (wave-private rows, local query l of wave w at (w * 64 + l)):
+	static constexpr int LVL_OFF = TICKET_OFF + 16;                 // LADDER_LEVELS floats per query (32 bytes), DMA'd once in the prologue
+	static constexpr int LCNT_OFF = LVL_OFF + NW * 64 * 4 * LADDER_LEVELS;   // landing zone of the counter words: 16 bytes per query, refetched every LADDER_PERIOD tiles
+	static constexpr int JCUR_OFF = LCNT_OFF + NW * 64 * 16;        // the level this wave's threshold of the query has reached (0 = tau0): what the drain still counts
+	static constexpr int LDS_BYTES = JCUR_OFF + NW * 64 * 4;
+	static_assert(NW != 4 || LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+	static_assert(LADDER_LEVELS == 8, "two 128-bit reads per query; eight 16-bit fields in four counter words");
 	static constexpr int BQ = 64 * NW;
 };
+#ifndef ANNCUR_LADDER_PERIOD
+#define ANNCUR_LADDER_PERIOD 16
+#endif
+constexpr int LADDER_PERIOD = ANNCUR_LADDER_PERIOD;   // tiles between two fetches of a wave's counter words (a power of two)
 constexpr uint32_t WQ_ITEM_BITS = 26, WQ_ITEM_MASK = (1u << WQ_ITEM_BITS) - 1u;
 
 // wave-uniform state of the candidate path (scalars)
@@ -51,12 +73,16 @@ struct WaveQueue {
 	uint32_t q_stride8;        // BYTES between the segments of consecutive queries (segments per query x capg x 8; x 63 queries < 2^32: nseg <= 255, capg <= 16384)
 	uint32_t capg, n_items;
 	int lane;
+	// threshold ladder (lad_on = 0: none): LDS byte addresses of the wave's level rows and reached-level words, the wave's first query's counter words
+	uint32_t lad_on, lvl, jcur;
+	uint32_t *lcnt;
 };
 
 // Drain: entry i of the queue -> lane i & 63 of pass i >> 6.  Segment address = uniform base + 32-bit byte offset (round 4; round 3 built a
 // 64-bit address per entry with two v_mad_u64_u32).  (Round 4 also tried two passes per iteration -- both entries read back to back, both
 // counter draws back to back: one LDS round trip less per 128 entries, seven more live registers where the drain is inlined into the tile
 // function, which the 256-register ring kernel does not have; no measurable gain in the 4-wave kernel either.)
+template <bool LAD = false>
 __device__ __forceinline__ void wq_drain(const WaveQueue &w, uint32_t &fill) {
 	const uint32_t n = (fill - w.base) >> 3;  // (uniform)
 	unsigned char *const segb = reinterpret_cast<unsigned char *>(w.seg);
@@ -73,6 +99,19 @@ __device__ __forceinline__ void wq_drain(const WaveQueue &w, uint32_t &fill) {
 				asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(w.cnt + ql * 4u), "v"(one) : "memory");
 #endif
 				if (pos < w.capg) *reinterpret_cast<uint2 *>(segb + (ql * w.q_stride8 + pos * 8u)) = make_uint2(e.x, item);
+				if (LAD && w.lad_on) {   // (uniform) count the candidate at the highest ladder level it reaches, if the wave is not there yet
+					f32x4 la = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};
+					uint32_t jc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+					asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b32 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+								 : "=&v"(la), "=&v"(lb), "=&v"(jc) : "v"(w.lvl + ql * 32u), "v"(w.jcur + ql * 4u) : "memory");
+#endif
+					const float v = __uint_as_float(e.x);
+					const uint32_t j = (uint32_t)(v >= la[0]) + (uint32_t)(v >= la[1]) + (uint32_t)(v >= la[2]) + (uint32_t)(v >= la[3])
+									   + (uint32_t)(v >= lb[0]) + (uint32_t)(v >= lb[1]) + (uint32_t)(v >= lb[2]) + (uint32_t)(v >= lb[3]);   // levels ascend: j = the highest reached
+					if (j > jc)
+						(void)__hip_atomic_fetch_add(w.lcnt + ql * 4u + ((j - 1u) >> 1), 1u << (16u * ((j - 1u) & 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 			}
 		}
 	}
@@ -90,6 +129,48 @@ __device__ __forceinline__ void filter16_one(float v, uint32_t code, float tau, 
 			lds_store_2x32(fill + rank * 8u, __float_as_uint(v), item0c + code);
 		}
 		fill += 8u * (uint32_t)__builtin_popcountll(m);
+	}
+}
+
+__device__ __forceinline__ uint32_t opaque_u32(uint32_t x) {   // the value, hidden from the optimiser (no hoisting, no CSE with earlier uses)
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("" : "+v"(x));
+#endif
+	return x;
+}
+__device__ __forceinline__ void ladder_fetch(const uint32_t *lcnt_wave, uint32_t land, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t voff = (uint32_t)lane * 16u;
+	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(land), "v"(voff), "s"(lcnt_wave) : "memory", "m0");
+#endif
+}
+
+// Ladder refresh (lane l <-> local query l of the wave): the counter words fetched LADDER_PERIOD tiles ago (this wave's own DMA piece, behind its
+// own vmcnt(0) at the end of that tile) -> the highest level at or above which k candidates have been counted -> the thresholds of the
+// MFMA layout (lane (g4, c16) serves queries 16 t + c16).  tn = -inf where no level qualifies.
+__device__ __forceinline__ void ladder_refresh(uint32_t lcnt_lane, uint32_t lvl_lane, uint32_t jcur_lane, uint32_t k, int c16, float (&tau)[4]) {
+	u32x4 c = {0u, 0u, 0u, 0u};
+	f32x4 la = {0.f, 0.f, 0.f, 0.f}, lb = {0.f, 0.f, 0.f, 0.f};
+	uint32_t jc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:16\n\tds_read_b32 %3, %6\n\ts_waitcnt lgkmcnt(0)"
+				 : "=&v"(c), "=&v"(la), "=&v"(lb), "=&v"(jc) : "v"(lcnt_lane), "v"(lvl_lane), "v"(jcur_lane) : "memory");
+#endif
+	const float lv[8] = {la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+	uint32_t cum = 0, jn = 0;
+	float tn = -INFINITY;
+#pragma unroll
+	for (int j = 8; j >= 1; --j) {
+		cum += (c[(j - 1) >> 1] >> (16 * ((j - 1) & 1))) & 0xffffu;
+		const bool take = jn == 0u && cum >= k;
+		jn = take ? (uint32_t)j : jn;
+		tn = take ? lv[j - 1] : tn;
+	}
+	if (jn > jc) lds_store_u32(jcur_lane, jn);
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		const float o = __int_as_float(__builtin_amdgcn_ds_bpermute((16 * t + c16) * 4, __float_as_int(tn)));
+		tau[t] = fmaxf(tau[t], o);
 	}
 }
 
@@ -124,7 +205,8 @@ __device__ __forceinline__ void stagger16_tile(const uint32_t (&aoff)[Fused16Cfg
 #endif
 		// (uniform, cold) every 8 pushes: the queue must take the next 8 + EPS (64 entries each at most) -- checked a few times per tile, not
 		// per push (two scalar instructions per step cost the bare loop 10 %; per push the 48 inlined drains ran the kernel out of SGPRs)
-		if (g > 0 && (g * EPS) % 8 == 0 && __builtin_expect(fill > w.limit, 0)) wq_drain(w, fill);
+		// (this drain does not count for the ladder: an uncounted candidate only delays a move, and the level reads would be live beside the accumulators)
+		if (g > 0 && (g * EPS) % 8 == 0 && __builtin_expect(fill > w.limit, 0)) wq_drain<false>(w, fill);
 		const int after = 2 * K - 1 - g;
 		lds_wait_frag(ring[g % AR], after < DIST ? after : DIST);
 		const bf16x8 a = __builtin_bit_cast(bf16x8, ring[g % AR]);
@@ -196,11 +278,29 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 	w.q_stride8 = (uint32_t)p.nseg * (uint32_t)p.capg * 8u;
 	w.seg = p.cand + (q_wave0 * p.nseg + split) * (int64_t)p.capg;
 	w.capg = (uint32_t)p.capg; w.n_items = (uint32_t)p.I; w.lane = lane;
+	w.lad_on = (uint32_t)p.ladder_on;
+	w.lvl = lds_base + (uint32_t)(C::LVL_OFF + wave_u * 64 * 4 * LADDER_LEVELS);
+	w.jcur = lds_base + (uint32_t)(C::JCUR_OFF + wave_u * 256);
+	w.lcnt = p.ladder_cnt + q_wave0 * 4;   // (the arrays are padded to whole row blocks: rows past Q are never counted, their thresholds are +inf)
+	const uint32_t lcnt_land = lds_base + (uint32_t)(C::LCNT_OFF + wave_u * 1024);
 	uint32_t fill = w.base;
 	{
 		const int64_t q = q_wave0 + lane;
 		lds_store_u32(w.cnt + (uint32_t)lane * 4u, (p.carry && q < p.Q) ? p.seg_cnt[q * p.nseg + split] : 0u);
+		lds_store_u32(w.jcur + (uint32_t)lane * 4u, 0u);
 	}
+	if (p.ladder_on) {   // (uniform) the wave's 64 level rows: 2 KB = two DMA pieces, waited for with the first tile
+#if defined(__HIP_DEVICE_COMPILE__)
+		const unsigned char *lsrc = reinterpret_cast<const unsigned char *>(p.ladder + q_wave0 * LADDER_LEVELS);
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const uint32_t m0v = w.lvl + (uint32_t)i * 1024u, voff = (uint32_t)(i * 1024 + lane * 16);
+			asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(lsrc) : "memory", "m0");
+		}
+#endif
+	}
+	uint32_t lad_tick = 0;
+	bool lad_pending = false;
 
 	// ---- tile schedule (see score_kernel): static contiguous share, or tickets of p.chunk_tiles tiles from the row block's counter
 	int t_cur = j_begin < j_end ? j_begin : -1, t_cend = j_end, t_next_chunk = -1;
@@ -271,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 	}
 	const uint32_t lane_code = (uint32_t)c16 << WQ_ITEM_BITS;
 	__builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): stagger16_tile() counts LDS reads
-	const float tau_hi[2] = {tau[2], tau[3]};
+	float tau_hi[2] = {tau[2], tau[3]};
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	uint32_t ph_acc[5] = {0u, 0u, 0u, 0u, 0u};   // phase stamps of the diagnostic build: see score_kernel
 	uint32_t ph_t = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -287,7 +387,25 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 	//  0.4888 at a period of 24 tiles; the per-tile barrier wait it was meant to remove is the waves' HIT imbalance, not their drains -- phase
 	//  stamps: barrier 546 -> 441 cycles per first-stage tile, drains 206 -> 274 -- and the countdown's own instructions cost 1.3 % of the
 	//  sweep even when switched off.  Removed; profiles/r04_ring_and_drain_experiments.txt.)
-#define R16_DRAIN_CHECK(J) do { if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain(w, fill); } while (0)
+#define R16_DRAIN_CHECK(J) do { if (fill >= w.base + C::DRAIN_AT * 8u) wq_drain<true>(w, fill); } while (0)
+	// ladder, at the head of a tile (uniform branches): consume the counter words fetched a tile ago; every LADDER_PERIOD tiles fetch them again
+	// (ONE piece: 64 queries x 16 bytes, sc1 = served by L2 / the fabric, never by this CU's L1; it lands before this tile's closing vmcnt(0))
+#define LADDER_STEP()                                                                                                           \
+	do {                                                                                                                        \
+		if (p.ladder_on) {                                                                                                      \
+			const uint32_t ll_ = opaque_u32((uint32_t)lane);   /* (the per-lane addresses below must not become loop-invariant registers of the tile loop) */ \
+			if (lad_pending) {                                                                                                  \
+				ladder_refresh(lcnt_land + ll_ * 16u, w.lvl + ll_ * 32u, w.jcur + ll_ * 4u, p.ladder_k, (int)(ll_ & 15u), tau);     \
+				tau_hi[0] = tau[2]; tau_hi[1] = tau[3];                                                                         \
+				tau_prev[0] = fmaxf(tau_prev[0], tau[2]); tau_prev[1] = fmaxf(tau_prev[1], tau[3]);                             \
+				lad_pending = false;                                                                                            \
+			}                                                                                                                   \
+			if ((++lad_tick & (LADDER_PERIOD - 1)) == 0u) {                                                                     \
+				ladder_fetch(w.lcnt, lcnt_land, (int)ll_);                                                                      \
+				lad_pending = true;                                                                                             \
+			}                                                                                                                   \
+		}                                                                                                                       \
+	} while (0)
 #define STAGGER16_STEP(CUR)                                                                                                     \
 	do {                                                                                                                        \
 		const int J = t_cur;                                                                                                    \
@@ -304,6 +422,7 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 		uint32_t ticket = 0;                                                                                                    \
 		if (crossed && tid == 0) ticket_draw(ticket, ctr_rb + slice);                                                           \
 		PH16(0);                                                                                                                \
+		LADDER_STEP();                                                                                                          \
 		R16_DRAIN_CHECK(J);                                                                                                     \
 		const uint32_t item0 = ((uint32_t)J * TILE_I + 4 * g4) | lane_code;                                                     \
 		PH16(1);                                                                                                                \
@@ -338,6 +457,7 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 		STAGGER16_STEP(1);
 	}
 #undef STAGGER16_STEP
+#undef LADDER_STEP
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (lane == 0 && d_sweep_stamps && p.debug_stamp && blockIdx.x * NW + wave < 8192) {
 		unsigned long long *ph = d_sweep_stamps + 5 * 8192 + (size_t)(blockIdx.x * NW + wave) * 8;
@@ -355,7 +475,7 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 #undef PH16
 #undef PH16_TILE
 	// drain: sub-tiles {2,3} of the last tile (16 pushes: at most the whole queue)
-	wq_drain(w, fill);
+	wq_drain<true>(w, fill);
 #define F16_LAST(e)                                                                                                             \
 	filter16_one(accP[(e) >> 3][((e) >> 2) & 1][(e) & 3],                                                                       \
 				 (uint32_t)((((e) >> 3) * 16 + ((e) & 3)) | ((uint32_t)(2 + (((e) >> 2) & 1)) << (WQ_ITEM_BITS + 4))),         \
@@ -364,7 +484,21 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 	F16_LAST(8); F16_LAST(9); F16_LAST(10); F16_LAST(11); F16_LAST(12); F16_LAST(13); F16_LAST(14); F16_LAST(15);
 #undef F16_LAST
 #undef F16_ELEM
-	wq_drain(w, fill);
+	wq_drain<true>(w, fill);
+	if (p.ladder_on) {   // the thresholds this wave ended with: the select's prefilter is the highest any workgroup reached (all of them are valid)
+		// (query ids recomputed from an opaque lane id: kept from the prologue they were eight VGPRs live across the tile loop -- spills at Kp = 256)
+		const int le = (int)opaque_u32((uint32_t)lane);
+		if ((le >> 4) == 0) {
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const int64_t qe = q_wave0 + 16 * t + (le & 15);
+				if (qe < p.Q) {
+					if (tau[t] >= 0.f) atomicMax(reinterpret_cast<int *>(p.tau_final + qe), __float_as_int(tau[t]));
+					else atomicMin(reinterpret_cast<unsigned int *>(p.tau_final + qe), __float_as_uint(tau[t]));
+				}
+			}
+		}
+	}
 	{
 		const int64_t q = q_wave0 + lane;
 		uint32_t c = 0;

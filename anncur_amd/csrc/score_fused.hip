@@ -109,6 +109,10 @@ struct FusedParams {
 	uint32_t *chunk_ctr;              // [n row blocks], zero at launch
 	uint8_t *chunk_owner;             // [n row blocks x n_chunks]: which item split swept the chunk (the repair path's map)
 	int sliced, chunks_per_slice;     // XCD-sliced tickets: chunk_ctr is [row block][N_SLICES], slice s = chunks [s * chunks_per_slice, + chunks_per_slice)
+	// threshold ladder of score16_kernel (score16.hpp): levels [n_rb x BQ][LADDER_LEVELS], counter words [n_rb x BQ][4] (zero at launch),
+	// the cell each wave raises to the threshold it ended with (initialised to tau0 by the threshold kernel), k
+	int ladder_on; uint32_t ladder_k;
+	const float *ladder; uint32_t *ladder_cnt; float *tau_final;
 	uint32_t *nfb;                    // the call's fallback counter (workspace word 0): the ring kernel reports a spin timeout there
 	int ring_stagger, ring_spin_sleep; // ring kernel: start delay of waves 4..7 in units of 64 cycles; s_sleep between two polls of a waiting wave
 };
@@ -1594,6 +1598,9 @@ struct FusedPlan {
 	bool bodyq1;  // the sweep stages run scoreq1_kernel (Kp = 512)
 	bool bodyq16; // ... scoreq16_kernel: the same body on 16x16x32 MFMAs
 	int chunk;  // dynamic tile schedule of the sweep stages: tiles per ticket (0: static shares)
+	bool ladder;  // score16_kernel moves its thresholds up a ladder of levels inside ONE sweep launch (score16.hpp): no stages, no refinement launches
+	int ladder_k2; // rank (in the prepass sample's group maxima) of the ladder's top level
+	size_t off_lcnt, off_lvl, off_tau2;
 	size_t off_gmax, off_tval, off_tidx, off_segcnt, off_cand, off_tau, off_hard, off_ctr, off_owner, total;
 };
 
@@ -1682,7 +1689,8 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	}
 }
 
-FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false, bool mfma32 = false, bool ring = false, bool evalf = false) {
+FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, bool mfma16 = false, bool qt1 = false, bool mfma32 = false, bool ring = false, bool evalf = false,
+					 bool no_ladder = false) {
 	FusedPlan P{};
 	P.ok = false;
 	P.leading = leading ? 1 : 0;
@@ -1787,10 +1795,29 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
 	int ft = (int)(0.35 / (per_lane_tile > 1e-9 ? per_lane_tile : 1e-9));
 	P.flush_tiles = ft < 1 ? 1 : (ft > 8 ? 8 : ft);
-	plan_stages(P, Q, k, exp_hits, (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
+	// Threshold ladder (score16.hpp, round 5): the default 16x16x32 body raises its thresholds inside ONE launch from counts of what it keeps, so it
+	// runs unstaged.  The ladder's top level = the sample's group maximum of rank k2 ~ where the k-th best of ALL items is expected to fall among
+	// the sample's (k x sample items / I; the norm-ordered leading sample holds about twice its share of the high scorers), at least 3, at most k / 2.
+	P.ladder = P.body16 && !P.ring16 && !P.wg8 && !no_ladder && P.n_groups <= 4096 && P.chunk > 0;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_LADDER")) P.ladder = P.ladder && atoi(dbg) != 0;
+#endif
+	{
+		double r = (double)k * ((double)P.n_st * TILE_I / (double)I) * (leading ? 2.0 : 1.25);
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+		if (const char *dbg = getenv("ANNCUR_DEBUG_LADDER_K2")) r = atof(dbg);
+#endif
+		int k2 = (int)(r + 0.5);
+		if (k2 > k / 2) k2 = k / 2;
+		if (k2 < 3) k2 = 3;
+		if (k2 > k) k2 = k;
+		P.ladder_k2 = k2;
+	}
+	plan_stages(P, Q, k, exp_hits, !P.ladder && (k <= WQ_K2 ? P.lg * P.S <= WAVE : true) && P.n_tiles >= 24 * P.S, 4.0 * P.S / P.n_tiles, TILE_I);
 	P.kmax = k <= 128 ? 128 : (k <= 512 ? 512 : 2048);
 	size_t off = 256;
 	P.off_ctr = off;    off = align256(off + (size_t)P.n_rb * 3 * 4 * N_SLICES);   // ticket counters [stage][row block][slice]: zeroed with the header, one memset
+	P.off_lcnt = off;   off = align256(off + (P.ladder ? (size_t)P.n_rb_s * P.BQ_s * 16 : 0));   // ladder counter words: zeroed with the header too
 	P.off_gmax = off;   off = align256(off + (size_t)Q * P.n_groups * 4);
 	P.off_tval = off;   off = align256(off + (size_t)Q * k * 4);
 	P.off_tidx = off;   off = align256(off + (size_t)Q * k * 4);
@@ -1798,6 +1825,8 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.off_tau = off;    off = align256(off + (size_t)Q * 4);
 	P.off_hard = off;   off = align256(off + (size_t)Q * 4);
 	P.off_owner = off;  off = align256(off + (size_t)3 * P.n_rb * (size_t)(P.n_tiles / (P.chunk > 0 ? P.chunk : P.n_tiles) + 2));   // chunk owners
+	P.off_lvl = off;    off = align256(off + (P.ladder ? (size_t)P.n_rb_s * P.BQ_s * 4 * LADDER_LEVELS : 0));
+	P.off_tau2 = off;   off = align256(off + (P.ladder ? (size_t)Q * 4 : 0));
 	P.off_cand = off;   off = align256(off + (size_t)Q * P.lg * P.S * (size_t)P.capg * 8);
 	P.total = off;
 	P.ok = true;
@@ -1867,7 +1896,7 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 		if ((rc = anncur_ensure_dyn_lds((const void *)select_candidates_kernel<KM>, (int)lds)) != ANNCUR_OK) return rc; \
 		hipLaunchKernelGGL((select_candidates_kernel<KM>), dim3(sel_grid), dim3(SEL_THREADS), lds, st, cand, seg_cnt, nseg, \
 						   P.S, stages, P.capg, X, ldx, Et, I, KP, (uint32_t)k, out_val, out_idx, (uint32_t *)ws, hard_list, hard_cnt,      \
-						   P.n_stages > 1 ? tau : (const float *)nullptr, tau_stride, remap);                                            \
+						   (P.n_stages > 1 || P.ladder) ? tau : (const float *)nullptr, tau_stride, remap);                              \
 	} while (0)
 	const int32_t *hard_list = nullptr;
 	const uint32_t *hard_cnt = nullptr;
@@ -1880,13 +1909,13 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 			constexpr int lds = 4 * WaveSelLayout<WqCfg<KW>::CAP>::BYTES;                                                         \
 			if ((rc = anncur_ensure_dyn_lds((const void *)select_wave_kernel<false, KW>, lds)) != ANNCUR_OK) return rc;           \
 			hipLaunchKernelGGL((select_wave_kernel<false, KW>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, P.capg, Q, \
-							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0, remap); \
+							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, (P.n_stages > 1 || P.ladder) ? 1 : 0, remap); \
 		} while (0)
 #define LAUNCH_SSEL(EE)                                                                                                           \
 		do {                                                                                                                      \
 			constexpr int lds = 4 * StreamSelLayout::BYTES;                                                                       \
 			hipLaunchKernelGGL((select_stream_kernel<false, EE>), dim3((unsigned)ceil_div64(Q, 4)), dim3(256), lds, st, cand, seg_cnt, nseg, P.capg, Q, \
-							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, P.n_stages > 1 ? 1 : 0, remap); \
+							   (uint32_t)k, out_val, out_idx, hc, hl, const_cast<float *>(tau), tau_stride, (P.n_stages > 1 || P.ladder) ? 1 : 0, remap); \
 		} while (0)
 		if (k <= WSEL_K) { if (stream_select_small()) LAUNCH_SSEL(2); else LAUNCH_WSEL(128); }
 		else if (k <= 256) LAUNCH_SSEL(4);
@@ -1908,7 +1937,8 @@ int launch_select(const FusedPlan &P, int nseg, const SweepStages &stages, const
 int launch_threshold(const FusedPlan &P, const float *gmax, int64_t Q, int k, unsigned char *ws, const float *&tau, int &tau_stride, hipStream_t st) {
 	if (P.n_groups <= 4096) {  // one wave per query, keys in LDS (kth_value_wave_kernel)
 		float *t = (float *)(ws + P.off_tau);
-		const int rc = anncur_internal_kth_value(gmax, Q, P.n_groups, P.n_groups, k, t, 1, st, /*coarse=*/1);   // (any lower bound on the k-th best will do)
+		const int rc = P.ladder ? anncur_internal_kth_value(gmax, Q, P.n_groups, P.n_groups, k, t, 1, st, /*coarse=*/1, (float *)(ws + P.off_lvl), P.ladder_k2, (float *)(ws + P.off_tau2))
+								: anncur_internal_kth_value(gmax, Q, P.n_groups, P.n_groups, k, t, 1, st, /*coarse=*/1);   // (any lower bound on the k-th best will do)
 		tau = t; tau_stride = 1;
 		return rc;
 	}
@@ -1995,6 +2025,11 @@ void co_abort(CoScan *co, hipStream_t st) {
 		if (co->row_end[i] > (i ? co->row_end[i - 1] : 0)) (void)hipStreamWaitEvent(st, co->ev[2 * i + 1], 0);
 }
 
+// error_lds_kernel / evalf_kernel address the workgroup's tile of the exact matrix as a uniform 64-bit base + a 32-bit byte offset per lane,
+// (row within the row block) x pitch x 2 + chunk: the routes that use them are taken only while the last row's offset stays below 2^32
+// (bq = 256 rows: pitch < 8 421 504 elements).  ADVICE r4: unchecked, a longer pitch read the wrong rows silently.
+bool exact_tile_offsets_fit(int64_t lda, int bq) { return lda >= 0 && (uint64_t)(bq - 1) * (uint64_t)lda * 2u + 64u < ((uint64_t)1 << 32); }
+
 // anncur_eval_fused: the exact matrix and the two per-row sums the sweep stages also produce (evalf_kernel)
 struct EvalArgs { const uint16_t *A; int64_t lda; float *err_sq, *norm_sq; };
 
@@ -2019,6 +2054,8 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (const char *dbg = getenv("ANNCUR_DEBUG_RING_SLEEP")) p.ring_spin_sleep = atoi(dbg);
 #endif
 	p.nseg = P.lg * P.S;
+	p.ladder_on = P.ladder ? 1 : 0; p.ladder_k = (uint32_t)k;
+	p.ladder = (const float *)(ws + P.off_lvl); p.ladder_cnt = (uint32_t *)(ws + P.off_lcnt); p.tau_final = (float *)(ws + P.off_tau2);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {
 		if (!g_stamps) {
@@ -2035,7 +2072,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 
 	const int chunk = (P.chunk > 0 && (Cfg::QT == 2 || P.bodyq1)) ? P.chunk : 0;   // (the one-sub-tile bodies with per-lane rings keep static shares)
 	const int owner_stride = P.n_rb * (P.n_tiles / (chunk > 0 ? chunk : P.n_tiles) + 2);
-	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, chunk > 0 ? P.off_gmax : 256, st));   // header (+ the stages' ticket counters)
+	ANNCUR_HIP_OK(hipMemsetAsync(ws, 0, (chunk > 0 || P.ladder) ? P.off_gmax : 256, st));   // header (+ the stages' ticket counters, the ladder's counter words)
 	EV(0);
 	// 1. prepass
 	p.n_wg = P.n_rb * P.S0;
@@ -2196,7 +2233,9 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 		stages.n_chunks[g] = chunk > 0 ? (P.stage_end[g] - prev + chunk - 1) / chunk : 0;
 		stages.owner[g] = (const uint8_t *)(ws + P.off_owner) + (size_t)g * owner_stride;
 	}
-	if ((rc = launch_select(P, P.lg * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st, item_ids)) != ANNCUR_OK) return rc;
+	// (ladder: the prefilter is the highest threshold a workgroup ended the sweep with -- k candidates at or above it were counted)
+	if ((rc = launch_select(P, P.lg * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, P.ladder ? p.tau_final : p.tau,
+							P.ladder ? 1 : p.tau_stride, st, item_ids)) != ANNCUR_OK) return rc;
 	EV(4);
 	return ANNCUR_OK;
 }
@@ -2328,9 +2367,10 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 
 FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, int flags = 0) {
 	const bool leading = (flags & ANNCUR_TOPK_LEADING_SAMPLE) != 0, mfma16 = (flags & ANNCUR_TOPK_MFMA16) != 0, qt1 = (flags & ANNCUR_TOPK_QT1) != 0;
-	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1, (flags & ANNCUR_TOPK_MFMA32) != 0, (flags & ANNCUR_TOPK_RING) != 0);
+	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1, (flags & ANNCUR_TOPK_MFMA32) != 0, (flags & ANNCUR_TOPK_RING) != 0,
+																	  false, (flags & ANNCUR_TOPK_STAGED) != 0);
 }
-constexpr int TOPK_FLAGS = ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1 | ANNCUR_TOPK_MFMA32 | ANNCUR_TOPK_RING;
+constexpr int TOPK_FLAGS = ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1 | ANNCUR_TOPK_MFMA32 | ANNCUR_TOPK_RING | ANNCUR_TOPK_STAGED;
 
 }  // namespace
 
@@ -2338,7 +2378,7 @@ extern "C" size_t anncur_score_topk_workspace_bytes(int64_t Q, int64_t I, int32_
 	const FusedPlan P = plan_any(Q, I, Kp, k);
 	if (!P.ok) return 0;
 	size_t t = P.total;
-	for (int flags : {ANNCUR_TOPK_MFMA16, ANNCUR_TOPK_MFMA32, ANNCUR_TOPK_QT1, ANNCUR_TOPK_RING}) {  // (whatever variant flag the call will carry)
+	for (int flags : {ANNCUR_TOPK_MFMA16, ANNCUR_TOPK_MFMA32, ANNCUR_TOPK_QT1, ANNCUR_TOPK_RING, ANNCUR_TOPK_STAGED}) {  // (whatever variant flag the call will carry)
 		const FusedPlan V = plan_any(Q, I, Kp, k, flags);
 		if (V.ok && V.total > t) t = V.total;
 	}
@@ -2431,6 +2471,9 @@ extern "C" int anncur_eval_fused(const void *X, int64_t ldx, const void *Et, int
 	ANNCUR_REQUIRE(a_dtype == ANNCUR_BF16 && A && (lda % 8) == 0 && ((uintptr_t)A % 16) == 0 && lda >= I, ANNCUR_E_UNSUPPORTED,
 				   "eval_fused: the exact matrix must be bf16 with 16-byte aligned rows (lda a multiple of 8): use anncur_score_topk + anncur_approx_error(_packed) otherwise");
 	ANNCUR_REQUIRE(err_sq && norm_sq, ANNCUR_E_INVALID, "eval_fused: null pointer");
+	ANNCUR_REQUIRE(exact_tile_offsets_fit(lda, 256), ANNCUR_E_UNSUPPORTED,
+				   "eval_fused: row pitch %lld of the exact matrix is too long for the kernel's 32-bit tile offsets (255 rows x pitch x 2 bytes must stay below 2^32): use anncur_score_topk + anncur_approx_error_packed",
+				   (long long)lda);
 	ANNCUR_REQUIRE(anncur_eval_fused_workspace_bytes(Q, I, Kp, k) > 0, ANNCUR_E_UNSUPPORTED, "eval_fused: shape (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path",
 				   (long long)Q, (long long)I, Kp, k);
 	if (Q == 0) return ANNCUR_OK;
@@ -2500,19 +2543,21 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
 /* the same for the flags of anncur_score_topk_ex: out[0 .. n_out) = {sample tiles, item tiles, S, segment capacity, group, segments per
  * query and item split (2: 32x32x16 sweep, 1: 16x16x32 sweep, 4: wide kernel), 32-query sub-tiles per wave, sweep stages,
  * stage_end[3], stage body[3] (0: 32x32x16 with the ballot filter, 1: with the exec-mask filter, 2: 16x16x32, 3 / 4: Kp = 512 with the
- * wave-level queue on 32x32x16 / 16x16x32 MFMAs, 5: 16x16x32 in 8-wave workgroups with the flag-synchronised tile ring), ring drain period[3]} --
+ * wave-level queue on 32x32x16 / 16x16x32 MFMAs, 5: 16x16x32 in 8-wave workgroups with the flag-synchronised tile ring), ring drain period[3],
+ * threshold ladder (1: the sweep raises its thresholds in-launch, score16.hpp; 0: staged), rank of the ladder's top level} --
  * what a test needs to see that a variant flag was honoured */
 extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
 	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
 	const FusedPlan P = plan_any(Q, I, Kp, k, flags);
 	ANNCUR_REQUIRE(P.ok && out && n_out >= 0, ANNCUR_E_UNSUPPORTED, "score_topk_plan_ex: unsupported shape");
 	const bool wide = wide_kp(Kp);
-	int32_t v[17] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
+	int32_t v[19] = {P.n_st, P.n_tiles, P.S, P.capg, P.group, wide ? 4 : P.lg, P.QT, P.n_stages};
+	v[17] = (!wide && P.ladder) ? 1 : 0; v[18] = (!wide && P.ladder) ? P.ladder_k2 : 0;
 	for (int g = 0; g < 3; ++g) {
 		const bool on = g < P.n_stages;
 		v[8 + g] = on ? P.stage_end[g] : 0; v[11 + g] = on ? (!wide && P.bodyef ? 6 : !wide && P.ring16 ? 5 : !wide && P.body16 ? 2 : (!wide && P.bodyq16 ? 4 : (!wide && P.bodyq1 ? 3 : P.stage_pred[g]))) : 0; v[14 + g] = on ? P.stage_flush[g] : 0;
 	}
-	for (int i = 0; i < n_out && i < 17; ++i) out[i] = v[i];
+	for (int i = 0; i < n_out && i < 19; ++i) out[i] = v[i];
 	return ANNCUR_OK;
 }
 
@@ -2582,7 +2627,8 @@ extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void
 		}                                                                                                                     \
 	} while (0)
 	// bf16 exact matrix with 16-byte aligned rows: the kernel that stages the exact tile through LDS
-	const bool lds_exact = a_dtype == ANNCUR_BF16 && (lda % 8) == 0 && ((uintptr_t)A % 16) == 0;
+	// (and a row pitch whose 32-bit tile offsets cannot wrap: exact_tile_offsets_fit; longer pitches take error_kernel's 64-bit row pointers)
+	const bool lds_exact = a_dtype == ANNCUR_BF16 && (lda % 8) == 0 && ((uintptr_t)A % 16) == 0 && exact_tile_offsets_fit(lda, Kp <= 256 ? 256 : 128);
 	if (lds_exact) {
 #define LAUNCH_ERRL(KPV)                                                                                                      \
 		do {                                                                                                                  \

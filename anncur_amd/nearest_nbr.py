@@ -121,6 +121,8 @@ class IVFFlatIPIndex:
 			X = ops.gather_rows(X, np.sort(rng.choice(n, size=cap, replace=False)))
 			n = cap
 		self.centroids = ops.gather_rows(X, rng.permutation(n)[:self.nlist])   # initial centroids: distinct random training points
+		if self.spherical:
+			ops.renorm_rows(self.centroids)   # FAISS post-processes the INITIAL centroids too (Clustering::train): the first assignment already runs on unit vectors
 		for it in range(self.niter):
 			counts, offsets, ids = ops.ivf_build_lists(self._assign(X), self.nlist)
 			ops.ivf_list_means(ops.gather_rows(X, ids), offsets, self.centroids)

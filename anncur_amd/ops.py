@@ -276,8 +276,15 @@ def approx_error_packed(Xp, Etp, A_exact, n_items):
 
 def eval_fused_ok(Kp, A_exact, Q, I, k):
 	"""True if anncur_eval_fused takes this cell: Kp <= 256, bf16 exact matrix with 16-byte aligned rows, shape inside the fused path."""
-	return (Kp in (64, 128, 256) and A_exact.dim() == 2 and A_exact.dtype == torch.bfloat16 and A_exact.stride(1) == 1 and _ld(A_exact) % 8 == 0
-			and _ld(A_exact) >= A_exact.shape[1] and A_exact.data_ptr() % 16 == 0 and _lib.load().anncur_eval_fused_workspace_bytes(Q, I, Kp, k) > 0)
+	if not (Kp in (64, 128, 256) and A_exact.dim() == 2 and A_exact.dtype == torch.bfloat16 and A_exact.stride(1) == 1 and _ld(A_exact) % 8 == 0
+			and _ld(A_exact) >= A_exact.shape[1] and A_exact.data_ptr() % 16 == 0):
+		return False
+	# the kernel's exact-tile offsets are 32-bit (255 rows x pitch x 2 bytes, csrc/score_fused.hip exact_tile_offsets_fit): longer pitches take the two-kernel route
+	if 255 * _ld(A_exact) * 2 + 64 >= 1 << 32:
+		return False
+	# one workspace for the whole cell (no query chunks here): cells above the limit take the chunked two-kernel route
+	nbytes = _lib.load().anncur_eval_fused_workspace_bytes(Q, I, Kp, k)
+	return 0 < nbytes <= FUSED_WS_LIMIT_BYTES
 
 
 @_on_device
@@ -460,14 +467,14 @@ def _item_ids_arg(item_ids, I, device):
 	return item_ids
 
 
-def _topk_flags(leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False):
+def _topk_flags(leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False, staged=False):
 	"""The flags word of anncur_score_topk_ex / _timed / _plan_ex."""
 	return ((_lib.TOPK_LEADING_SAMPLE if leading_sample else 0) | (_lib.TOPK_MFMA16 if mfma16 else 0) | (_lib.TOPK_QT1 if qt1 else 0)
-			| (_lib.TOPK_MFMA32 if mfma32 else 0) | (_lib.TOPK_RING if ring else 0))
+			| (_lib.TOPK_MFMA32 if mfma32 else 0) | (_lib.TOPK_RING if ring else 0) | (_lib.TOPK_STAGED if staged else 0))
 
 
 @_on_device
-def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False, ring=False):
+def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False, ring=False, staged=False):
 	"""Fused S_hat = X.E + top-k.  Xp [Q x Kp] bf16 packed, Etp [Ip x Kp] bf16 packed (see pack_bf16).
 	workspace: from fused_workspace(); default = one grow-only buffer per device (one call in flight at a time).
 	leading_sample / item_ids: the index builder's hints of anncur_score_topk_ex (rows of Etp ordered by descending norm, and the
@@ -493,7 +500,7 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 		val = torch.empty((Q, k), dtype=torch.float32, device=Xp.device)
 		idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 		for q0 in range(0, Q, qc):   # (a chunk of 512 queries is accepted whatever its workspace size)
-			part = score_topk_fused(Xp[q0:q0 + qc], Etp, I, k, leading_sample=leading_sample, item_ids=item_ids, mfma16=mfma16, qt1=qt1, mfma32=mfma32, ring=ring)
+			part = score_topk_fused(Xp[q0:q0 + qc], Etp, I, k, leading_sample=leading_sample, item_ids=item_ids, mfma16=mfma16, qt1=qt1, mfma32=mfma32, ring=ring, staged=staged)
 			val[q0:q0 + qc], idx[q0:q0 + qc] = part.values, part.indices
 		return TopK(val, idx)
 	if workspace is None:
@@ -506,7 +513,12 @@ def score_topk_fused(Xp, Etp, I, k, return_fallbacks=False, workspace=None, lead
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 	ids = _item_ids_arg(item_ids, I, Xp.device)
 	check(lib.anncur_score_topk_ex(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
-								   _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), _p(ids) if ids is not None else None, _stream()), "score_topk")
+								   _topk_flags(leading_sample, mfma16, qt1, mfma32, ring, staged), _p(ids) if ids is not None else None, _stream()), "score_topk")
+	if ring and not torch.cuda.is_current_stream_capturing():
+		# ANNCUR_TOPK_RING (opt-in): a wave whose bounded spin on the tile ring's flags ran out stopped waiting and added 2^30 to the call's
+		# fallback counter (csrc/score16r.hpp); its candidates are then not to be trusted.  Fatal here (one host sync, the variant is opt-in).
+		if int(ws[:4].view(torch.int32).item()) >= 1 << 30:
+			raise _lib.AnncurHipError("score_topk (ring body): a wave gave up waiting on the tile ring; the result of this call is invalid")
 	if return_fallbacks:
 		return TopK(val, idx), ws[:4].view(torch.int32)
 	return TopK(val, idx)
@@ -535,6 +547,13 @@ def cu_partition_streams(device, n_scan):
 	runtime lacks the call."""
 	device = torch.device(device)
 	idx = device.index if device.index is not None else torch.cuda.current_device()
+	# hipExtStreamCreateWithCUMask makes BLOCKING streams: work on the NULL stream synchronises with them implicitly, and graph replays on a
+	# masked stream right after NULL-stream work ended in a GPU memory access fault when RCCL was in the process (round 4, DESIGN 7; never
+	# reproduced without RCCL: scripts/r5/cumask_null_stream_repro.hip).  A caller whose current stream is the NULL stream is one torch op away
+	# from that: refused here.  Run under `with torch.cuda.stream(torch.cuda.Stream()):` (bench.py does).
+	if torch.cuda.current_stream(idx).cuda_stream == 0:
+		raise _lib.AnncurHipError("cu_partition_streams: the current stream is the NULL stream, which synchronises implicitly with CU-masked (blocking) streams; "
+								  "make a non-default stream current first (with torch.cuda.stream(torch.cuda.Stream()): ...)")
 	n_cu = torch.cuda.get_device_properties(idx).multi_processor_count
 	n_scan = (int(n_scan) // 32) * 32
 	if not (0 < n_scan < n_cu):
@@ -558,7 +577,7 @@ def cu_partition_streams(device, n_scan):
 
 
 @_on_device
-def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False, mfma32=False, ring=False):
+def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, item_ids=None, mfma16=False, qt1=False, aux=None, serial=False, mfma32=False, ring=False, staged=False):
 	"""The per-query evaluation loop's two top-k's in one call (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:97-106):
 	(exact = rowwise_topk(A, k), approx = score_topk_fused(Xp, Etp, I, k_retvr)), the exact scan's row chunks co-scheduled with the
 	retrieval's latency-bound launches on a second stream (anncur_eval_topk).  serial=True: the same two results, one after the other."""
@@ -590,12 +609,12 @@ def eval_topk(A, k, Xp, Etp, I, k_retvr, workspace=None, leading_sample=False, i
 		aux = aux or aux_stream(A.device)
 		aux_p = ctypes.c_void_p(aux.cuda_stream)
 	check(lib.anncur_eval_topk(_p(A), _dt(A), _ld(A), k, _p(ev), _p(ei), _p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k_retvr, _p(av), _p(ai), _p(ws), nbytes,
-							   _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), _p(ids) if ids is not None else None, _stream(), aux_p), "eval_topk")
+							   _topk_flags(leading_sample, mfma16, qt1, mfma32, ring, staged), _p(ids) if ids is not None else None, _stream(), aux_p), "eval_topk")
 	return TopK(ev, ei), TopK(av, ai)
 
 
 @_on_device
-def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False, ring=False):
+def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, mfma16=False, qt1=False, mfma32=False, ring=False, staged=False):
 	"""Measurement only: (TopK, [prepass, threshold, sweep stage, select, sweep kernels only, n sweep launches, sweep launch 1, 2, 3]) in
 	ms, from HIP events on the launch stream."""
 	_dev(Xp, Etp)
@@ -610,32 +629,33 @@ def score_topk_fused_timed(Xp, Etp, I, k, leading_sample=False, item_ids=None, m
 	ms = (ctypes.c_float * 9)()
 	ids = _item_ids_arg(item_ids, I, Xp.device)
 	check(lib.anncur_score_topk_timed(_p(Xp), _ld(Xp), _p(Etp), Kp, Q, I, Kp, k, _p(val), _p(idx), _p(ws), nbytes,
-									  _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), _p(ids) if ids is not None else None, _stream(), ms),
+									  _topk_flags(leading_sample, mfma16, qt1, mfma32, ring, staged), _p(ids) if ids is not None else None, _stream(), ms),
 		  "score_topk_timed")
 	return TopK(val, idx), [float(x) for x in ms]
 
 
 @_on_device
-def fused_survivors(workspace, Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False):
+def fused_survivors(workspace, Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False, staged=False):
 	"""Mean number of candidates per query the sweep of the last score_topk_fused call on `workspace` kept (diagnostics; synchronises)."""
 	out = ctypes.c_double()
-	check(_lib.load().anncur_score_topk_survivors(_p(workspace), Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), ctypes.byref(out), _stream()),
+	check(_lib.load().anncur_score_topk_survivors(_p(workspace), Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32, ring, staged), ctypes.byref(out), _stream()),
 		  "score_topk_survivors")
 	return out.value
 
 
-def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False):
+def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False, staged=False):
 	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 body (per-lane
 	rings; the default above k = 384, and for Kp = 512), 1 = the 16x16x32 body (one queue per wave; the default for Kp <= 256, k <= 384),
 	4 = the wide kernel (Kp > 512); "QT": 32-query sub-tiles per wave (1 = qt1 honoured, or Kp = 512);
 	"stage_pred": body of each sweep stage -- 0 / 1 = 32x32x16 with the ballot / exec-mask filter, 2 = 16x16x32 (4-wave workgroups, barrier per
 	tile), 3 / 4 = Kp = 512 with the wave queue on 32x32x16 / 16x16x32, 5 = 16x16x32 in 8-wave workgroups with the tile ring (ring=True)."""
-	out = (ctypes.c_int32 * 17)()
-	check(_lib.load().anncur_score_topk_plan_ex(Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32, ring), out, 17), "score_topk_plan_ex")
+	out = (ctypes.c_int32 * 19)()
+	check(_lib.load().anncur_score_topk_plan_ex(Q, I, Kp, k, _topk_flags(leading_sample, mfma16, qt1, mfma32, ring, staged), out, 19), "score_topk_plan_ex")
 	v = [int(x) for x in out]
 	plan = dict(zip(("n_sample_tiles", "n_tiles", "splits", "segment_capacity", "group", "lg", "QT", "n_stages"), v[:8]))
 	n = plan["n_stages"]
 	plan["stage_end"], plan["stage_pred"], plan["stage_flush"] = v[8:8 + n], v[11:11 + n], v[14:14 + n]
+	plan["ladder"], plan["ladder_top_rank"] = bool(v[17]), v[18]   # the sweep raises its thresholds in-launch (csrc/score16.hpp; staged=True switches it off)
 	return plan
 
 

@@ -34,6 +34,149 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
 
+
+# ------------------------------------------------------------------ supervisor: the measurement runs in a CHILD of the process the launcher started
+# The default placement of the exact scan (a CU-masked stream beside the retrieval, --scan-mode partition) once ended in a GPU memory access
+# fault when RCCL was in the process (round 4: profiles/r04_rccl_single_rank_fault.txt).  A process that has touched the GPU can neither
+# recover from such a fault nor re-exec itself on this pool -- so the process the launcher starts (plain `python bench.py`, or a torchrun rank)
+# never touches the GPU: it starts the measuring process as a child ("worker", same arguments, same environment), relays its exit code, and if
+# a partition-mode attempt dies of a GPU fault (SIGABRT / SIGSEGV / SIGBUS, or a fault message on stderr) it starts ONE more attempt as FRESH
+# children with --scan-mode side; the line then says so (scan_mode.fallback_reason).  With N > 1 the supervisors of the ranks agree through
+# a key-value store (the launcher's rendezvous store when torchrun provides one): a rank whose worker died flags the attempt, the others end
+# their workers (which would otherwise wait in a collective for ever) and all of them start the fallback attempt together on a fresh port.
+# --direct (or ANNCUR_BENCH_WORKER=1) runs the measurement in this process: what the profiling scripts put behind `rocprofv3 --`.
+_FAULT_MARKS = ("Memory access fault", "HSA_STATUS_ERROR", "hipErrorIllegalAddress", "hipErrorLaunchFailure", "HW Exception", "GPU core dump")
+_FAULT_RCS = (134, 139, 135, -6, -11, -7)
+
+
+def _scan_mode_arg(argv):
+	for i, a in enumerate(argv):
+		if a == "--scan-mode" and i + 1 < len(argv): return argv[i + 1]
+		if a.startswith("--scan-mode="): return a.split("=", 1)[1]
+	return "serial" if "--no-overlap" in argv else None
+
+
+def _supervise(argv):
+	import signal
+	import socket
+	import subprocess
+	import threading
+	rank_env = os.environ.get("RANK")
+	world = int(os.environ.get("WORLD_SIZE", "1")) if rank_env is not None else 1
+	rank = int(rank_env) if rank_env is not None else 0
+	store = None
+	if world > 1:
+		from datetime import timedelta
+		from torch.distributed import TCPStore   # (imports torch; nothing here initialises a GPU)
+		host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+		agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+		store = TCPStore(host, port, world, is_master=(rank == 0 and not agent), timeout=timedelta(seconds=600), wait_for_workers=False)
+	tag = f"anncur_bench/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}"
+	child = [None]
+
+	def _on_signal(signum, _frame):   # the launcher ends its ranks with SIGTERM: take the worker along
+		if child[0] is not None and child[0].poll() is None:
+			child[0].kill()
+		raise SystemExit(128 + signum)
+	for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+		signal.signal(sg, _on_signal)
+
+	def attempt(a, extra, reason):
+		env = dict(os.environ, ANNCUR_BENCH_WORKER="1")
+		env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+		if reason:
+			env["ANNCUR_BENCH_FALLBACK_REASON"] = reason
+		if store is not None:
+			# the workers rendezvous on a port of their own (rank 0's worker hosts that store): a second attempt must not meet the keys of the first
+			key = f"{tag}/a{a}/port"
+			if rank == 0:
+				with socket.socket() as sk:
+					sk.bind(("127.0.0.1", 0)); wport = sk.getsockname()[1]
+				store.set(key, str(wport))
+			env["MASTER_PORT"] = store.get(key).decode()
+			env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+		proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+		child[0] = proc
+		tails = {"out": [], "err": bytearray()}
+
+		def pump_err():
+			for chunk in iter(lambda: proc.stderr.read1(65536), b""):
+				sys.stderr.buffer.write(chunk); sys.stderr.buffer.flush()
+				tails["err"] += chunk
+				del tails["err"][:-16384]
+		def pump_out():
+			for line in proc.stdout:
+				tails["out"].append(line.decode(errors="replace"))
+		threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+		for t in threads: t.start()
+		fkey, okkey = f"{tag}/a{a}/failed", f"{tag}/a{a}/ok"
+		reported, peer_failed = False, None
+		while True:
+			rc = proc.poll()
+			if rc is not None and not reported:
+				reported = True
+				if store is None:
+					break
+				if rc == 0: store.add(okkey, 1)
+				else: store.set(fkey, f"rank {rank}: worker exit code {rc}"); break
+			if store is not None:
+				if store.check([fkey]):
+					peer_failed = store.get(fkey).decode()
+					if proc.poll() is None: proc.kill()
+					break
+				if reported and store.add(okkey, 0) >= world:
+					break
+			time.sleep(0.2)
+		rc = proc.wait()
+		for t in threads: t.join(timeout=5)
+		lines = [l for l in tails["out"] if l.startswith("{") and '"metric"' in l]
+		err = tails["err"].decode(errors="replace")
+		own_fault = rc != 0 and (rc in _FAULT_RCS or any(m in err for m in _FAULT_MARKS))
+		return rc, lines, own_fault, peer_failed, err
+
+	mode0 = _scan_mode_arg(argv)
+	rc, lines, own_fault, peer_failed, err = attempt(0, [], None)
+	failed = (rc != 0 and not lines) or peer_failed is not None
+	if failed and mode0 in (None, "partition"):
+		# was it a GPU fault somewhere in the job?  every rank has to reach the same verdict: one more store round
+		fault = own_fault
+		if store is not None:
+			store.set(f"{tag}/verdict/{rank}", "fault" if own_fault else ("peer" if rc == 0 or peer_failed is not None and not own_fault else "error"))
+			verdicts = [store.get(f"{tag}/verdict/{r}").decode() for r in range(world)]
+			fault = "fault" in verdicts
+		if fault:
+			mark = next((m for m in _FAULT_MARKS if m in err), None)
+			reason = (f"the --scan-mode partition attempt died (rank {rank}: exit code {rc}" + (f", '{mark}' on stderr" if mark else "") + "); "
+					  "fresh worker processes re-ran the measurement with --scan-mode side") if own_fault else \
+					 f"the --scan-mode partition attempt died on another rank ({peer_failed}); fresh worker processes re-ran the measurement with --scan-mode side"
+			print(f"[bench] {reason}", file=sys.stderr, flush=True)
+			extra = ["--scan-mode", "side"]
+			rc, lines, own_fault, peer_failed, err = attempt(1, extra, reason)
+			failed = (rc != 0 and not lines) or peer_failed is not None
+	if lines and rank == 0:
+		sys.stdout.write(lines[-1] if lines[-1].endswith("\n") else lines[-1] + "\n"); sys.stdout.flush()
+	if failed:
+		return rc if rc not in (0, None) else 1
+	return 0
+
+
+def _gpus_arg(argv):
+	for i, a in enumerate(argv):
+		if a == "--gpus" and i + 1 < len(argv) and argv[i + 1].isdigit(): return int(argv[i + 1])
+		if a.startswith("--gpus=") and a[7:].isdigit(): return int(a[7:])
+	return None
+
+
+def _wants_supervisor(argv):
+	if os.environ.get("ANNCUR_BENCH_WORKER") or "--direct" in argv or "-h" in argv or "--help" in argv:
+		return False
+	# `--gpus N` (N > 1) outside a launcher: this process only starts torch.distributed.run (self_launch); its RANKS become the supervisors
+	return not (os.environ.get("RANK") is None and (_gpus_arg(argv) or 1) > 1)
+
+
+if __name__ == "__main__" and _wants_supervisor(sys.argv[1:]):
+	raise SystemExit(_supervise(sys.argv[1:]))
+
 import numpy as np
 import torch
 
@@ -429,6 +572,12 @@ def run_config(args, cfg_name, ctx, light=False):
 		torch.cuda.synchronize()
 
 	_mark(f"launcher built ({scan_mode})")
+	if scan_mode == "partition" and os.environ.get("ANNCUR_BENCH_FAIL_PARTITION_RANK") == str(rank):
+		# fault injection (tests/test_gpu_bench_multirank.py): die the way a GPU memory fault ends a process -- SIGABRT, no Python teardown --
+		# once the partition's streams and graphs exist; the supervisor must answer with fresh workers and --scan-mode side
+		torch.cuda.synchronize()
+		print("[bench] injected abort in partition mode (ANNCUR_BENCH_FAIL_PARTITION_RANK)", file=sys.stderr, flush=True)
+		os.abort()
 	launch, graphed = launchers[scan_mode]
 	scan_mode_used = scan_mode
 	res = run_steps(args.warmup)
@@ -651,7 +800,9 @@ def run_config(args, cfg_name, ctx, light=False):
 			"value_with_index_build": world * Q / (ms_per_step * 1e-3 + index_build_s),
 			"fused_plan": plan_now,
 			"launch_mode": "eager" if not graphed else "hipGraph replay (the step's launches captured once per result slot)",
-			"scan_mode": {"used": scan_mode_used, "scan_cus": scan_cus if scan_mode_used == "partition" else None,
+			"scan_mode": {"used": scan_mode_used, "requested": "partition" if os.environ.get("ANNCUR_BENCH_FALLBACK_REASON") else (args.scan_mode or "partition"),
+						  "fallback_reason": os.environ.get("ANNCUR_BENCH_FALLBACK_REASON"),   # set by the supervisor when a partition attempt died of a GPU fault and fresh workers re-ran with "side"
+						  "scan_cus": scan_cus if scan_mode_used == "partition" else None,
 						  "retrieval_streams": args.retr_streams if scan_mode_used == "partition" else 1, "gather_folded_into_scan": bool(scan_mode_used == "partition" and args.fold_gather and ops.rowwise_topk_gather_ok(A_test, k) and Kp == len(anc))},
 			"sustained": sustained, "ranks_seen": ranks_seen, "allgather_ms": allgather_ms, "backend": (args.backend if use_dist else None),
 			"solo_rank0": ({"value": solo, "unit": "queries/s", "what": "the same K steps on rank 0 alone, other ranks idle: N x this is the ideal weak-scaling value"} if solo else None),
@@ -706,6 +857,25 @@ def run_config(args, cfg_name, ctx, light=False):
 	return out
 
 
+def _fake_worker(args):
+	"""Test scaffolding for the supervisor (tests/test_cpu_host.py, no GPU): ANNCUR_BENCH_FAKE_WORKER=fault_in_partition makes the worker of
+	rank ANNCUR_BENCH_FAKE_RANK die like a GPU fault does (message on stderr, SIGABRT) while the scan placement is the partition, the other
+	ranks wait as they would in a collective; any other attempt prints a result line that names its placement and the fallback reason."""
+	rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+	mode = args.scan_mode or "partition"
+	if os.environ["ANNCUR_BENCH_FAKE_WORKER"] == "fault_in_partition" and mode == "partition":
+		if rank == int(os.environ.get("ANNCUR_BENCH_FAKE_RANK", "0")):
+			print("Memory access fault by GPU node-1 (fake worker)", file=sys.stderr, flush=True)
+			os.abort()
+		time.sleep(600)   # (a rank waiting in a collective for the one that died: its supervisor ends it)
+	if os.environ["ANNCUR_BENCH_FAKE_WORKER"] == "plain_error":
+		raise SystemExit(3)
+	if rank == 0:
+		print(json.dumps({"metric": "fake", "value": 1.0, "n_gpus": world, "scan_mode": {"used": mode, "requested": "partition" if os.environ.get("ANNCUR_BENCH_FALLBACK_REASON") else mode,
+																				   "fallback_reason": os.environ.get("ANNCUR_BENCH_FALLBACK_REASON")}}), flush=True)
+	return 0
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=None, help="default: WORLD_SIZE under torchrun, else 1")
@@ -724,19 +894,22 @@ def main():
 	ap.add_argument("--scan-cus", type=int, default=None, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD); default 96 for Kp <= 256, 64 above")
 	ap.add_argument("--scan-mode", default=None, choices=["side", "partition", "tail", "chunks", "serial"],
 					help="how the exact scan is scheduled against the retrieval: partition = on a stream whose CU mask leaves it --scan-cus CUs, beside the "
-						 "retrieval on all of them (default where the retrieval's sweep draws its tiles dynamically: Kp <= 256); side = on a second stream "
-						 "from the start of the step, joined before the overlap count (default otherwise); chunks = anncur_eval_topk (row chunks forked "
+						 "retrieval on all of them (the default at every Kp: 96 scan CUs for Kp <= 256, 64 above); side = on a second stream "
+						 "from the start of the step, joined before the overlap count (the fallback when CU-masked streams are unavailable or a partition run died); chunks = anncur_eval_topk (row chunks forked "
 						 "beside the retrieval's latency-bound launches); serial = one stream")
 	ap.add_argument("--retr-streams", type=int, default=2, choices=[1, 2], help="--scan-mode partition: retrieval chains of consecutive steps on one stream or on two (a workspace each)")
 	ap.add_argument("--fold-gather", action="store_true", help="--scan-mode partition: C_q out of the scan's own pass over A (anncur_rowwise_topk_gather) instead of "
 					"the gather kernel -- built for SURVEY a2's 'fold into the first pass', measured slower (see the comment at its use): off by default")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
+	ap.add_argument("--direct", action="store_true", help="measure in THIS process (no supervisor / worker split, no fallback attempt): what profiling scripts put behind `rocprofv3 --`")
 	args = ap.parse_args()
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if args.gpus is None:
 		args.gpus = world if os.environ.get("RANK") is not None else 1
 	if args.gpus > 1 and os.environ.get("RANK") is None:
 		self_launch(args)
+	if os.environ.get("ANNCUR_BENCH_FAKE_WORKER"):
+		return _fake_worker(args)
 	if args.gpus != world:   # before any process group exists: nothing to tear down, no rank left waiting in a collective
 		raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 	# stdout carries exactly ONE line (the result JSON): libraries that print banners to fd 1 (RCCL at communicator creation
@@ -805,4 +978,4 @@ def _run_all(args, ctx, world, rank):
 
 
 if __name__ == "__main__":
-	main()
+	raise SystemExit(main())

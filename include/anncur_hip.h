@@ -202,8 +202,15 @@ int anncur_score_topk(const void *X, int64_t ldx, const void *Et, int64_t lde,
 /*  ANNCUR_TOPK_RING (Kp = 128 / 256, k <= 128): the 16x16x32 body in 8-wave workgroups of 512 queries whose item tiles stream through a
  *    ring of four LDS slots synchronised by per-wave landed / done counters in LDS instead of a workgroup barrier per tile (round 4,
  *    csrc/score16r.hpp: half the L2 -> LDS traffic, half the DMA pieces per wave).  Same result bit for bit; measured slower than the
- *    default (4-wave workgroups, two tile buffers, one barrier per tile) at every size tried -- an A/B variant, not the default. */
+ *    default (4-wave workgroups, two tile buffers, one barrier per tile) at every size tried -- an A/B variant, not the default.
+ *    Callers that set it MUST read workspace word 0 (uint32) after the call has completed: every spin of that body is bounded, and a
+ *    wave whose spin ran out adds 2^30 to that word and stops waiting -- the call still returns ANNCUR_OK, its result is invalid
+ *    (anncur_amd/ops.py::score_topk_fused(ring=True) raises on it). */
 #define ANNCUR_TOPK_RING 16
+/*  ANNCUR_TOPK_STAGED: the default 16x16x32 body (Kp <= 256, k <= 384) WITHOUT its threshold ladder -- the sweep in stages with a refinement
+ *    launch between them, as rounds 1-4 ran it (A/B and parity reference; the default since round 5 is ONE sweep launch whose waves move
+ *    their thresholds up a ladder of levels from device-wide counts of the candidates kept so far: csrc/score16.hpp).  Same result. */
+#define ANNCUR_TOPK_STAGED 32
 int anncur_score_topk_ex(const void *X, int64_t ldx, const void *Et, int64_t lde,
                          int64_t Q, int64_t I, int32_t Kp, int32_t k,
                          float *out_val, int32_t *out_idx,

@@ -1,5 +1,6 @@
 """CPU-only checks: the C-ABI library exports exactly what include/anncur_hip.h declares, host logic against the oracle,
 row-sharding over gloo (world_size 2), error behaviour without a GPU."""
+import json
 import os
 import re
 import subprocess
@@ -55,8 +56,14 @@ def test_sweep_variant_flags_reach_the_plan():
 	from anncur_amd import _lib, ops
 	assert ops._topk_flags() == 0 and ops._topk_flags(True, True, True, True) == (_lib.TOPK_LEADING_SAMPLE | _lib.TOPK_MFMA16 | _lib.TOPK_QT1 | _lib.TOPK_MFMA32)
 	base = ops.fused_plan(10000, 100000, 256, 100)
-	assert (base["lg"], base["QT"]) == (1, 2) and base["n_stages"] == len(base["stage_end"]) == 2 and base["stage_end"][-1] == base["n_tiles"]
-	assert all(b == 2 for b in base["stage_pred"])                              # k <= 128: the 16x16x32 body in every stage
+	# round 5: the default 16x16x32 body sweeps in ONE launch and raises its thresholds up a ladder of levels in flight (csrc/score16.hpp)
+	assert (base["lg"], base["QT"]) == (1, 2) and base["n_stages"] == len(base["stage_end"]) == 1 and base["stage_end"][-1] == base["n_tiles"]
+	assert base["ladder"] and base["ladder_top_rank"] == 10 and ops.fused_plan(10000, 100000, 256, 100, leading_sample=True)["ladder_top_rank"] == 16
+	assert all(b == 2 for b in base["stage_pred"])                              # k <= 384: the 16x16x32 body
+	staged = ops.fused_plan(10000, 100000, 256, 100, staged=True)               # ANNCUR_TOPK_STAGED: rounds 1-4's staged sweep of the same body (A/B, parity reference)
+	assert not staged["ladder"] and staged["n_stages"] == len(staged["stage_end"]) == 2 and all(b == 2 for b in staged["stage_pred"]) and staged["lg"] == 1
+	assert ops._topk_flags(staged=True) == _lib.TOPK_STAGED and not ops.fused_plan(10000, 100000, 256, 100, mfma32=True)["ladder"]
+	assert not ops.fused_plan(6250, 1000000, 512, 100)["ladder"] and not ops.fused_plan(10000, 100000, 256, 100, ring=True)["ladder"]
 	m32 = ops.fused_plan(10000, 100000, 256, 100, mfma32=True)
 	assert m32["lg"] == 2 and all(b in (0, 1) for b in m32["stage_pred"])
 	assert ops.fused_plan(10000, 100000, 256, 500)["lg"] == 2                   # k > 128: 32x32x16 throughout
@@ -78,7 +85,7 @@ def test_sweep_variant_flags_reach_the_plan():
 	assert ops._topk_flags(ring=True) == _lib.TOPK_RING
 	import inspect
 	src = inspect.getsource(ops.score_topk_fused.__wrapped__) + inspect.getsource(ops.score_topk_fused_timed.__wrapped__)
-	assert src.count("_topk_flags(leading_sample, mfma16, qt1, mfma32, ring)") == 2 and "mfma16=mfma16, qt1=qt1, mfma32=mfma32, ring=ring" in src
+	assert src.count("_topk_flags(leading_sample, mfma16, qt1, mfma32, ring, staged)") == 2 and "mfma16=mfma16, qt1=qt1, mfma32=mfma32, ring=ring, staged=staged" in src
 
 
 def test_product_never_imports_the_oracle():
@@ -375,3 +382,46 @@ def test_static_hazard_checks_find_planted_hazards():
 	early = _listing(["ds_read_b128 v[20:23], v9", "ds_read_b128 v[24:27], v10", "s_waitcnt lgkmcnt(1)",
 					  "v_mfma_f32_32x32x16_bf16 v[32:47], v[24:27], v[52:55], v[32:47]", "s_endpgm"])   # consumes the YOUNGER read: still in flight
 	assert len(check_lds_hazards.check_body("kernel", early)) == 1
+
+
+# ------------------------------------------------------------------ bench.py's supervisor: the N > 1 line must survive a GPU fault of the partition placement
+def _bench_with_fake_workers(fake, extra_args, extra_env=None, timeout=240):
+	env = dict(os.environ, ANNCUR_BENCH_FAKE_WORKER=fake)
+	for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ANNCUR_BENCH_WORKER", "ANNCUR_BENCH_FALLBACK_REASON"):
+		env.pop(v, None)
+	env.update(extra_env or {})
+	return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_supervisor_falls_back_to_side_after_a_gpu_fault_single_rank():
+	"""The process the driver starts never touches the GPU: it runs the measurement in a child.  A partition-mode child that dies like a GPU
+	fault (message on stderr + SIGABRT; faked here, no GPU) is answered with ONE fresh child in --scan-mode side, and the line says so."""
+	p = _bench_with_fake_workers("fault_in_partition", ["--steps", "2"])
+	assert p.returncode == 0, p.stderr[-2000:]
+	lines = [l for l in p.stdout.splitlines() if l.strip()]
+	assert len(lines) == 1, p.stdout
+	out = json.loads(lines[0])
+	assert out["scan_mode"]["used"] == "side" and out["scan_mode"]["requested"] == "partition"
+	assert "partition attempt died" in out["scan_mode"]["fallback_reason"] and "Memory access fault" in out["scan_mode"]["fallback_reason"]
+
+
+def test_bench_supervisor_relays_a_clean_run_and_a_plain_error_unchanged():
+	p = _bench_with_fake_workers("ok", ["--steps", "2"])
+	assert p.returncode == 0 and json.loads(p.stdout.strip())["scan_mode"] == {"used": "partition", "requested": "partition", "fallback_reason": None}
+	p = _bench_with_fake_workers("plain_error", ["--steps", "2"])       # not a GPU fault: no second attempt, the exit code comes through
+	assert p.returncode == 3 and not p.stdout.strip() and "partition attempt died" not in p.stderr
+	p = _bench_with_fake_workers("fault_in_partition", ["--steps", "2", "--scan-mode", "side"])   # an explicit placement is never overridden (and the fake only faults in partition mode)
+	assert p.returncode == 0 and json.loads(p.stdout.strip())["scan_mode"]["fallback_reason"] is None
+
+
+@pytest.mark.parametrize("bad_rank", [0, 1])
+def test_bench_supervisor_falls_back_on_every_rank_when_one_rank_faults(bad_rank):
+	"""--gpus 2 through the self-launch (torch.distributed.run -> two supervisors -> two workers): the worker of ONE rank dies of a (faked) GPU
+	fault while the other waits in a collective; its supervisor flags the attempt in the launcher's store, the other supervisor ends its own
+	worker, both start fresh workers with --scan-mode side on a fresh rendezvous port, and rank 0 prints ONE line that carries the reason."""
+	p = _bench_with_fake_workers("fault_in_partition", ["--gpus", "2", "--steps", "2"], {"ANNCUR_BENCH_FAKE_RANK": str(bad_rank)}, timeout=400)
+	assert p.returncode == 0, p.stderr[-3000:]
+	lines = [l for l in p.stdout.splitlines() if l.strip()]
+	assert len(lines) == 1, p.stdout
+	out = json.loads(lines[0])
+	assert out["n_gpus"] == 2 and out["scan_mode"]["used"] == "side" and f"rank {bad_rank}" in out["scan_mode"]["fallback_reason"]

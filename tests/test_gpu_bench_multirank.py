@@ -126,3 +126,43 @@ def test_bench_single_gpu_default_line_and_scan_placements():
 	assert d["roofline"]["bound"] == "mfma" and 0.2 < d["roofline"]["frac"] < 1.0 and d["roofline_scan"]["bound"] == "hbm"
 	assert all(b == 2 for b in d["fused_plan"]["stage_pred"])          # the 16x16x32 body
 	assert d["recall"] == outs["side"]["recall"] and d["recall"]["recall@1"] == 1.0
+
+
+def test_bench_partition_abort_falls_back_to_side_with_fresh_workers():
+	"""the N > 1 line must not be lost to a GPU fault of the CU-partition placement.  Rank 1's WORKER aborts (SIGABRT, the way a
+	GPU memory fault ends a process) once its partition streams and graphs exist; the supervisors -- the processes the launcher started, which
+	never touch the GPU -- end the surviving worker and start ONE fresh attempt with --scan-mode side; rank 0 prints one line that says so."""
+	p = _run({"ANNCUR_BENCH_FAIL_PARTITION_RANK": "1"}, timeout=900)
+	assert p.returncode == 0, p.stderr[-3000:]
+	lines = [l for l in p.stdout.splitlines() if l.strip()]
+	assert len(lines) == 1, p.stdout[-2000:]
+	out = json.loads(lines[0])
+	assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3
+	assert out["scan_mode"]["used"] == "side" and out["scan_mode"]["requested"] == "partition"
+	assert "partition attempt died" in out["scan_mode"]["fallback_reason"] and "rank 1" in out["scan_mode"]["fallback_reason"]
+	assert out["value"] > 0 and 0.0 <= out["recall"]["recall@10"] <= 1.0
+	assert "injected abort in partition mode" in p.stderr
+
+
+def test_bench_partition_abort_single_rank_and_no_fallback_for_an_explicit_mode():
+	short = ["--config", "small", "--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--cpu-sample-queries", "0", "--no-k500", "--no-ivf"]
+	p = _run({"ANNCUR_BENCH_FAIL_PARTITION_RANK": "0"}, args=short)
+	assert p.returncode == 0, p.stderr[-3000:]
+	out = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+	assert out["scan_mode"]["used"] == "side" and "partition attempt died" in out["scan_mode"]["fallback_reason"]
+	p = _run({"ANNCUR_BENCH_FAIL_PARTITION_RANK": "0"}, args=short + ["--scan-mode", "partition"])   # an explicit placement is not overridden... but a GPU fault of it still is answered
+	assert p.returncode == 0 and json.loads([l for l in p.stdout.splitlines() if l.strip()][0])["scan_mode"]["used"] == "side"
+	p = _run({"ANNCUR_BENCH_FAIL_PARTITION_RANK": "0"}, args=short + ["--direct"])                   # --direct: no supervisor, the abort comes through
+	assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_cu_partition_streams_refuses_the_null_stream():
+	if not torch.cuda.is_available():
+		pytest.skip("no GPU")
+	from anncur_amd import _lib, ops
+	dev = torch.device("cuda:0")
+	with pytest.raises(_lib.AnncurHipError, match="NULL stream"):
+		ops.cu_partition_streams(dev, 96)
+	with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+		retr, scan = ops.cu_partition_streams(dev, 96)
+	assert scan.cuda_stream != 0

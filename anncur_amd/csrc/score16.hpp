@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 				tau_prev[0] = fmaxf(tau_prev[0], tau[2]); tau_prev[1] = fmaxf(tau_prev[1], tau[3]);                             \
 				lad_pending = false;                                                                                            \
 			}                                                                                                                   \
-			if ((++lad_tick & (LADDER_PERIOD - 1)) == 0u) {                                                                     \
+			if ((++lad_tick & p.ladder_mask) == 0u) {                                                                           \
 				ladder_fetch(w.lcnt, lcnt_land, (int)ll_);                                                                      \
 				lad_pending = true;                                                                                             \
 			}                                                                                                                   \
@@ -486,8 +486,14 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 #undef F16_ELEM
 	wq_drain<true>(w, fill);
 	if (p.ladder_on) {   // the thresholds this wave ended with: the select's prefilter is the highest any workgroup reached (all of them are valid)
+		// one last look at the counters, now that this wave's own adds have completed (vmcnt): the workgroup that finishes last sees every count
+		// of the launch, and the select takes the maximum over the workgroups
 		// (query ids recomputed from an opaque lane id: kept from the prologue they were eight VGPRs live across the tile loop -- spills at Kp = 256)
 		const int le = (int)opaque_u32((uint32_t)lane);
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+		ladder_fetch(w.lcnt, lcnt_land, le);
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+		ladder_refresh(lcnt_land + (uint32_t)le * 16u, w.lvl + (uint32_t)le * 32u, w.jcur + (uint32_t)le * 4u, p.ladder_k, le & 15, tau);
 		if ((le >> 4) == 0) {
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {

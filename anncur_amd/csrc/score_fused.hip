@@ -111,7 +111,7 @@ struct FusedParams {
 	int sliced, chunks_per_slice;     // XCD-sliced tickets: chunk_ctr is [row block][N_SLICES], slice s = chunks [s * chunks_per_slice, + chunks_per_slice)
 	// threshold ladder of score16_kernel (score16.hpp): levels [n_rb x BQ][LADDER_LEVELS], counter words [n_rb x BQ][4] (zero at launch),
 	// the cell each wave raises to the threshold it ended with (initialised to tau0 by the threshold kernel), k
-	int ladder_on; uint32_t ladder_k;
+	int ladder_on; uint32_t ladder_k, ladder_mask;   // ladder_mask = period - 1 (a power of two): tiles between two fetches of a wave's counter words
 	const float *ladder; uint32_t *ladder_cnt; float *tau_final;
 	uint32_t *nfb;                    // the call's fallback counter (workspace word 0): the ring kernel reports a spin timeout there
 	int ring_stagger, ring_spin_sleep; // ring kernel: start delay of waves 4..7 in units of 64 cycles; s_sleep between two polls of a waiting wave
@@ -2054,7 +2054,10 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (const char *dbg = getenv("ANNCUR_DEBUG_RING_SLEEP")) p.ring_spin_sleep = atoi(dbg);
 #endif
 	p.nseg = P.lg * P.S;
-	p.ladder_on = P.ladder ? 1 : 0; p.ladder_k = (uint32_t)k;
+	p.ladder_on = P.ladder ? 1 : 0; p.ladder_k = (uint32_t)k; p.ladder_mask = (uint32_t)(LADDER_PERIOD - 1);
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_LADDER_PERIOD")) { int v = atoi(dbg); if (v >= 1 && (v & (v - 1)) == 0) p.ladder_mask = (uint32_t)(v - 1); }
+#endif
 	p.ladder = (const float *)(ws + P.off_lvl); p.ladder_cnt = (uint32_t *)(ws + P.off_lcnt); p.tau_final = (float *)(ws + P.off_tau2);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_STAMPS")) {

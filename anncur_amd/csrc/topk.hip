@@ -464,25 +464,28 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 // Round 2: the key array is dynamic LDS sized to n (it was a static 4 x 2048 array: 36 KB per workgroup whatever n) and n may be
 // 4096: the threshold of k = 1000 (4000 group maxima per query) no longer goes through the workgroup-level top-k (0.74 -> 0.21 ms).
 constexpr int KTH_MAX_N = 4096;
-// The coarse (16-bit key prefix) k-th AND k2-th largest keys (k2 <= k) from the SAME two histogram passes: the k2-th key's digits are read
-// off the histograms the k-th key's select fills anyway (a second wsel_kth cost the threshold kernel 15 us at cfg2: as much as the first).
-// When the k2-th key lies in a higher top-byte bin than the k-th (scores spanning a factor of four or more between the two ranks), G is the
-// smallest key of the next top-byte bin -- any value above T serves (the ladder's counts make a move valid, not its levels).
-__device__ __forceinline__ void kth2_coarse(const WaveSel &w, const uint32_t *key, uint32_t n, uint32_t k, uint32_t k2, uint32_t &T, uint32_t &G) {
+// The coarse (16-bit key prefix) k-th AND k2-th largest keys (k2 <= k) from the SAME two passes over the keys: the second pass fills one
+// histogram for the k-th key's top byte and, where the k2-th key has another top byte (the sortable key's top byte is the sign and seven
+// exponent bits: thresholds around 2.0 straddle two of them), a second histogram for that one (a second wsel_kth cost the threshold kernel
+// 15 us at cfg2: as much as the first).  hist2: 256 more words of the wave's LDS.
+__device__ __forceinline__ void kth2_coarse(const WaveSel &w, uint32_t *hist2, const uint32_t *key, uint32_t n, uint32_t k, uint32_t k2, uint32_t &T, uint32_t &G) {
 	const uint32_t lane = (uint32_t)lane_id();
 	uint32_t bin0 = 0, a0 = 0, hb = 0, binG0 = 0, aG0 = 0;
 #pragma unroll
 	for (int pass = 0; pass < 2; ++pass) {
-		const int shift = 24 - 8 * pass;
 #pragma unroll
-		for (int i = 0; i < 4; ++i) w.hist[lane * 4 + i] = 0;
+		for (int i = 0; i < 4; ++i) { w.hist[lane * 4 + i] = 0; hist2[lane * 4 + i] = 0; }
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll 4
 		for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
 			const uint32_t j = j0 + lane;
 			if (j < n) {
 				const uint32_t x = key[j];
-				if (pass == 0 || (x >> 24) == bin0) atomicAdd(&w.hist[(x >> shift) & 255u], 1u);
+				if (pass == 0) atomicAdd(&w.hist[x >> 24], 1u);
+				else {
+					if ((x >> 24) == bin0) atomicAdd(&w.hist[(x >> 16) & 255u], 1u);
+					else if ((x >> 24) == binG0) atomicAdd(&hist2[(x >> 16) & 255u], 1u);
+				}
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -493,14 +496,13 @@ __device__ __forceinline__ void kth2_coarse(const WaveSel &w, const uint32_t *ke
 			uint32_t bin1, a1, binG1 = 0;
 			wsel_find_bin(w.hist, lane, k - a0, bin1, a1, hb);
 			T = ((bin0 << 8) | bin1) << 16;
-			if (binG0 == bin0) {   // (uniform) k2 > a0: the k2-th key shares the top byte
-				wsel_find_bin(w.hist, lane, k2 - a0, binG1, a1, hb);
-				G = ((bin0 << 8) | binG1) << 16;
-			} else G = (bin0 + 1u) << 24;
+			wsel_find_bin(binG0 == bin0 ? w.hist : hist2, lane, k2 - aG0, binG1, a1, hb);   // (uniform choice; aG0 == a0 when the top bytes agree)
+			G = ((binG0 << 8) | binG1) << 16;
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
 }
+
 // Threshold LADDER (round 5, score16.hpp): with ladder != nullptr the wave also selects the k2-th largest value g (k2 < k) and writes
 // ladder[q][j - 1] = tau + (g - tau) j / LADDER_LEVELS, j = 1..LADDER_LEVELS: candidate thresholds ABOVE tau that the sweep may move up to once it has
 // counted k candidates at or above one of them.  Any values would be valid there (the count makes the move valid, not the level); value-linear
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(256) void kth_value_wave_kernel(const float *__rest
 	extern __shared__ __attribute__((aligned(16))) unsigned char kth_smem[];
 	const uint32_t lane = (uint32_t)lane_id();
 	const int wave = threadIdx.x >> 6;
-	uint32_t *hist = reinterpret_cast<uint32_t *>(kth_smem) + wave * (256 + n_pad);
+	uint32_t *hist = reinterpret_cast<uint32_t *>(kth_smem) + wave * (256 + n_pad + (ladder ? 256 : 0));
 	uint32_t *keys = hist + 256;
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
 	if (q >= Q) return;
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256) void kth_value_wave_kernel(const float *__rest
 	// is a value <= the exact one by less than one bf16 ulp (0.8 %), i.e. still a valid lower bound, for half the histogram passes
 	// (the fused top-k's threshold: 23.6 -> 13 us at 512 keys, 91 -> 48 us at 2000; ~2 % more survivors in the first sweep stage)
 	uint32_t kk, gk = 0;
-	if (ladder) kth2_coarse(w, w.whi, (uint32_t)n, k, k2 < k ? k2 : k, kk, gk);   // (the ladder's call is the coarse one)
+	if (ladder) kth2_coarse(w, hist + 256 + n_pad, w.whi, (uint32_t)n, k, k2 < k ? k2 : k, kk, gk);   // (the ladder's call is the coarse one; its second histogram sits behind the keys)
 	else if (coarse) kk = wsel_kth<false, 2>(w, w.whi, (uint32_t)n, k, need, w.whi, 0u);
 	else kk = wsel_kth<false, 4>(w, w.whi, (uint32_t)n, k, need, w.whi, 0u);
 	if (lane == 0) out[q * out_stride] = f32_unsortable(kk);
@@ -725,7 +727,7 @@ int anncur_internal_kth_value(const float *G, int64_t Q, int n, int64_t ldg, int
 	ANNCUR_REQUIRE(n >= 1 && n <= KTH_MAX_N && k >= 1 && k <= n, ANNCUR_E_INVALID, "kth_value: need 1 <= k <= n <= 4096");
 	const unsigned grid = (unsigned)ceil_div64(Q, 4);
 	const int n_pad = (n + 63) & ~63;
-	const int lds = 4 * (256 + n_pad) * 4;  // (<= 68 KB: above the 64 KB default only for n > 3840)
+	const int lds = 4 * (256 + n_pad + (ladder ? 256 : 0)) * 4;  // (<= 72 KB: above the 64 KB default only for n > 3584)
 	int rc;
 	if (lds > 64 * 1024 && (rc = anncur_ensure_dyn_lds((const void *)kth_value_wave_kernel, lds)) != ANNCUR_OK) return rc;
 	hipLaunchKernelGGL(kth_value_wave_kernel, dim3(grid), dim3(256), lds, st, G, Q, n, ldg, (uint32_t)k, out, out_stride, n_pad, coarse, ladder, (uint32_t)(k2 < 1 ? 1 : k2), tau2);

@@ -357,7 +357,7 @@ def run_config(args, cfg_name, ctx, light=False):
 		Xq = ops.gather_cols(A_test, anc_dev)                          # a2: C_q
 		if Xq.shape[1] != Kp:
 			Xq = ops.pack_bf16(Xq, Kp)
-		return ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, workspace=workspace)   # a6 + a7 fused (item rows in the index's norm order)
+		return ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged, workspace=workspace)   # a6 + a7 fused (item rows in the index's norm order)
 
 	def make_launcher(mode):
 		"""launch(slot) for one way of placing the exact scan (a8's HBM-bound half) beside the MFMA-bound retrieval:
@@ -404,7 +404,7 @@ def run_config(args, cfg_name, ctx, light=False):
 				Xq = ops.gather_cols(A_test, anc_dev)
 				if Xq.shape[1] != Kp:
 					Xq = ops.pack_bf16(Xq, Kp)
-				exact, approx = ops.eval_topk(A_test, k, Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, serial=mode == "serial")
+				exact, approx = ops.eval_topk(A_test, k, Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged, serial=mode == "serial")
 			return ops.overlap_counts(exact.indices, approx.indices, cells)   # a8 rerank (closed form) + a10
 
 		if mode == "partition":
@@ -439,7 +439,7 @@ def run_config(args, cfg_name, ctx, light=False):
 				if fold: state[slot]["exact"], state[slot]["Xq"] = ops.rowwise_topk_gather(A_test, k, tabs)
 				else: state[slot]["exact"] = ops.rowwise_topk(A_test, k)
 			def piece_retr(slot):
-				state[slot]["approx"] = (ops.score_topk_fused(state[slot]["Xq"], cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, workspace=wss[slot])
+				state[slot]["approx"] = (ops.score_topk_fused(state[slot]["Xq"], cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged, workspace=wss[slot])
 										 if fold else retrieve(wss[slot]))
 			def piece_tail(slot): ops.copy_to_mapped_host(ops.overlap_counts(state[slot]["exact"].indices, state[slot]["approx"].indices, cells), pinned[slot])
 			fns = (piece_scan, piece_retr, piece_tail)
@@ -580,6 +580,30 @@ def run_config(args, cfg_name, ctx, light=False):
 		os.abort()
 	launch, graphed = launchers[scan_mode]
 	scan_mode_used = scan_mode
+	# sustained: the same step looped for >= 10 s, BEFORE the W warm-up and K timed steps (round 5; it ran after them before).  Two reasons:
+	# under a long MFMA load the chip lowers its clock (MI355X_MICROARCH.md 'DVFS give-back') and a 5 s utilisation sampler sees the GPU busy; and
+	# the timed burst then starts on a chip that is out of its idle power state -- measured on one box, K = 20 steps after W = 5: 0.995 ms per step
+	# straight after the (host-heavy, GPU-idle) graph capture, 0.919 after 200 warm-up steps, 0.918 after 1000, 0.904 for K = 200: the first tens
+	# of milliseconds after idle run ~8 % slow, which is the box's clock ramp, not the step.  (--sustained-seconds 0: no such loop, the old order.)
+	sustained = None
+	if args.sustained_seconds > 0 and not light:
+		barrier()
+		t0 = time.perf_counter(); n_sus = 0
+		while True:
+			run_steps(20); n_sus += 20
+			torch.cuda.synchronize()
+			if time.perf_counter() - t0 >= args.sustained_seconds:
+				break
+		sus_s = time.perf_counter() - t0
+		if use_dist:
+			t = torch.tensor([sus_s / n_sus], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+			torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+			sus_step = t.item()
+		else:
+			sus_step = sus_s / n_sus
+		sustained = {"value": world * Q / sus_step, "unit": "queries/s", "ms_per_step": 1e3 * sus_step, "seconds": sus_s, "steps": n_sus,
+					 "order": "runs BEFORE the W warm-up and K timed steps: the timed burst starts at the chip's settled clock, not in its ramp out of idle"}
+	_mark("sustained section done")
 	res = run_steps(args.warmup)
 	barrier()
 	_mark("warm-up steps done")
@@ -625,27 +649,6 @@ def run_config(args, cfg_name, ctx, light=False):
 		_mark("solo: steps done")
 		barrier()
 	_mark("solo section done")
-	# sustained: the same step looped for >= 10 s (the timed region above is a burst of K steps; under a long MFMA load the chip
-	# lowers its clock -- MI355X_MICROARCH.md 'DVFS give-back'; long enough for a 5 s utilisation sampler to see the GPU busy)
-	sustained = None
-	if args.sustained_seconds > 0 and not light:
-		barrier()
-		t0 = time.perf_counter(); n_sus = 0
-		while True:
-			run_steps(20); n_sus += 20
-			torch.cuda.synchronize()
-			if time.perf_counter() - t0 >= args.sustained_seconds:
-				break
-		sus_s = time.perf_counter() - t0
-		if use_dist:
-			t = torch.tensor([sus_s / n_sus], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-			torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-			sus_step = t.item()
-		else:
-			sus_step = sus_s / n_sus
-		sustained = {"value": world * Q / sus_step, "unit": "queries/s", "ms_per_step": 1e3 * sus_step, "seconds": sus_s, "steps": n_sus}
-
-	_mark("sustained section done")
 	# ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
 	stage = np.zeros(9)
 	Xq = ops.gather_cols(A_test, anc_dev)
@@ -653,7 +656,7 @@ def run_config(args, cfg_name, ctx, light=False):
 		Xq = ops.pack_bf16(Xq, Kp)
 	n_prof = max(3, min(args.steps, 10))
 	for _ in range(n_prof):
-		_, ms = ops.score_topk_fused_timed(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
+		_, ms = ops.score_topk_fused_timed(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged)
 		stage += np.array(ms)
 	stage /= n_prof
 	ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -671,12 +674,12 @@ def run_config(args, cfg_name, ctx, light=False):
 		Xr = ops.gather_cols(A_test, anc_dev)
 		if Xr.shape[1] != Kp:
 			Xr = ops.pack_bf16(Xr, Kp)
-		ops.score_topk_fused(Xr, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids)
+		ops.score_topk_fused(Xr, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged)
 	ev[1].record(); torch.cuda.synchronize()
 	retrieve_ms = ev[0].elapsed_time(ev[1]) / n_ro
 	def survivors(kk):   # candidates per query the sweep of the last call kept (the default workspace those calls ran on)
 		ws_ = ops._Workspace.get(_lib.load().anncur_score_topk_workspace_bytes(Q, I, Kp, kk), device)
-		return ops.fused_survivors(ws_, Q, I, Kp, kk, leading_sample=True)
+		return ops.fused_survivors(ws_, Q, I, Kp, kk, leading_sample=True, staged=args.sweep_staged)
 	survivors_k = survivors(kr)
 	survivors_k500 = None
 	# retrieve-only at k_retvr = 500, the reference's default for entry A (crossenc.py:238): more survivors, wave-level select with
@@ -684,13 +687,13 @@ def run_config(args, cfg_name, ctx, light=False):
 	retrieve500_ms = None
 	if not args.no_k500 and not light and ops.fused_supported(Q, I, Kp, 500):
 		for _ in range(2):
-			ops.score_topk_fused(Xr, cur._Etp_sorted, I, 500, leading_sample=True, item_ids=cur._item_ids)
+			ops.score_topk_fused(Xr, cur._Etp_sorted, I, 500, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged)
 		ev[0].record()
 		for _ in range(n_ro):
 			Xr = ops.gather_cols(A_test, anc_dev)
 			if Xr.shape[1] != Kp:
 				Xr = ops.pack_bf16(Xr, Kp)
-			ops.score_topk_fused(Xr, cur._Etp_sorted, I, 500, leading_sample=True, item_ids=cur._item_ids)
+			ops.score_topk_fused(Xr, cur._Etp_sorted, I, 500, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged)
 		ev[1].record(); torch.cuda.synchronize()
 		retrieve500_ms = ev[0].elapsed_time(ev[1]) / n_ro
 		survivors_k500 = survivors(500)
@@ -711,14 +714,35 @@ def run_config(args, cfg_name, ctx, light=False):
 			ev[1].record(); torch.cuda.synchronize()
 			return ev[0].elapsed_time(ev[1]) / n
 		one_ms = _timed(lambda: ops.eval_fused(Xq, cur._Etp, A_test, I, kr))
-		two_ms = _timed(lambda: (ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids), ops.approx_error_packed(Xq, cur._Etp, A_test, I)))
+		two_ms = _timed(lambda: (ops.score_topk_fused(Xq, cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged), ops.approx_error_packed(Xq, cur._Etp, A_test, I)))
 		err_ms = _timed(lambda: ops.approx_error_packed(Xq, cur._Etp, A_test, I))
 		entry_a = {"eval_fused_ms": one_ms, "two_kernel_route_ms": two_ms, "error_kernel_alone_ms": err_ms, "exact_scan_ms": scan_ms,
 				   "cell_kernels_ms": one_ms + scan_ms, "cell_kernels_two_kernel_route_ms": two_ms + scan_ms,
 				   "what": "retrieval (prepass, threshold, sweep stages, refinement, select) + per-row sum (S_hat - A)^2, sum A^2 of one entry-A grid cell at this size; "
 						   "eval_fused = one S_hat GEMM per sweep stage (csrc/score_evalf.hpp), two-kernel route = the fused top-k and error_lds_kernel (two S_hat GEMMs)"}
+	# ------------------------------------------------------------------ roofline.ceiling: the same sweep with (almost) nothing to keep
+	# "a bare-loop ceiling measurement (same tile schedule, survivors suppressed)".  On the PRODUCT library: the same queries against
+	# a copy of the index whose item rows from the 2049th on are scaled by 2^-7 (an exponent shift: the bf16 mantissas, hence the operands' bit
+	# activity, stay what they are) -- every query's top-k then lies among the first 2048 items, the prepass threshold clears everything after the
+	# first 64 tiles, and the sweep kernel runs its plan (tickets, tile DMA, MFMA chain, filter compares, barrier) with ~no hit block taken.
+	ceiling = None
+	if not light and not args.no_ceiling and I > 8192:
+		Et_bare = cur._Etp_sorted.clone()
+		Et_bare[2048:] *= 0.0078125
+		bare = np.zeros(9)
+		for i_ in range(n_prof + 1):
+			_, ms = ops.score_topk_fused_timed(Xq, Et_bare, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged)
+			if i_ > 0: bare += np.array(ms)
+		bare /= n_prof
+		ws_ = ops._Workspace.get(_lib.load().anncur_score_topk_workspace_bytes(Q, I, Kp, kr), device)
+		bare_surv = ops.fused_survivors(ws_, Q, I, Kp, kr, leading_sample=True, staged=args.sweep_staged)
+		ceiling = {"sweep_kernels_ms": float(bare[4]), "achieved": 2.0 * Q * Kp * I / (float(bare[4]) * 1e-3) / 1e12, "unit": "TFLOP/s",
+				   "frac": 2.0 * Q * Kp * I / (float(bare[4]) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "survivors_per_query": bare_surv,
+				   "what": "the same sweep kernel(s), plan and queries against an index copy whose item rows past the 2048th are scaled by 2^-7: the top-k lies in the first 64 tiles and "
+						   "the rest of the sweep takes no hit block -- what this tile loop does on this box with the candidate path idle (HIP events, this run)"}
+		del Et_bare
 	_mark("per-kernel timings done")
-	plan_now = ops.fused_plan(Q, I, Kp, kr, leading_sample=True)
+	plan_now = ops.fused_plan(Q, I, Kp, kr, leading_sample=True, staged=args.sweep_staged)
 	n_sweep = max(1, int(round(stage[5])))                 # the sweep runs as n_sweep launches of the same kernel (threshold refined in between)
 	sweep_flops = 2.0 * Q * Kp * I / n_sweep               # algorithmic flops per launch (average over the stages)
 	sweep_ms = stage[4] / n_sweep                          # average launch duration of score_kernel<Kp,sweep>
@@ -774,7 +798,8 @@ def run_config(args, cfg_name, ctx, light=False):
 						 "achieved": sweep_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": sweep_tflops / PEAK_BF16_TFLOPS,
 						 "traffic": traffic, "flops_per_launch": sweep_flops, "avg_launch_ms": float(sweep_ms), "launches_per_step": n_sweep,
 						 "frac_rocprof": (sweep_flops / (rocprof_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS if rocprof_ms else None), "avg_launch_ms_rocprof": rocprof_ms,
-						 "rocprof_source": rocprof_src, "stages_rocprof": rocprof_stages,
+						 "rocprof_source": rocprof_src, "stages_rocprof": rocprof_stages, "ceiling": ceiling,
+						 "survivors_per_query": survivors_k,
 						 "what": "achieved / frac / avg_launch_ms: HIP events around every sweep launch of this (un-profiled) run; *_rocprof: the same kernel in the last committed rocprofv3 summary under profiles/"},
 			"roofline_scan": {"bound": "hbm", "kernel": "rowwise_topk_wave_kernel<bf16> (exact top-k scan, one wave per row)",
 							  "achieved": scan_bytes / (scan_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -901,6 +926,8 @@ def main():
 	ap.add_argument("--fold-gather", action="store_true", help="--scan-mode partition: C_q out of the scan's own pass over A (anncur_rowwise_topk_gather) instead of "
 					"the gather kernel -- built for SURVEY a2's 'fold into the first pass', measured slower (see the comment at its use): off by default")
 	ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a captured HIP graph")
+	ap.add_argument("--sweep-staged", action="store_true", help="A/B: the retrieval's sweep in stages with a refinement launch between them (ANNCUR_TOPK_STAGED, rounds 1-4) instead of one launch with the in-flight threshold ladder")
+	ap.add_argument("--no-ceiling", action="store_true", help="skip roofline.ceiling (the sweep on survivor-free operands); profiling runs: its launches share the sweep kernel's name")
 	ap.add_argument("--direct", action="store_true", help="measure in THIS process (no supervisor / worker split, no fallback attempt): what profiling scripts put behind `rocprofv3 --`")
 	args = ap.parse_args()
 	world = int(os.environ.get("WORLD_SIZE", "1"))

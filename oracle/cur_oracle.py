@@ -222,8 +222,9 @@ def eval_approx_score_mat(exact, approx, top_k, top_k_retvr):
 
 # --------------------------------------------------------------------------- entry point A
 def run_approx_eval_w_seed(approx_method, A, n_ment_anchors, n_ent_anchors, top_k, top_k_retvr, seed,
-						   precomp_approx=None):
-	"""eval/run_retrieval_eval_wrt_exact_crossenc.py:47-158."""
+						   precomp_approx=None, stable=False):
+	"""eval/run_retrieval_eval_wrt_exact_crossenc.py:47-158.  stable=True: the per-query loop with the tie-stable top-k (per_query_loop_stable) --
+	the well-defined statement of the same lines for tie-heavy (bf16) score matrices."""
 	n_ments, n_ents = A.shape
 	rng = np.random.default_rng(seed=seed)                                    # :65
 	row_idxs = select_anchors(rng, n_ments, n_ment_anchors)                   # :67
@@ -239,7 +240,10 @@ def run_approx_eval_w_seed(approx_method, A, n_ment_anchors, n_ent_anchors, top_
 		S = precomp_approx
 	else:
 		raise NotImplementedError(f"approx_method = {approx_method} not supported")
-	(ex_i, _), _, (rr_i, _) = per_query_loop(A, S, top_k, top_k_retvr)        # :97-122
+	if stable:
+		ex_i, _, rr_i = per_query_loop_stable(A, S, top_k, top_k_retvr)
+	else:
+		(ex_i, _), _, (rr_i, _) = per_query_loop(A, S, top_k, top_k_retvr)    # :97-122
 
 	def score(idxs):                                                          # :124-148
 		res = overlap_to_flat(compute_overlap(ex_i[idxs], rr_i[idxs]))

@@ -9,10 +9,10 @@ cfg=${2:-cfg2}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --config $cfg --steps 10 --warmup 2 --cpu-sample-queries 0 --sustained-seconds 0 --no-k500 --no-graph --no-overlap --no-ivf > $out/bench_stats.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --direct --no-ceiling --config $cfg --steps 10 --warmup 2 --cpu-sample-queries 0 --sustained-seconds 0 --no-k500 --no-graph --no-overlap --no-ivf > $out/bench_stats.json 2> $out/stats.err
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   name=$(echo $pmc | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d $out/pmc_$name -o run -- python3 bench.py --config $cfg --steps 3 --warmup 1 --cpu-sample-queries 0 --sustained-seconds 0 --no-k500 --no-graph --no-overlap --no-ivf > $out/bench_$name.json 2> $out/pmc_$name.err
+  rocprofv3 --kernel-trace --output-format csv --pmc $pmc -d $out/pmc_$name -o run -- python3 bench.py --direct --no-ceiling --config $cfg --steps 3 --warmup 1 --cpu-sample-queries 0 --sustained-seconds 0 --no-k500 --no-graph --no-overlap --no-ivf > $out/bench_$name.json 2> $out/pmc_$name.err
   echo "pmc pass $name done"
 done
 find $out -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete

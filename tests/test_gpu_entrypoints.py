@@ -401,6 +401,90 @@ def test_row_sharded_entry_A_equals_single_process(gpu):
 			assert sharded == pytest.approx(single, rel=1e-5, abs=1e-6), (t, m)
 
 
+# ------------------------------------------------------------------ bf16 entry A through anncur_eval_fused
+def _bf16_cell_matrix():
+	"""A bf16 score matrix large enough for the one-sweep route of a grid cell (cur.eval_rows / CURRowIndex.eval_cell -> ops.eval_fused)."""
+	g = torch.Generator().manual_seed(21)
+	Z = torch.randn(24, 20000, generator=g)
+	A = torch.randn(1200, 24, generator=g) @ Z / (24 ** 0.5) + 0.1 * torch.randn(1200, 20000, generator=g)
+	return A.bfloat16()
+
+
+def _check_cell_against_oracle(got, want, top_k):
+	"""recall statistics within 5e-3 (means) / one count (p50), error norms within 2e-3 relative -- the bf16 route's bar (bf16 copies of E and C_q)."""
+	for t in ("anchor", "non_anchor", "all"):
+		for m, w in want[t].items():
+			g = float(got[t][m])
+			if m.startswith("approx_error"):
+				assert g == pytest.approx(float(w), rel=2e-3), (t, m, g, float(w))
+			elif m.endswith("_p50"):
+				assert abs(g - float(w)) <= (1.0 / top_k if "_frac_" in m else 1.0) + 1e-9, (t, m, g, float(w))
+			elif m.endswith("_std"):
+				assert abs(g - float(w)) <= (2e-2 if "_frac_" in m else 2e-2 * top_k), (t, m, g, float(w))
+			else:
+				assert abs(g - float(w)) <= (5e-3 if "_frac_" in m else 5e-3 * top_k), (t, m, g, float(w))
+
+
+def test_entry_A_bf16_cell_through_eval_fused_matches_the_oracle(gpu):
+	"""The product wiring of round 4's one-sweep route: harness.run_approx_eval_w_seed("cur") on a bf16 matrix (subset sums of the per-row error
+	terms, square roots, the NaN of an empty subset) against the ORACLE's statement of crossenc.py:47-158 on the same bf16-rounded values
+	(tie-stable loop: bf16 scores are tie-heavy and torch.topk's tie order is arbitrary)."""
+	from anncur_amd import harness, ops
+	from oracle import cur_oracle as O
+	A = _bf16_cell_matrix()
+	A_dev = A.to(gpu)
+	top_k, k_retvr = 100, 100      # (top_k = k_retvr: recall well below 1, so the comparison has teeth)
+	assert ops.eval_fused_ok(64, A_dev, 1200, 20000, k_retvr), "the cell must take the one-sweep route"
+	taken = []
+	orig = ops.eval_fused
+	ops.eval_fused = lambda *a, **kw: (taken.append(1), orig(*a, **kw))[1]
+	try:
+		got = harness.run_approx_eval_w_seed("cur", A_dev, 128, 64, top_k, k_retvr, seed=3)
+		full = harness.run_approx_eval_w_seed("cur", A_dev, 1200, 64, top_k, k_retvr, seed=3)     # every row an anchor: the non-anchor subset is empty
+	finally:
+		ops.eval_fused = orig
+	assert len(taken) == 2, "harness.run_approx_eval_w_seed did not go through ops.eval_fused"
+	want = O.run_approx_eval_w_seed("cur", A.float(), 128, 64, top_k, k_retvr, seed=3, stable=True)
+	_check_cell_against_oracle(got, want, top_k)
+	assert np.isnan(full["non_anchor"]["approx_error_relative"]) and float(full["non_anchor"]["approx_error"]) == 0.0   # 0 / 0, like torch.norm of an empty block
+	assert float(full["anchor"]["approx_error"]) == pytest.approx(float(full["all"]["approx_error"]), rel=1e-6)
+
+
+def _sharded_bf16_worker(rank, world, port, q):
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	from anncur_amd import harness, ops
+	from anncur_amd.dist import ShardedScoreMatrix, shard_bounds
+	A = _bf16_cell_matrix()
+	s, e = shard_bounds(1200, rank, world)
+	A_loc = A[s:e].cuda()
+	fused_ok = bool(ops.eval_fused_ok(64, A_loc, e - s, 20000, 100))
+	sm = ShardedScoreMatrix(A_loc, 1200)
+	res = harness.run_approx_eval_w_seed_sharded(sm, 128, 64, 100, 100, seed=3)
+	q.put((rank, fused_ok, None if res is None else {t: {m: float(v) for m, v in d.items()} for t, d in res.items()}))
+	dist.destroy_process_group()
+
+
+def test_entry_A_bf16_cell_row_sharded_matches_the_oracle(gpu):
+	"""The same cell on a row-sharded bf16 matrix (two ranks over gloo on the one GPU): CURRowIndex.eval_cell -> ops.eval_fused on every rank's
+	block, the [counts, err, nrm] rows gathered to rank 0 -- against the oracle, to the same bar as the single-process cell."""
+	import torch.multiprocessing as mp
+	from oracle import cur_oracle as O
+	ctx = mp.get_context("spawn")
+	q = ctx.Queue()
+	port = 29300 + os.getpid() % 200
+	procs = [ctx.Process(target=_sharded_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+	for p in procs: p.start()
+	outs = [q.get(timeout=600) for _ in procs]
+	for p in procs: p.join(timeout=60)
+	assert all(ok for _, ok, _ in outs), "every rank's block must take the one-sweep route"
+	res = [r for _, _, r in outs if r is not None]
+	assert len(res) == 1
+	want = O.run_approx_eval_w_seed("cur", _bf16_cell_matrix().float(), 128, 64, 100, 100, seed=3, stable=True)
+	_check_cell_against_oracle(res[0], want, 100)
+
+
 def test_entry_A_from_score_chunks_equals_combined_pickle(gpu, tmp_path):
 	"""the producer's row chunks ingested straight to the device give the same results file as the combined pickle
 	(the reference's pickle -> cat -> pickle -> load route), and the combiner writes that pickle with the reference's schema."""
@@ -521,3 +605,41 @@ def test_entry_point_B_other_methods_match_reference_restatement(gpu, tmp_path):
 	# bienc (splits.py:283): scores = mention_embeds @ label_embeds.T from precomputed embeddings
 	f3 = epB.main(common + ["--eval_method", "bienc", "--mention_embeds_file", str(tmp_path / "ment.npy"), "--entity_embeds_file", str(tmp_path / "ent.npy"), "--misc", "bi"])
 	check(f3, sweep({a: ment_emb @ ent_emb.t() for a in ancs}), 5e-3)
+
+
+def test_entry_point_B_fixed_anc_ent_methods_match_reference_goldens(gpu, tmp_path, golden_dir, golden_meta):
+	"""a13 against the REFERENCE: eval_method = fixed_anc_ent / fixed_anc_ent_cur through this build's CLI with the default
+	(= the reference's hard-coded) grids, against what the reference's own run_eval_method returned on the same pickles
+	(oracle/make_golden.py (viii): tests/golden/fixed_anc_ent_1100.npz, 4704 cells per method).  A cell may differ by two swapped boundary
+	near-ties among its 150 queries (fp32 summation order); at least 97 % of the cells must agree to the reference's own 4 decimals."""
+	from eval import run_retrieval_eval_wrt_exact_crossenc_w_fixed_train_test_splits as epB
+	gold = np.load(os.path.join(golden_dir, "fixed_anc_ent_1100.npz"))
+	g = torch.Generator().manual_seed(13)
+	n_ent, n_train, n_test, r, n_fixed = 1100, 50, 150, 12, 40
+	Z = torch.randn(r, n_ent, generator=g)
+	A_train = torch.randn(n_train, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_train, n_ent, generator=g)
+	A_test = torch.randn(n_test, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_test, n_ent, generator=g)
+	topk_ents = torch.randperm(n_ent, generator=g)[:60]
+	e2e = (Z.t() @ Z[:, topk_ents]) / r + 0.02 * torch.randn(n_ent, 60, generator=g)
+	_dump(str(tmp_path / "train.pkl"), A_train, ment_idxs=list(range(n_train)))
+	_dump(str(tmp_path / "test.pkl"), A_test, ment_idxs=list(range(n_train, n_train + n_test)))
+	with open(tmp_path / "e2e.pkl", "wb") as f:
+		pickle.dump({"ent_to_ent_scores": e2e, "topk_ents": [topk_ents.numpy()]}, f)
+	common = ["--data_name", "lego", "--res_dir", str(tmp_path / "out"), "--test_data_file", str(tmp_path / "test.pkl"), "--train_data_file", str(tmp_path / "train.pkl"),
+			  "--n_seeds", "1", "--e2e_fname", str(tmp_path / "e2e.pkl"), "--n_fixed_anc_ent", str(n_fixed), "--pinv", "numpy"]
+	for method in ("fixed_anc_ent", "fixed_anc_ent_cur"):
+		assert golden_meta["fixed_anc_ent"][method]["cells"] == len(gold[f"{method}_keys"]) == 4704
+		res_file = epB.main(common + ["--eval_method", method, "--misc", method])
+		with open(res_file) as f:
+			got = json.load(f)["seed=0"]
+		n_cells = n_exact = 0
+		worst = 0.0
+		for (tk, kr, na), want_cnt, want_frac in zip(gold[f"{method}_keys"].tolist(), gold[f"{method}_common_mean"].tolist(), gold[f"{method}_common_frac_mean"].tolist()):
+			if method == "fixed_anc_ent_cur" and na == 0:
+				continue   # zero anchors: S_hat = 0, every item ties, and the reference's own number is whatever order torch.topk returns
+			cell = got[f"top_k={tk}"][f"k_retvr={kr}"][f"anc_n_m={n_train}_anc_n_e={na}"]
+			d = abs(cell["exact_vs_reranked_approx_retvr~common_mean"] - want_cnt)
+			assert d <= 2.0 / n_test + 1.01e-4, (method, tk, kr, na, cell["exact_vs_reranked_approx_retvr~common_mean"], want_cnt)
+			assert abs(cell["exact_vs_reranked_approx_retvr~common_frac_mean"] - want_frac) <= 2.0 / n_test / tk + 1.01e-4, (method, tk, kr, na)
+			n_cells += 1; n_exact += d <= 1.01e-4; worst = max(worst, d)
+		assert n_cells >= 4500 and n_exact >= 0.97 * n_cells, (method, n_cells, n_exact, worst)

@@ -142,3 +142,42 @@ def test_grids_match_reference_defaults():
 	kr, na = O.splits_grids(10031)
 	assert kr[0] == 0 and 1000 in kr and 900 in kr and 45 in kr
 	assert 10031 in na and 2000 in na and 10 in na
+
+
+def test_oracle_loop_reproduces_the_fixed_anc_ent_goldens(golden_dir):
+	"""splits.py:305-358 through the oracle's statement of the per-query loop, against what the reference's own run_eval_method returned on the same
+	inputs (oracle/make_golden.py (viii)): fixed_anc_ent on a few k_retvr values, fixed_anc_ent_cur on the first anchor counts of the reference's
+	sequential rng(0) stream."""
+	import torch
+	from oracle import cur_oracle as O
+	gold = np.load(os.path.join(golden_dir, "fixed_anc_ent_1100.npz"))
+	g = torch.Generator().manual_seed(13)
+	n_ent, n_train, n_test, r, n_fixed = 1100, 50, 150, 12, 40
+	Z = torch.randn(r, n_ent, generator=g)
+	A_train = torch.randn(n_train, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_train, n_ent, generator=g)
+	A_test = torch.randn(n_test, r, generator=g) @ Z / r ** 0.5 + 0.05 * torch.randn(n_test, n_ent, generator=g)
+	topk_ents = torch.randperm(n_ent, generator=g)[:60]
+	e2e = (Z.t() @ Z[:, topk_ents]) / r + 0.02 * torch.randn(n_ent, 60, generator=g)
+	key = "exact_vs_reranked_approx_retvr~common_frac_mean"
+
+	def cells(method):
+		return {tuple(k): v for k, v in zip(gold[f"{method}_keys"].tolist(), gold[f"{method}_common_frac_mean"].tolist())}
+	want = cells("fixed_anc_ent")
+	S_fix = A_test[:, topk_ents[:n_fixed]] @ e2e[:, :n_fixed].t()
+	anc_vals = sorted({k[2] for k in want})
+	for kr in (10, 50, 200):
+		for k, m in O.eval_approx_score_mat_for_all_topk(A_test, S_fix, [1, 10, 50, 100], kr).items():
+			for na in (anc_vals[0], anc_vals[7], anc_vals[-1]):   # the same numbers under every anchor count (splits.py:399-407)
+				assert m[key] == pytest.approx(want[(k, kr, na)], abs=1.01e-4), (k, kr, na)
+	want = cells("fixed_anc_ent_cur")
+	R = e2e[:, :n_fixed].t()
+	rng = np.random.default_rng(seed=0)
+	for n_anc in anc_vals[:6]:                                     # (0, 1, 2, ...: consumed in grid order from ONE generator)
+		anc = sorted(rng.choice(n_ent, size=n_anc, replace=False))
+		if n_anc == 0:
+			continue
+		U = torch.tensor(np.linalg.pinv(R[:, anc].numpy()))
+		S = A_test[:, anc] @ (U @ R)
+		for kr in (10, 100):
+			for k, m in O.eval_approx_score_mat_for_all_topk(A_test, S, [1, 10, 50, 100], kr).items():
+				assert m[key] == pytest.approx(want[(k, kr, n_anc)], abs=1.01e-4), (k, kr, n_anc)

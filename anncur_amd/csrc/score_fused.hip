@@ -2362,7 +2362,12 @@ int launch_wide(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, 
 		stages.end[g] = P.stage_end[g] * u < n_tiles32 ? P.stage_end[g] * u : n_tiles32;
 		stages.tps[g] = P.stage_tps[g] * u;
 	}
+#if defined(ANNCUR_V_WIDE_NOREAD) || defined(ANNCUR_V_WIDE_MFMAONLY) || defined(ANNCUR_V_WIDE_NODMA_NOREAD) || defined(ANNCUR_V_WIDE_NODMA) || defined(ANNCUR_V_WIDE_NOBAR) || defined(ANNCUR_V_WIDE_NOFILTER) || defined(ANNCUR_V_WIDE_BASE)
+	// (ablation builds of wide_kernel: the candidates are garbage, the select -- which would repair every query from scratch -- is skipped)
+	(void)item_ids; (void)out_val; (void)out_idx;
+#else
 	if ((rc = launch_select(P, 4 * P.S, stages, p.cand, p.seg_cnt, p.X, ldx, p.Et, Q, I, KP, k, out_val, out_idx, ws, p.tau, p.tau_stride, st, item_ids)) != ANNCUR_OK) return rc;
+#endif
 	EV(4);
 	return ANNCUR_OK;
 }

@@ -65,7 +65,7 @@ __device__ __forceinline__ void wide_dma(const unsigned char *base, const uint32
 										 (__attribute__((address_space(3))) void *)(tile + (wave * 4 + i) * 1024), 16, 0, 0);
 }
 
-struct WideFrag { bf16x8 a[4], b[2]; };
+struct WideFrag { u32x4 a[4], b[2]; };   // raw registers: inline-asm read destinations
 
 // MODE 0: prepass (group maxima, GROUP = 16 or 4 items).  MODE 1: filter sweep.
 template <int MODE, int GROUP>
@@ -121,12 +121,23 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 		segoff[t] = (uint32_t)(((wq * 64 + 32 * t + r) * nseg + sg) * p.capg) * 8u;
 	}
 
-	// ---- fragment addresses: row * 128 + ((2 s + h) ^ x) * 16, x = (row >> 1) & 7 = (r >> 1) & 7 for every sub-tile
+	// ---- fragment addresses: row * 128 + ((2 s + h) ^ x) * 16, x = (row >> 1) & 7 = (r >> 1) & 7 for every sub-tile.
+	// Round 5: the reads are inline asm with COUNTED waits (as the Kp <= 256 sweep's): hipcc waited lgkmcnt(0) in front of every second MFMA
+	// group, i.e. for the fragments it had requested one instruction earlier -- two exposed LDS round trips per k-tile.  One address register
+	// per (operand, k-step) of stage 0; stage 1 is 64 KiB on, past the 16-bit offset field, so it gets registers of its own (STAGE is a literal).
 	const int x = (r >> 1) & 7;
-	const uint32_t a_base = (uint32_t)(wi * 128 + r) * 128u, b_base = (uint32_t)W_TILE_BYTES + (uint32_t)(wq * 64 + r) * 128u;
-	uint32_t coff[4];
+	const uint32_t lds0 = lds_addr(smem);
+	uint32_t fa[2][4], fb[2][4];
 #pragma unroll
-	for (int s = 0; s < 4; ++s) coff[s] = (uint32_t)(((2 * s + h) ^ x) * 16);
+	for (int s = 0; s < 4; ++s) {
+		const uint32_t co = (uint32_t)(((2 * s + h) ^ x) * 16);
+		fa[0][s] = lds0 + (uint32_t)(wi * 128 + r) * 128u + co;
+		fb[0][s] = lds0 + (uint32_t)W_TILE_BYTES + (uint32_t)(wq * 64 + r) * 128u + co;
+		fa[1][s] = fa[0][s] + (uint32_t)W_STAGE_BYTES;
+		fb[1][s] = fb[0][s] + (uint32_t)W_STAGE_BYTES;
+	}
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const uint32_t lds0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds0);
 
 	if (j_begin < j_end) {
 		set_asrc(bt_of(j_begin));
@@ -146,70 +157,82 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 #pragma unroll
 				for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
 
-		// One 64-wide k-tile = 4 k-steps of 6 fragment reads + 8 MFMAs; the fragments of step s + 1 are requested before the
-		// MFMAs of step s (two register sets), so only the first read of a k-tile exposes its LDS latency.
-#define WIDE_LOAD(F, STAGE, s)                                                                                    \
+		// One 64-wide k-tile = 4 k-steps of 6 fragment reads + 8 MFMAs.  The fragments of step s + 1 are requested before the MFMAs of step s
+		// (two register sets) and the MFMAs wait with lgkmcnt(6): the six reads just issued stay in flight.
+		// (ablation builds, `make variant V=WIDE_<what>`: results become wrong; scripts/r5/wide_ablation.sh)
+#if defined(ANNCUR_V_WIDE_NOREAD) || defined(ANNCUR_V_WIDE_MFMAONLY) || defined(ANNCUR_V_WIDE_NODMA_NOREAD)
+#define WIDE_LOAD(F, STAGE, s) do { if (kt == 0 && j == j_begin) { WIDE_LOAD_(F, STAGE, s); } } while (0)
+#else
+#define WIDE_LOAD(F, STAGE, s) WIDE_LOAD_(F, STAGE, s)
+#endif
+#define WIDE_LOAD_(F, STAGE, s)                                                                                   \
 		do {                                                                                                      \
-			const unsigned char *sb = smem + (STAGE) * W_STAGE_BYTES + coff[s];                                   \
-			_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                         \
-				F.a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(sb + a_base + m * 4096));    \
-			_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
-				F.b[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(sb + b_base + t * 4096));    \
+			_Pragma("unroll") for (int m = 0; m < 4; ++m) lds_read_frag_at(F.a[m], fa[STAGE][s], m * 4096);        \
+			_Pragma("unroll") for (int t = 0; t < 2; ++t) lds_read_frag_at(F.b[t], fb[STAGE][s], t * 4096);        \
 		} while (0)
+#define WIDE_WAIT(F, N)                                                                                           \
+		asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]), "+v"(F.b[0]), "+v"(F.b[1]) : "n"(N))
 #define WIDE_MFMA(F)                                                                                              \
 		do {                                                                                                      \
 			_Pragma("unroll") for (int m = 0; m < 4; ++m)                                                         \
 				_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                     \
-					acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[m], F.b[t], acc[m][t], 0, 0, 0);      \
+					acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.a[m]), __builtin_bit_cast(bf16x8, F.b[t]), acc[m][t], 0, 0, 0); \
 		} while (0)
 		// The wave's DMA pieces of the next k-tile have landed, its fragment reads are done: raw barrier.
 		// (Tried and dropped: warming the XCD's L2 two k-tiles ahead with one 4-byte load per 128-byte line and thread, excluded
 		//  from the wait by a counted vmcnt: 907 vs 960 TFLOP/s at 10k x 100k x 1024 -- the loop is not waiting on misses.)
+#if defined(ANNCUR_V_WIDE_NOBAR) || defined(ANNCUR_V_WIDE_MFMAONLY)
+#define WIDE_SYNC() do { } while (0)
+#else
 #define WIDE_SYNC()                                                                                               \
 		do {                                                                                                      \
 			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
 			__builtin_amdgcn_s_barrier();                                                                         \
 			asm volatile("" ::: "memory");                                                                        \
 		} while (0)
+#endif
 		// DMA of the next k-tile: two of the wave's eight 1 KiB pieces per k-step, issued between the fragment reads and the MFMAs
 		// of the step (eight back-to-back issues at the head of the k-tile kept both waves of a SIMD off the matrix pipe together).
-#define WIDE_PIECE(BASE, OFF, TILE, i)                                                                            \
-		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((BASE) + (OFF)[i]),      \
-										 (__attribute__((address_space(3))) void *)((TILE) + (wave * 4 + (i)) * 1024), 16, 0, 0)
+		// Hand-placed (round 5): uniform 64-bit base in SGPRs + the lane's 32-bit offset, M0 from a scalar -- the builtin cost two 64-bit
+		// VALU adds and two v_readfirstlane per piece.
+#if defined(ANNCUR_V_WIDE_NODMA) || defined(ANNCUR_V_WIDE_MFMAONLY) || defined(ANNCUR_V_WIDE_NODMA_NOREAD)
+#define WIDE_NODMA_COND && false
+#else
+#define WIDE_NODMA_COND
+#endif
+#define WIDE_PIECE(BASE, OFF, TILE_OFF, i)                                                                        \
+		do {                                                                                                      \
+			const uint32_t m0v_ = lds0_u + (uint32_t)(TILE_OFF) + (uint32_t)(wave_u * 4 + (i)) * 1024u;            \
+			asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v_), "v"((OFF)[i]), "s"(BASE) : "memory", "m0"); \
+		} while (0)
 #define WIDE_DMA2(s)                                                                                              \
 		do {                                                                                                      \
-			if (den) {                                                                                            \
+			if (den WIDE_NODMA_COND) {                                                                                            \
 				if ((s) < 2) { WIDE_PIECE(da, aoff, dd, 2 * ((s) & 1)); WIDE_PIECE(da, aoff, dd, 2 * ((s) & 1) + 1); } \
 				else { WIDE_PIECE(db, boff, dd + W_TILE_BYTES, 2 * ((s) & 1)); WIDE_PIECE(db, boff, dd + W_TILE_BYTES, 2 * ((s) & 1) + 1); } \
 			}                                                                                                     \
 		} while (0)
-#ifdef WIDE_SETPRIO
-#define WIDE_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define WIDE_PRIO(x) do {} while (0)
-#endif
 #define WIDE_COMPUTE(STAGE)                                                                                       \
 		do {                                                                                                      \
 			WideFrag f0, f1;                                                                                      \
 			WIDE_LOAD(f0, STAGE, 0);                                                                              \
-			__builtin_amdgcn_sched_barrier(0);                                                                    \
-			WIDE_LOAD(f1, STAGE, 1); WIDE_DMA2(0); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f0); WIDE_PRIO(0); __builtin_amdgcn_sched_barrier(0); \
-			WIDE_LOAD(f0, STAGE, 2); WIDE_DMA2(1); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f1); WIDE_PRIO(0); __builtin_amdgcn_sched_barrier(0); \
-			WIDE_LOAD(f1, STAGE, 3); WIDE_DMA2(2); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f0); WIDE_PRIO(0); __builtin_amdgcn_sched_barrier(0); \
-			WIDE_DMA2(3); __builtin_amdgcn_sched_barrier(0); WIDE_PRIO(1); WIDE_MFMA(f1); WIDE_PRIO(0);           \
+			WIDE_LOAD(f1, STAGE, 1); WIDE_DMA2(0); WIDE_WAIT(f0, 6); WIDE_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
+			WIDE_LOAD(f0, STAGE, 2); WIDE_DMA2(1); WIDE_WAIT(f1, 6); WIDE_MFMA(f1); __builtin_amdgcn_sched_barrier(0); \
+			WIDE_LOAD(f1, STAGE, 3); WIDE_DMA2(2); WIDE_WAIT(f0, 6); WIDE_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
+			WIDE_DMA2(3); WIDE_WAIT(f1, 0); WIDE_MFMA(f1);                                                         \
 		} while (0)
 
 		ANNCUR_PAD_HERE();
 		for (int kt = 0; kt < nk; kt += 2) {
 			// stage 0 holds k-tile kt: fetch kt + 1 into stage 1 while it is consumed
 			const unsigned char *da = abase + (kt + 1) * 128, *db = xbase + (kt + 1) * 128;
-			unsigned char *dd = smem + W_STAGE_BYTES;
+			uint32_t dd = (uint32_t)W_STAGE_BYTES;   // LDS byte offset of the stage being filled
 			bool den = true;
 			WIDE_COMPUTE(0);
 			WIDE_SYNC();
 			// stage 1 holds k-tile kt + 1: fetch kt + 2 (or the first k-tile of the next block tile) into stage 0
 			const bool last = kt + 2 >= nk;
-			dd = smem;
+			dd = 0u;
 			if (!last) {
 				da = abase + (kt + 2) * 128; db = xbase + (kt + 2) * 128;
 			} else if (j + 1 < j_end) {
@@ -219,7 +242,12 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 				den = false;
 			}
 			WIDE_COMPUTE(1);
+#if defined(ANNCUR_V_WIDE_NOFILTER) || defined(ANNCUR_V_WIDE_MFMAONLY)
+			if (last) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1])); }
+			if (false) {
+#else
 			if (last) {
+#endif
 				// ---- epilogue of the block tile (the next tile's DMA is in flight).  C/D layout: query = lane & 31,
 				// item row = (e & 3) + 8 (e >> 2) + 4 h within the 32-item sub-tile m of the wave's item half wi
 				if (MODE == 0) {
@@ -278,7 +306,9 @@ __global__ __launch_bounds__(512, 2) void wide_kernel(const WideParams p) {
 #undef WIDE_SYNC
 #undef WIDE_PIECE
 #undef WIDE_DMA2
-#undef WIDE_PRIO
+#undef WIDE_WAIT
+#undef WIDE_NODMA_COND
+#undef WIDE_LOAD_
 	}
 #undef bt_of
 	if (MODE == 1) {

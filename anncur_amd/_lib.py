@@ -11,6 +11,8 @@ from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p, POINTE
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ANNCUR_LIB: measurement scripts point this at the -DANNCUR_TIMING_EXPERIMENTS build (`make -C anncur_amd/csrc experiments`)
 LIB_PATH = os.environ.get("ANNCUR_LIB") or os.path.join(_HERE, "lib", "libanncur_hip.so")
+# the experiments library (ablation knobs, A/B variants such as the tile-ring sweep body; never loaded by the product)
+IS_EXPERIMENTS_LIB = os.path.basename(LIB_PATH).startswith(("libanncur_hip_exp", "libanncur_hip_v_"))
 
 F32, BF16, F64 = 0, 1, 2
 TOPK_LEADING_SAMPLE = 1

@@ -27,6 +27,7 @@
 //   done:   the tile function's last fragment read has returned (its final wait) -> ds_write done.
 //   reader: ds_read of the counters -> (values sufficient) -> ds_read of the tile / DMA into the slot.
 #pragma once
+#ifdef ANNCUR_TIMING_EXPERIMENTS   // (round 5) measured 3-4 % slower than the barrier body: compiled into the experiments library only
 
 template <int KP>
 struct Ring16Cfg {
@@ -414,3 +415,4 @@ __global__ __launch_bounds__(512, 2) void score16r_kernel(const FusedParams p) {
 		if (q < p.Q) p.seg_cnt[q * p.nseg + split] = c;
 	}
 }
+#endif  // ANNCUR_TIMING_EXPERIMENTS

@@ -1748,7 +1748,12 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_MFMA16") && !evalf) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
 #endif
+#ifdef ANNCUR_TIMING_EXPERIMENTS
 	P.ring16 = P.body16 && k <= WSEL_K && KP >= 128 && P.chunk == CHUNK_TILES && ring;   // opt-in (ANNCUR_TOPK_RING): measured slower than the barrier body, see score16r.hpp
+#else
+	P.ring16 = false;   // (the tile-ring body is compiled into the experiments library only; the product refuses the flag: score_topk_impl)
+	(void)ring;
+#endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_RING16")) P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && atoi(dbg) != 0;
 #endif
@@ -2153,12 +2158,15 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 				hipLaunchKernelGGL((scoreq16_kernel<KP>), dim3(p.n_wg), dim3(256), FusedQ1Cfg<KP>::LDS_BYTES, st, p);
 				launched = true;
 			}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
 			if (!launched && P.bodyq1) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)scoreq1_kernel<KP>, FusedQ1Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
 				hipLaunchKernelGGL((scoreq1_kernel<KP>), dim3(p.n_wg), dim3(256), FusedQ1Cfg<KP>::LDS_BYTES, st, p);
 				launched = true;
 			}
+#endif
 		}
+#ifdef ANNCUR_TIMING_EXPERIMENTS
 		if constexpr (KP >= 128 && KP <= 256 && QTV == 2) {  // 16x16x32 sweep, 8-wave workgroups with the flag-synchronised tile ring (score16r.hpp)
 			if (!launched && P.ring16) {
 				if ((rc = anncur_ensure_dyn_lds((const void *)score16r_kernel<KP>, Ring16Cfg<KP>::LDS_BYTES)) != ANNCUR_OK) return rc;
@@ -2166,6 +2174,7 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 				launched = true;
 			}
 		}
+#endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 		// score16_kernel<Kp, 8>: the barrier body in 8-wave workgroups (512 queries, one per CU: half the DMA pieces per wave).  Measured (round 4,
 		// one process): sweep launches 0.5125 vs 0.4874 ms, bare 0.436 vs 0.395 -- with both waves of a SIMD in ONE workgroup the partners run in
@@ -2378,6 +2387,13 @@ FusedPlan plan_any(int64_t Q, int64_t I, int KP, int k, int flags = 0) {
 	return wide_kp(KP) ? plan_wide(Q, I, KP, k, leading) : plan_fused(Q, I, KP, k, leading, mfma16 && !qt1, qt1, (flags & ANNCUR_TOPK_MFMA32) != 0, (flags & ANNCUR_TOPK_RING) != 0,
 																	  false, (flags & ANNCUR_TOPK_STAGED) != 0);
 }
+bool ring_flag_ok(int flags) {
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	(void)flags; return true;
+#else
+	return (flags & ANNCUR_TOPK_RING) == 0;
+#endif
+}
 constexpr int TOPK_FLAGS = ANNCUR_TOPK_LEADING_SAMPLE | ANNCUR_TOPK_MFMA16 | ANNCUR_TOPK_QT1 | ANNCUR_TOPK_MFMA32 | ANNCUR_TOPK_RING | ANNCUR_TOPK_STAGED;
 
 }  // namespace
@@ -2403,6 +2419,8 @@ static int score_topk_impl(const void *X, int64_t ldx, const void *Et, int64_t l
 						   int32_t k, float *out_val, int32_t *out_idx, void *workspace, size_t workspace_bytes,
 						   void *stream, hipEvent_t *ev, int32_t flags = 0, const int32_t *item_ids = nullptr, CoScan *co = nullptr, const EvalArgs *ea = nullptr) {
 	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk: unknown flags 0x%x", flags);
+	ANNCUR_REQUIRE(ring_flag_ok(flags), ANNCUR_E_UNSUPPORTED, "score_topk: ANNCUR_TOPK_RING (the tile-ring sweep body) is compiled into the experiments library only "
+				   "(make -C anncur_amd/csrc experiments; ANNCUR_LIB=.../libanncur_hip_exp.so): measured slower than the default body");
 	const FusedPlan P = ea ? plan_fused(Q, I, Kp, k, false, false, false, false, false, true) : plan_any(Q, I, Kp, k, flags);
 	ANNCUR_REQUIRE(P.ok, ANNCUR_E_UNSUPPORTED,
 				   "score_topk: (Q=%lld, I=%lld, Kp=%d, k=%d) is outside the fused path (Kp in {64,128,256,512} or a multiple of 128 up to %d, "
@@ -2556,6 +2574,7 @@ extern "C" int anncur_score_topk_plan(int64_t Q, int64_t I, int32_t Kp, int32_t 
  * what a test needs to see that a variant flag was honoured */
 extern "C" int anncur_score_topk_plan_ex(int64_t Q, int64_t I, int32_t Kp, int32_t k, int32_t flags, int32_t *out, int32_t n_out) {
 	ANNCUR_REQUIRE((flags & ~TOPK_FLAGS) == 0, ANNCUR_E_INVALID, "score_topk_plan_ex: unknown flags 0x%x", flags);
+	ANNCUR_REQUIRE(ring_flag_ok(flags), ANNCUR_E_UNSUPPORTED, "score_topk_plan_ex: ANNCUR_TOPK_RING is compiled into the experiments library only");
 	const FusedPlan P = plan_any(Q, I, Kp, k, flags);
 	ANNCUR_REQUIRE(P.ok && out && n_out >= 0, ANNCUR_E_UNSUPPORTED, "score_topk_plan_ex: unsupported shape");
 	const bool wide = wide_kp(Kp);

@@ -26,6 +26,7 @@ struct FusedQ1Cfg {
 // item row of accumulator register e within the lane's half of a 32-item tile
 #define Q1_ROW(e) ((uint32_t)(((e) & 3) + 8 * ((e) >> 2)))
 
+#ifdef ANNCUR_TIMING_EXPERIMENTS   // (round 5) superseded by scoreq16_kernel (score_q16.hpp, which keeps FusedQ1Cfg): the 32x32x16 body is an A/B variant of the experiments library
 // One tile: MFMA chain of this tile into `acc`, filter of the previous tile's accumulator `accP` in its shadow (one element every
 // second k-step); A fragments through the counted-wait register ring (see stagger1_tile).
 template <int KP, int CUR>
@@ -211,4 +212,5 @@ __global__ __launch_bounds__(256, 2) void scoreq1_kernel(const FusedParams p) {
 		if (q < p.Q) p.seg_cnt[q * p.nseg + split] = c;
 	}
 }
+#endif  // ANNCUR_TIMING_EXPERIMENTS
 #undef Q1_ROW

@@ -63,7 +63,7 @@ def test_sweep_variant_flags_reach_the_plan():
 	staged = ops.fused_plan(10000, 100000, 256, 100, staged=True)               # ANNCUR_TOPK_STAGED: rounds 1-4's staged sweep of the same body (A/B, parity reference)
 	assert not staged["ladder"] and staged["n_stages"] == len(staged["stage_end"]) == 2 and all(b == 2 for b in staged["stage_pred"]) and staged["lg"] == 1
 	assert ops._topk_flags(staged=True) == _lib.TOPK_STAGED and not ops.fused_plan(10000, 100000, 256, 100, mfma32=True)["ladder"]
-	assert not ops.fused_plan(6250, 1000000, 512, 100)["ladder"] and not ops.fused_plan(10000, 100000, 256, 100, ring=True)["ladder"]
+	assert not ops.fused_plan(6250, 1000000, 512, 100)["ladder"]
 	m32 = ops.fused_plan(10000, 100000, 256, 100, mfma32=True)
 	assert m32["lg"] == 2 and all(b in (0, 1) for b in m32["stage_pred"])
 	assert ops.fused_plan(10000, 100000, 256, 500)["lg"] == 2                   # k > 128: 32x32x16 throughout
@@ -76,12 +76,14 @@ def test_sweep_variant_flags_reach_the_plan():
 	assert p512["lg"] == 1 and p512["QT"] == 1 and all(b == 4 for b in p512["stage_pred"])            # ... on 16x16x32 MFMAs
 	assert ops.fused_plan(6250, 1000000, 512, 100, mfma32=True)["lg"] == 2           # the per-lane-ring body on request
 	assert ops.fused_plan(64, (1 << 26) + 64, 64, 10)["lg"] == 2                      # queue entries carry the query beside the item: I < 2^26
-	# ANNCUR_TOPK_RING (round 4): the 16x16x32 body in 8-wave workgroups of 512 queries with the flag-synchronised tile ring, Kp = 128 / 256
-	ring = ops.fused_plan(10000, 100000, 256, 100, ring=True)
-	assert all(b == 5 for b in ring["stage_pred"]) and ring["lg"] == 1 and ring["splits"] == 13    # ceil(256 CUs / 20 row blocks of 512 queries)
-	assert all(b == 5 for b in ops.fused_plan(10000, 100000, 128, 100, ring=True)["stage_pred"])
-	assert all(b == 2 for b in ops.fused_plan(10000, 100000, 64, 100, ring=True)["stage_pred"])    # Kp = 64: a tile is 4 DMA pieces, fewer than 8 waves
-	assert all(b in (0, 1) for b in ops.fused_plan(10000, 100000, 256, 500, ring=True)["stage_pred"])   # k > 128 keeps the 32x32x16 body
+	# ANNCUR_TOPK_RING (round 4: the 16x16x32 body in 8-wave workgroups with a flag-synchronised tile ring) measured slower than the default and lives
+	# in the experiments library only since round 5: the product refuses the flag instead of silently running something else
+	if _lib.IS_EXPERIMENTS_LIB:
+		ring = ops.fused_plan(10000, 100000, 256, 100, ring=True)
+		assert all(b == 5 for b in ring["stage_pred"]) and ring["lg"] == 1 and ring["splits"] == 13 and not ring["ladder"]
+	else:
+		with pytest.raises(_lib.AnncurHipError, match="experiments library"):
+			ops.fused_plan(10000, 100000, 256, 100, ring=True)
 	assert ops._topk_flags(ring=True) == _lib.TOPK_RING
 	import inspect
 	src = inspect.getsource(ops.score_topk_fused.__wrapped__) + inspect.getsource(ops.score_topk_fused_timed.__wrapped__)

@@ -229,6 +229,33 @@ def test_eval_fused_equals_the_two_kernel_route(ops, Q, I, K, k):
 		ops.eval_fused(Xp, Etp, A.float(), I, k)
 
 
+def test_error_kernels_with_a_row_pitch_beyond_the_32_bit_tile_offsets(ops):
+	"""error_lds_kernel / evalf_kernel address their tile of the exact matrix as a uniform base + a 32-bit byte offset (row within the row
+	block x pitch x 2); from a pitch of 8 421 504 elements on, row 255's offset wraps and the DMA would read the wrong rows -- silently.  The routes
+	that use those kernels are now taken only while the offsets fit: with a pitch of 8.6 M elements eval_fused is refused (the harness then takes
+	the two-kernel route) and approx_error_packed runs error_kernel's 64-bit row pointers -- sums equal to the compact matrix'."""
+	Q, I, K, k = 300, 40000, 64, 10
+	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=77)
+	Kp = Xp.shape[1]
+	A = (X.float() @ E.float() + 0.3 * torch.randn(Q, I, generator=_g(5))).bfloat16().cuda()
+	pitch = 8_600_000                                                  # > (2^32 - 64) / (255 * 2): 5.2 GB of bf16 for 300 rows
+	buf = torch.empty((Q, pitch), dtype=torch.bfloat16, device="cuda")
+	Aw = buf[:, :I]
+	Aw.copy_(A)
+	assert Aw.stride(0) == pitch and ops.eval_fused_ok(Kp, A, Q, I, k) and not ops.eval_fused_ok(Kp, Aw, Q, I, k)
+	with pytest.raises(Exception):
+		ops.eval_fused(Xp, Etp, Aw, I, k)
+	e0, n0 = ops.approx_error_packed(Xp, Etp, A, I)
+	e1, n1 = ops.approx_error_packed(Xp, Etp, Aw, I)
+	torch.cuda.synchronize()
+	torch.testing.assert_close(e1, e0, rtol=2e-5, atol=1e-6)
+	torch.testing.assert_close(n1, n0, rtol=2e-5, atol=1e-6)
+	rows = torch.tensor([0, 1, 130, 255, 256, 299])                     # (row 255 of a row block: the offset that wrapped)
+	S64 = X[rows].double() @ E.double()
+	torch.testing.assert_close(e1[rows.cuda()].double().cpu(), ((S64 - A[rows.cuda()].double().cpu()) ** 2).sum(1), rtol=1e-4, atol=1e-6)
+	del buf
+
+
 @pytest.mark.parametrize("Q,I,K,k", [(1000, 40000, 256, 10), (777, 50001, 200, 64), (513, 30000, 128, 32), (5, 20000, 256, 7), (2049, 123457, 256, 128), (4100, 200000, 128, 100)])
 def test_fused_ring_body_equals_the_barrier_body(ops, Q, I, K, k):
 	"""ANNCUR_TOPK_RING (round 4, csrc/score16r.hpp): 8-wave workgroups of 512 queries, the item tiles through a ring of four LDS slots
@@ -236,6 +263,9 @@ def test_fused_ring_body_equals_the_barrier_body(ops, Q, I, K, k):
 	arithmetic is the barrier body's instruction for instruction: values bit for bit, index sets identical, no repaired query, no spin
 	timeout (a timeout adds 2^30 to the fallback counter).  Ragged row blocks (Q not a multiple of 512), a partial last tile, both
 	item orders, one- and two-stage plans."""
+	from anncur_amd import _lib
+	if not _lib.IS_EXPERIMENTS_LIB:
+		pytest.skip("the tile-ring body is compiled into the experiments library only since round 5 (ANNCUR_LIB=anncur_amd/lib/libanncur_hip_exp.so)")
 	X, E, Xp, Etp = _fused_case(ops, Q, I, K, k, seed=Q + I + K + k)
 	Kp = Xp.shape[1]
 	plan = ops.fused_plan(Q, I, Kp, k, ring=True)

@@ -108,13 +108,18 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	if not ops.fused_supported(Q, I, Kp, k):
 		return
 	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
-	kw = dict(mfma16=variant == "mfma16", qt1=variant == "qt1", mfma32=variant == "mfma32", ring=variant == "ring")
+	from anncur_amd import _lib
+	if variant == "ring" and not _lib.IS_EXPERIMENTS_LIB:
+		variant = "staged"   # (round 5) the tile-ring body lives in the experiments library only; its draws exercise ANNCUR_TOPK_STAGED (the staged sweep of rounds 1-4) instead
+	kw = dict(mfma16=variant == "mfma16", qt1=variant == "qt1", mfma32=variant == "mfma32", ring=variant == "ring", staged=variant == "staged")
 	plan = ops.fused_plan(Q, I, Kp, k, **kw)
 	if variant == "ring":   # (round 4) the tile-ring body runs where the 16x16x32 body would: Kp = 128 / 256, k <= 128
 		assert all(b == 5 for b in plan["stage_pred"]) == (Kp in (128, 256) and k <= 128), plan
 	elif Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = 16x16x32 up to k = 384)
-		want_lg = {"mfma16": (1,), "mfma32": (2,), "qt1": (2,) if Kp >= 128 else (1, 2), "": (1, 2)}[variant]   # (qt1 at Kp = 64: no such body, the default runs)
+		want_lg = {"mfma16": (1,), "mfma32": (2,), "qt1": (2,) if Kp >= 128 else (1, 2), "": (1, 2), "staged": (1, 2)}[variant]   # (qt1 at Kp = 64: no such body, the default runs)
 		assert plan["lg"] in want_lg and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
+	if variant == "staged": assert not plan["ladder"]
+	elif variant == "" and plan["lg"] == 1 and Kp <= 256: assert plan["ladder"] and plan["n_stages"] == 1   # the default 16x16x32 body sweeps in one launch (threshold ladder)
 	v, i = ops.score_topk_fused(Xp, Etp, I, k, **kw)   # (sweep variants: same answer)
 	S = X.double() @ E.double()
 	rv, ri = torch.topk(S, k, dim=1)

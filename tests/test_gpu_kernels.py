@@ -229,6 +229,53 @@ def test_eval_fused_equals_the_two_kernel_route(ops, Q, I, K, k):
 		ops.eval_fused(Xp, Etp, A.float(), I, k)
 
 
+@pytest.mark.parametrize("kind", ["bench_like", "ascending_norms", "identical_queries", "integer_ties", "flat"])
+def test_fused_threshold_ladder_equals_the_staged_sweep(ops, kind):
+	"""Round 5 (csrc/score16.hpp): the default 16x16x32 body sweeps in ONE launch and moves its thresholds up a ladder of levels from device-wide
+	counts of the candidates kept so far.  Any timing of the counts must give THE top-k: against the staged sweep of rounds 1-4
+	(ANNCUR_TOPK_STAGED) bit for bit, and against the fp64 order.  Shapes of the data that stress it: item rows whose norms ASCEND (every later
+	tile beats the running threshold: the opposite of the index's order, segments overflow into the repair path), all queries identical (every
+	workgroup counts into the same few words), exactly representable integers with ties at every level, a flat ladder (all scores equal)."""
+	Q, I, K, k = 700, 60000, 256, 100
+	g = _g(123)
+	if kind == "integer_ties":
+		X = torch.randint(0, 3, (Q, K), generator=g).float().bfloat16()
+		E = torch.randint(-2, 3, (K, I), generator=g).float().bfloat16()
+	elif kind == "flat":
+		X = torch.ones(Q, K).bfloat16(); E = torch.ones(K, I).bfloat16()
+	else:
+		Z = torch.randn(24, I, generator=g)
+		X = torch.randn(Q, K, generator=g).bfloat16()
+		E = (torch.randn(K, 24, generator=g) @ Z / 24 ** 0.5 + 0.05 * torch.randn(K, I, generator=g))
+		if kind == "ascending_norms": E = E * torch.linspace(0.2, 2.0, I)[None, :]
+		if kind == "identical_queries": X = X[:1].expand(Q, K).contiguous()
+		E = E.bfloat16()
+	Kp = ops.padded_k(K)
+	Xp = ops.pack_bf16(X.cuda(), Kp); Etp = ops.pack_bf16(E.t().contiguous().cuda(), Kp, row_multiple=32)
+	plan, plan_s = ops.fused_plan(Q, I, Kp, k), ops.fused_plan(Q, I, Kp, k, staged=True)
+	assert plan["ladder"] and plan["n_stages"] == 1 and not plan_s["ladder"] and plan_s["n_stages"] >= 2
+	for _ in range(3):   # (a dependence on the timing of the counts would come and go)
+		a = ops.score_topk_fused(Xp, Etp, I, k)
+		torch.cuda.synchronize()
+		b = ops.score_topk_fused(Xp, Etp, I, k, staged=True)
+		torch.cuda.synchronize()
+		assert torch.equal(a.values, b.values) and torch.equal(a.indices, b.indices), kind
+	S = X.double() @ E.double()
+	order = torch.argsort(S, dim=1, descending=True, stable=True)[:, :k]
+	if kind in ("integer_ties", "flat"):    # exactly representable: THE top-k under the defined order
+		assert torch.equal(a.indices.cpu().long(), order) and torch.equal(a.values.cpu().double(), torch.gather(S, 1, order))
+	else:
+		rv = torch.gather(S, 1, order)
+		assert (a.values.cpu().double() - rv).abs().max() <= 1e-4 * float(S.abs().max())
+		assert (torch.gather(S, 1, a.indices.cpu().long()) - a.values.cpu().double()).abs().max() <= 1e-4 * float(S.abs().max())
+	if kind == "bench_like":   # ... and it does what it is for: fewer candidates kept than the staged sweep keeps
+		from anncur_amd import _lib
+		ws = ops._Workspace.get(_lib.load().anncur_score_topk_workspace_bytes(Q, I, Kp, k), Xp.device)
+		ops.score_topk_fused(Xp, Etp, I, k); n_lad = ops.fused_survivors(ws, Q, I, Kp, k)
+		ops.score_topk_fused(Xp, Etp, I, k, staged=True); n_stg = ops.fused_survivors(ws, Q, I, Kp, k, staged=True)
+		assert k <= n_lad < n_stg, (n_lad, n_stg)
+
+
 def test_error_kernels_with_a_row_pitch_beyond_the_32_bit_tile_offsets(ops):
 	"""error_lds_kernel / evalf_kernel address their tile of the exact matrix as a uniform base + a 32-bit byte offset (row within the row
 	block x pitch x 2); from a pitch of 8 421 504 elements on, row 255's offset wraps and the DMA would read the wrong rows -- silently.  The routes

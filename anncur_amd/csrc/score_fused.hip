@@ -1743,8 +1743,13 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	const bool can16 = KP <= 256 && P.QT == 2 && I < (int64_t)(1 << 26);
 	// (default up to k = 384 since late round 4: same process, warm, round robin at cfg2 size -- k = 150: 0.733 vs 0.738 ms for the 32x32x16 body,
 	//  200: 0.779 vs 0.827, 256: 0.829 vs 0.878, 300: 0.909 vs 0.942, 384: 0.951 vs 0.968; level from 500 on: 1.04 / 1.04, 1000: 1.50 / 1.50)
-	constexpr int BODY16_MAX_K = 384;
-	P.body16 = can16 && !mfma32 && !evalf && (mfma16 || k <= BODY16_MAX_K);
+	// Round 5: with the in-flight threshold ladder (score16.hpp; needs the wave-level threshold kernel, i.e. <= 4096 group maxima: k <= 1024) the
+	// 16x16x32 body wins up to k = 1024 -- one process, alternating, cfg2 size: k = 500 0.984 ms against 1.055-1.072 for the staged 32x32x16 body
+	// (1970 against 2606 candidates per query, select 0.144 against 0.19), k = 1000 1.38 against 1.53; without the ladder (ANNCUR_TOPK_STAGED) the
+	// round-4 limit stands
+	constexpr int BODY16_MAX_K = 384, BODY16_MAX_K_LADDER = 1024;
+	const bool ladder_possible = !no_ladder && ticketed && P.n_groups <= 4096;
+	P.body16 = can16 && !mfma32 && !evalf && (mfma16 || k <= (ladder_possible ? BODY16_MAX_K_LADDER : BODY16_MAX_K));
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_MFMA16") && !evalf) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
 #endif

@@ -645,7 +645,7 @@ def fused_survivors(workspace, Q, I, Kp, k, leading_sample=False, mfma16=False, 
 
 def fused_plan(Q, I, Kp, k, leading_sample=False, mfma16=False, qt1=False, mfma32=False, ring=False, staged=False):
 	"""The plan a fused call with these flags runs.  "lg": candidate segments per (query, item split) -- 2 = the 32x32x16 body (per-lane
-	rings; the default above k = 384, and for Kp = 512), 1 = the 16x16x32 body (one queue per wave; the default for Kp <= 256, k <= 384),
+	rings; the default above k = 1024 -- above 384 under staged=True --, and for Kp = 512), 1 = the 16x16x32 body (one queue per wave; the default for Kp <= 256, k <= 1024),
 	4 = the wide kernel (Kp > 512); "QT": 32-query sub-tiles per wave (1 = qt1 honoured, or Kp = 512);
 	"stage_pred": body of each sweep stage -- 0 / 1 = 32x32x16 with the ballot / exec-mask filter, 2 = 16x16x32 (4-wave workgroups, barrier per
 	tile), 3 / 4 = Kp = 512 with the wave queue on 32x32x16 / 16x16x32, 5 = 16x16x32 in 8-wave workgroups with the tile ring (ring=True)."""

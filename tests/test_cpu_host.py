@@ -59,14 +59,17 @@ def test_sweep_variant_flags_reach_the_plan():
 	# round 5: the default 16x16x32 body sweeps in ONE launch and raises its thresholds up a ladder of levels in flight (csrc/score16.hpp)
 	assert (base["lg"], base["QT"]) == (1, 2) and base["n_stages"] == len(base["stage_end"]) == 1 and base["stage_end"][-1] == base["n_tiles"]
 	assert base["ladder"] and base["ladder_top_rank"] == 10 and ops.fused_plan(10000, 100000, 256, 100, leading_sample=True)["ladder_top_rank"] == 16
-	assert all(b == 2 for b in base["stage_pred"])                              # k <= 384: the 16x16x32 body
+	assert all(b == 2 for b in base["stage_pred"])                              # the 16x16x32 body (k <= 1024 with the ladder)
 	staged = ops.fused_plan(10000, 100000, 256, 100, staged=True)               # ANNCUR_TOPK_STAGED: rounds 1-4's staged sweep of the same body (A/B, parity reference)
 	assert not staged["ladder"] and staged["n_stages"] == len(staged["stage_end"]) == 2 and all(b == 2 for b in staged["stage_pred"]) and staged["lg"] == 1
 	assert ops._topk_flags(staged=True) == _lib.TOPK_STAGED and not ops.fused_plan(10000, 100000, 256, 100, mfma32=True)["ladder"]
 	assert not ops.fused_plan(6250, 1000000, 512, 100)["ladder"]
 	m32 = ops.fused_plan(10000, 100000, 256, 100, mfma32=True)
 	assert m32["lg"] == 2 and all(b in (0, 1) for b in m32["stage_pred"])
-	assert ops.fused_plan(10000, 100000, 256, 500)["lg"] == 2                   # k > 128: 32x32x16 throughout
+	p500 = ops.fused_plan(10000, 100000, 256, 500)                                # round 5: with the ladder the 16x16x32 body is the default up to k = 1024
+	assert p500["lg"] == 1 and p500["ladder"] and p500["n_stages"] == 1 and ops.fused_plan(10000, 100000, 256, 1000)["ladder"]
+	assert ops.fused_plan(10000, 100000, 256, 500, staged=True)["lg"] == 2      # without it (ANNCUR_TOPK_STAGED) round 4's limit stands: 32x32x16 above k = 384
+	assert ops.fused_plan(10000, 100000, 256, 300, staged=True)["lg"] == 1 and ops.fused_plan(10000, 100000, 256, 1100)["lg"] == 2   # (k > 1024: > 4096 group maxima, no ladder)
 	assert all(b == 2 for b in ops.fused_plan(10000, 100000, 256, 100, mfma16=True)["stage_pred"])
 	assert ops.fused_plan(10000, 100000, 256, 100, mfma16=True)["lg"] == 1
 	assert ops.fused_plan(300, 40000, 64, 10, mfma16=True)["lg"] == 1

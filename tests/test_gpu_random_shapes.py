@@ -115,7 +115,7 @@ def test_fused_score_topk_random(ops, Q, I, K, k, rank, noise, seed, variant):
 	plan = ops.fused_plan(Q, I, Kp, k, **kw)
 	if variant == "ring":   # (round 4) the tile-ring body runs where the 16x16x32 body would: Kp = 128 / 256, k <= 128
 		assert all(b == 5 for b in plan["stage_pred"]) == (Kp in (128, 256) and k <= 128), plan
-	elif Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = 16x16x32 up to k = 384)
+	elif Kp <= 256:   # the variant the draw names is the kernel that runs (Kp = 512 has one body; qt1 needs Kp >= 128; "" = 16x16x32 up to k = 1024 with the ladder, up to 384 staged)
 		want_lg = {"mfma16": (1,), "mfma32": (2,), "qt1": (2,) if Kp >= 128 else (1, 2), "": (1, 2), "staged": (1, 2)}[variant]   # (qt1 at Kp = 64: no such body, the default runs)
 		assert plan["lg"] in want_lg and plan["QT"] == (1 if variant == "qt1" and Kp >= 128 else 2), (variant, plan)
 	if variant == "staged": assert not plan["ladder"]

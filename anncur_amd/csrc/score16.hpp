@@ -241,6 +241,15 @@ __global__ __launch_bounds__(64 * NW, 2) void score16_kernel(const FusedParams p
 	unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
 	asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_entry)::"memory");
 #endif
+	// static priority (experiment, round 5): the two workgroups of a CU share each SIMD's matrix pipe; at equal priority their waves fall into
+	// step -- both in the MFMA section (each at half rate), then both in the tile's ~600 cycles of DMA issue / checks / barrier with the pipe idle.
+	// One of the two at a higher priority runs its MFMA section at full rate and does its bookkeeping while the other has the pipe.
+#ifdef ANNCUR_TIMING_EXPERIMENTS   // measured NULL (ANNCUR_DEBUG_PRIO = 1 / 2 / 3, by dispatch half or by parity: sweep 0.4511-0.4543 ms against 0.4517-0.4542 without; profiles/r05_static_priority_null.txt)
+	if (p.prio_mode) {   // (uniform)
+		const int sel = (p.prio_mode & 4) ? (int)(blockIdx.x & 1u) : (int)((blockIdx.x >> 8) & 1u);   // which co-resident workgroup: blocks b and b + 256 share a CU under round-robin dispatch (speed only)
+		if (sel) { if ((p.prio_mode & 3) == 1) __builtin_amdgcn_s_setprio(1); else if ((p.prio_mode & 3) == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+	}
+#endif
 	const int wid = xcd_remap(blockIdx.x, p.n_wg);
 	const int n_rb = (int)((p.Q + C::BQ - 1) / C::BQ);
 	// work id -> (row block, split): split-major (p.rb_major = 1, row-block-major, is an experiments knob: measured worse, see launch_fused)

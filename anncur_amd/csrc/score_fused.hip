@@ -111,6 +111,7 @@ struct FusedParams {
 	int sliced, chunks_per_slice;     // XCD-sliced tickets: chunk_ctr is [row block][N_SLICES], slice s = chunks [s * chunks_per_slice, + chunks_per_slice)
 	// threshold ladder of score16_kernel (score16.hpp): levels [n_rb x BQ][LADDER_LEVELS], counter words [n_rb x BQ][4] (zero at launch),
 	// the cell each wave raises to the threshold it ended with (initialised to tau0 by the threshold kernel), k
+	int prio_mode;                    // static wave priority of the sweep's workgroups (score16_kernel): see launch_fused
 	int ladder_on; uint32_t ladder_k, ladder_mask;   // ladder_mask = period - 1 (a power of two): tiles between two fetches of a wave's counter words
 	const float *ladder; uint32_t *ladder_cnt; float *tau_final;
 	uint32_t *nfb;                    // the call's fallback counter (workspace word 0): the ring kernel reports a spin timeout there
@@ -2064,6 +2065,10 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	if (const char *dbg = getenv("ANNCUR_DEBUG_RING_SLEEP")) p.ring_spin_sleep = atoi(dbg);
 #endif
 	p.nseg = P.lg * P.S;
+	p.prio_mode = 0;
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+	if (const char *dbg = getenv("ANNCUR_DEBUG_PRIO")) p.prio_mode = atoi(dbg);
+#endif
 	p.ladder_on = P.ladder ? 1 : 0; p.ladder_k = (uint32_t)k; p.ladder_mask = (uint32_t)(LADDER_PERIOD - 1);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_LADDER_PERIOD")) { int v = atoi(dbg); if (v >= 1 && (v & (v - 1)) == 0) p.ladder_mask = (uint32_t)(v - 1); }

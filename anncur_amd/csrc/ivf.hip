@@ -334,6 +334,392 @@ __global__ __launch_bounds__(256) void ivf_map_ids_kernel(const int32_t *__restr
 	out[i] = id;
 }
 
+
+// ================================================================================================================================
+// Round 5: the batched search as ONE call (anncur_ivf_search_grouped) -- packed score rows, a pair sort without passes per list, a
+// 128 x 128-tile bf16 GEMM.  What the round-4 pipeline spent per 10^4 queries on 10^5 x 768 vectors (rocprofv3, 1.08 ms in all): pair sort
+// 0.25 ms (one workgroup PER LIST passing over all pairs, twice), -inf fill of S 0.095, GEMM 0.33, scan of S 0.145 -- S is [nq x nprobe x
+// lmax] there and three quarters of it padding (lists of 1..1026 vectors, 5 400 scanned per query of 17 442 columns).
+//   packed rows: query q's row of S holds its probed lists back to back (coff[q, slot] = vectors in its earlier slots), row_len[q] scores
+//     in all; nothing is pre-filled (rows shorter than k get -inf up to k) and the scan reads row_len[q] columns (anncur_rowwise_topk_ragged);
+//   pair sort: LDS histograms per 256 queries + one global atomic per (workgroup, list present) for the counts, the same again for the
+//     positions.  The order of a list's pairs depends on the atomics' timing; a pair's scores do not depend on its position;
+//   tiles: tile_start over (list, 128-pair tile, 128-vector tile) for bf16 (64 x 64 for fp32), workgroup b takes tile xcd_remap(b, n_tiles):
+//     the tiles of a list run on ONE XCD around the same time and share the list's vectors and its pairs' queries in that L2 (round 4:
+//     consecutive tiles on eight XCDs, every operand tile from beyond L2 -- 2.7 GB per search).
+constexpr int IVF_MAX_NLIST_LDS = 8192;   // 2 x nlist words of LDS in the sort kernels
+constexpr int IVF_RAGGED_MAX_K = 128;    // anncur_rowwise_topk_ragged: the wave-per-row scan (WSEL_K of wave_select.hpp)
+
+__device__ __forceinline__ int ivf_xcd_remap(int b, int n) {   // work ids of one XCD contiguous (blocks b and b + 8 share an XCD); a bijection on [0, n)
+	const int q = n >> 3, r = n & 7, x = b & 7, l = b >> 3;
+	return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+// coff / row_len / short-row padding and the pairs-per-list counts (counts zeroed by the caller).  One thread per query.
+__global__ __launch_bounds__(256) void ivf_layout_kernel(const int32_t *__restrict__ probe, int64_t nq, int32_t nprobe, const int32_t *__restrict__ offsets,
+														  int32_t nlist, int32_t k, int64_t pitch, uint32_t *__restrict__ coff, int32_t *__restrict__ row_len,
+														  int32_t *__restrict__ counts, float *__restrict__ S) {
+	extern __shared__ uint32_t ivf_hist[];
+	for (int i = threadIdx.x; i < nlist; i += 256) ivf_hist[i] = 0u;
+	__syncthreads();
+	const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (q < nq) {
+		uint32_t run = 0;
+		for (int s = 0; s < nprobe; ++s) {
+			const int32_t l = probe[q * nprobe + s];
+			coff[q * nprobe + s] = run;
+			if (l >= 0 && l < nlist) {
+				run += (uint32_t)(offsets[l + 1] - offsets[l]);
+				atomicAdd(&ivf_hist[l], 1u);
+			}
+		}
+		for (uint32_t c = run; c < (uint32_t)k; ++c) S[q * pitch + c] = -INFINITY;   // fewer than k vectors in the probed lists
+		row_len[q] = (int32_t)(run > (uint32_t)k ? run : (uint32_t)k);
+	}
+	__syncthreads();
+	for (int i = threadIdx.x; i < nlist; i += 256)
+		if (ivf_hist[i] != 0u) atomicAdd(&counts[i], (int32_t)ivf_hist[i]);
+}
+
+// pair_off = exclusive prefix of the pair counts (+ a copy as the scatter's cursors) and tile_start = exclusive prefix of the lists' tile
+// counts, tile = T pairs x T vectors.  One workgroup.
+__global__ __launch_bounds__(256) void ivf_pair_offsets_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ offsets, int32_t nlist, int32_t T,
+																int32_t *__restrict__ pair_off, int32_t *__restrict__ cursor, int32_t *__restrict__ tile_start) {
+	__shared__ int32_t carry[2];
+	__shared__ int32_t wsum[2][4];
+	if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+	__syncthreads();
+	for (int32_t b = 0; b < nlist; b += 256) {
+		const int32_t l = b + threadIdx.x;
+		int32_t c0 = 0, c1 = 0;
+		if (l < nlist) {
+			c0 = counts[l];
+			c1 = ((c0 + T - 1) / T) * ((offsets[l + 1] - offsets[l] + T - 1) / T);
+		}
+		int32_t i0 = c0, i1 = c1;
+		for (int d = 1; d < WAVE; d <<= 1) {
+			const int32_t t0 = __shfl_up(i0, d), t1 = __shfl_up(i1, d);
+			if (lane_id() >= d) { i0 += t0; i1 += t1; }
+		}
+		if (lane_id() == WAVE - 1) { wsum[0][threadIdx.x >> 6] = i0; wsum[1][threadIdx.x >> 6] = i1; }
+		__syncthreads();
+		int32_t b0 = carry[0], b1 = carry[1];
+		for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) { b0 += wsum[0][w]; b1 += wsum[1][w]; }
+		if (l < nlist) { pair_off[l] = b0 + i0 - c0; cursor[l] = b0 + i0 - c0; tile_start[l] = b1 + i1 - c1; }
+		__syncthreads();
+		if (threadIdx.x == 255) { carry[0] = b0 + i0; carry[1] = b1 + i1; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { pair_off[nlist] = carry[0]; tile_start[nlist] = carry[1]; }
+}
+
+// pairs -> their lists' ranges: pair_q[pos] = query row, pair_out[pos] = element offset of the pair's scores in S (q * pitch + coff).
+__global__ __launch_bounds__(256) void ivf_scatter_kernel(const int32_t *__restrict__ probe, int64_t nq, int32_t nprobe, int32_t nlist, int64_t pitch,
+														   const uint32_t *__restrict__ coff, int32_t *__restrict__ cursor, int32_t *__restrict__ pair_q,
+														   uint32_t *__restrict__ pair_out) {
+	extern __shared__ uint32_t ivf_hist[];
+	uint32_t *base = ivf_hist + nlist;
+	for (int i = threadIdx.x; i < nlist; i += 256) ivf_hist[i] = 0u;
+	__syncthreads();
+	const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (q < nq)
+		for (int s = 0; s < nprobe; ++s) {
+			const int32_t l = probe[q * nprobe + s];
+			if (l >= 0 && l < nlist) atomicAdd(&ivf_hist[l], 1u);
+		}
+	__syncthreads();
+	for (int i = threadIdx.x; i < nlist; i += 256) {
+		const uint32_t c = ivf_hist[i];
+		base[i] = c != 0u ? (uint32_t)atomicAdd(&cursor[i], (int32_t)c) : 0u;
+		ivf_hist[i] = 0u;
+	}
+	__syncthreads();
+	if (q < nq)
+		for (int s = 0; s < nprobe; ++s) {
+			const int32_t l = probe[q * nprobe + s];
+			if (l >= 0 && l < nlist) {
+				const uint32_t pos = base[l] + atomicAdd(&ivf_hist[l], 1u);
+				pair_q[pos] = (int32_t)q;
+				pair_out[pos] = (uint32_t)(q * pitch) + coff[q * nprobe + s];
+			}
+		}
+}
+
+// work id -> (list, pair tile, vector tile): every thread looks at its lists' tile ranges (one round trip; non-empty ranges are disjoint)
+__device__ __forceinline__ void ivf_find_tile(const int32_t *__restrict__ tile_start, int32_t nlist, const int32_t *__restrict__ offsets, int32_t T, int32_t wid,
+											   int32_t *meta, int32_t &l, int32_t &qt, int32_t &vt) {
+	for (int32_t i = threadIdx.x; i < nlist; i += 256) {
+		const int32_t ts = tile_start[i], te = tile_start[i + 1];
+		if (ts <= wid && wid < te) { meta[0] = i; meta[1] = ts; }
+	}
+	__syncthreads();
+	l = __builtin_amdgcn_readfirstlane(meta[0]);   // (what depends on the tile stays in scalar registers: the DMA's source bases are SGPR pairs)
+	const int32_t vcnt = (offsets[l + 1] - offsets[l] + T - 1) / T, within = wid - __builtin_amdgcn_readfirstlane(meta[1]);
+	qt = within / vcnt; vt = within - qt * vcnt;
+}
+
+// The round-3/4 tile kernels (64 x 64; fp32 lists, and bf16 rows whose length is not a multiple of 64) on the packed layout.
+template <typename T>
+__global__ __launch_bounds__(256) void ivf_tile64_packed_kernel(const T *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
+																 const T *__restrict__ Q, int64_t ldq, const int32_t *__restrict__ pair_q,
+																 const uint32_t *__restrict__ pair_out, const int32_t *__restrict__ pair_off,
+																 const int32_t *__restrict__ tile_start, int32_t nlist, float *__restrict__ S) {
+	constexpr bool F32 = sizeof(T) == 4;
+	__shared__ __attribute__((aligned(16))) unsigned char tiles_lds[F32 ? 2 * GK * GP * 4 : 2 * GT * 64];
+	__shared__ int32_t arow[GT];
+	__shared__ uint32_t orow[GT];
+	__shared__ int32_t meta[2];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+	const int32_t n_tiles = tile_start[nlist];
+	if ((int32_t)blockIdx.x >= n_tiles) return;   // (uniform: before any barrier)
+	int32_t l, qt, vt;
+	ivf_find_tile(tile_start, nlist, offsets, GT, ivf_xcd_remap((int)blockIdx.x, n_tiles), meta, l, qt, vt);
+	const int32_t p0 = pair_off[l] + qt * GT, p_end = pair_off[l + 1];
+	const int32_t v0 = offsets[l] + vt * GT, v_end = offsets[l + 1];
+	if (tid < GT) {
+		const bool in = p0 + tid < p_end;
+		arow[tid] = in ? pair_q[p0 + tid] : -1;
+		orow[tid] = in ? pair_out[p0 + tid] : 0u;
+	}
+	__syncthreads();
+	f32x16g acc;
+#pragma unroll
+	for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+	if constexpr (F32) {
+		float *As = reinterpret_cast<float *>(tiles_lds), *Bs = As + GK * GP;
+		const int kk = tid & 15, mm = tid >> 4;
+		float ra[4], rb[4];
+		auto load = [&](int k0) {
+#pragma unroll
+			for (int p = 0; p < 4; ++p) {
+				const int m = mm + 16 * p;
+				const int32_t qr = arow[m];
+				ra[p] = (qr >= 0 && k0 + kk < dp) ? Q[(int64_t)qr * ldq + k0 + kk] : 0.f;
+				rb[p] = (v0 + m < v_end && k0 + kk < dp) ? Xs[(int64_t)(v0 + m) * ldx + k0 + kk] : 0.f;
+			}
+		};
+		load(0);
+		for (int k0 = 0; k0 < dp; k0 += GK) {
+#pragma unroll
+			for (int p = 0; p < 4; ++p) { As[kk * GP + mm + 16 * p] = ra[p]; Bs[kk * GP + mm + 16 * p] = rb[p]; }
+			__syncthreads();
+			if (k0 + GK < dp) load(k0 + GK);
+#pragma unroll
+			for (int ks = 0; ks < GK / 2; ++ks)
+				acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(2 * ks + h) * GP + wm * 32 + r], Bs[(2 * ks + h) * GP + wn * 32 + r], acc, 0, 0, 0);
+			__syncthreads();
+		}
+	} else {
+		u32x4g *As = reinterpret_cast<u32x4g *>(tiles_lds), *Bs = As + GT * 4;
+		const int row = tid >> 2, ch = tid & 3;
+		const int slot = row * 4 + (ch ^ ((row >> 2) & 3));
+		const int32_t qr = arow[row];
+		const uint16_t *ap = qr >= 0 ? reinterpret_cast<const uint16_t *>(Q) + (int64_t)qr * ldq + ch * 8 : nullptr;
+		const uint16_t *bp = v0 + row < v_end ? reinterpret_cast<const uint16_t *>(Xs) + (int64_t)(v0 + row) * ldx + ch * 8 : nullptr;
+		const u32x4g zero = {0u, 0u, 0u, 0u};
+		u32x4g ra, rb;
+		auto load = [&](int k0) {
+			const bool in = k0 + ch * 8 < dp;
+			ra = (ap && in) ? *reinterpret_cast<const u32x4g *>(ap + k0) : zero;
+			rb = (bp && in) ? *reinterpret_cast<const u32x4g *>(bp + k0) : zero;
+		};
+		load(0);
+		for (int k0 = 0; k0 < dp; k0 += 32) {
+			As[slot] = ra; Bs[slot] = rb;
+			__syncthreads();
+			if (k0 + 32 < dp) load(k0 + 32);
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks) {
+				const int ra_row = wm * 32 + r, rb_row = wn * 32 + r, c = 2 * ks + h;
+				const bf16x8g a = __builtin_bit_cast(bf16x8g, As[ra_row * 4 + (c ^ ((ra_row >> 2) & 3))]);
+				const bf16x8g b = __builtin_bit_cast(bf16x8g, Bs[rb_row * 4 + (c ^ ((rb_row >> 2) & 3))]);
+				acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+			}
+			__syncthreads();
+		}
+	}
+	// C/D layout: col = lane & 31 (vector), row = (e & 3) + 8 (e >> 2) + 4 h (pair)
+#pragma unroll
+	for (int e = 0; e < 16; ++e) {
+		const int m = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, n = wn * 32 + r;
+		if (p0 + m < p_end && v0 + n < v_end) S[(int64_t)orow[m] + (vt * GT + n)] = acc[e];
+	}
+}
+
+// ---- bf16, 128 pairs x 128 vectors per workgroup (round 5).  Four waves, wave (wm, wn) owns pairs [64 wm, +64) x vectors [64 wn, +64): 2 x 2
+// accumulators of v_mfma_f32_32x32x16_bf16; d streamed in 64-wide k-tiles through two 32 KiB LDS stages (pairs' query rows 16 KiB + vectors
+// 16 KiB) filled by global_load_lds_dwordx4 -- the query rows gathered by the per-lane source address --, one barrier per k-tile, fragment
+// reads as inline asm with counted waits (the scheme of score_wide.hpp; the LDS image and its swizzle are that kernel's: row-major 128-byte
+// rows, 16-byte chunk index XOR (row >> 1) & 7 on the DMA's source address and again at the reads).  Two workgroups per CU.
+// Rows: dp a multiple of 64, 16-byte aligned; nq * ldq * 2 < 2^32 (32-bit source offsets behind a uniform base).
+constexpr int T128 = 128;
+constexpr int T128_TILE_BYTES = 128 * 128, T128_STAGE_BYTES = 2 * T128_TILE_BYTES, T128_LDS_BYTES = 2 * T128_STAGE_BYTES, T128_LDS_TOTAL = T128_LDS_BYTES + 2 * T128 * 4 + 16;
+struct T128Frag { u32x4g a[2], b[2]; };
+__device__ __forceinline__ void t128_read(u32x4g &dst, uint32_t addr, int off) {   // `off` folds to an immediate after unrolling
+#if defined(__HIP_DEVICE_COMPILE__)
+	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+#endif
+}
+__global__ __launch_bounds__(256, 2) void ivf_tile128_kernel(const uint16_t *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
+															  const uint16_t *__restrict__ Q, int64_t ldq, const int32_t *__restrict__ pair_q,
+															  const uint32_t *__restrict__ pair_out, const int32_t *__restrict__ pair_off,
+															  const int32_t *__restrict__ tile_start, int32_t nlist, float *__restrict__ S) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char t128_smem[];   // the two stages at offset 0, then the tile's rows
+	int32_t *arow = reinterpret_cast<int32_t *>(t128_smem + T128_LDS_BYTES);
+	uint32_t *orow = reinterpret_cast<uint32_t *>(arow + T128);
+	int32_t *meta = reinterpret_cast<int32_t *>(orow + T128);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+	const int32_t n_tiles = tile_start[nlist];
+	if ((int32_t)blockIdx.x >= n_tiles) return;   // (uniform: before any barrier)
+	int32_t l, qt, vt;
+	ivf_find_tile(tile_start, nlist, offsets, T128, ivf_xcd_remap((int)blockIdx.x, n_tiles), meta, l, qt, vt);
+	const int32_t p0 = pair_off[l] + qt * T128, p_rows = min(T128, pair_off[l + 1] - p0);
+	const int32_t v0 = offsets[l] + vt * T128, v_rows = min(T128, offsets[l + 1] - v0);
+	if (tid < T128) {   // rows past the tile's pairs re-read its last pair's query (their scores are not stored)
+		const int32_t p = p0 + min(tid, p_rows - 1);
+		arow[tid] = pair_q[p];
+		orow[tid] = pair_out[p];
+	}
+	__syncthreads();
+
+	// ---- DMA sources: piece (wave * 4 + i) = tile rows 8 (wave * 4 + i) .. + 8, this lane: row + (lane >> 3), chunk lane & 7
+	const unsigned char *abase = reinterpret_cast<const unsigned char *>(Q);
+	const unsigned char *bbase = reinterpret_cast<const unsigned char *>(Xs) + (int64_t)v0 * ldx * 2;
+	uint32_t aoff[4], boff[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int prow = (wave * 4 + i) * 8 + (lane >> 3), pchunk = (lane & 7) ^ ((prow >> 1) & 7);
+		aoff[i] = (uint32_t)arow[prow] * (uint32_t)(ldq * 2) + (uint32_t)pchunk * 16u;
+		boff[i] = (uint32_t)min(prow, v_rows - 1) * (uint32_t)(ldx * 2) + (uint32_t)pchunk * 16u;
+	}
+	const int x = (r >> 1) & 7;
+	const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)t128_smem;
+	uint32_t fa[2][4], fb[2][4];
+#pragma unroll
+	for (int s = 0; s < 4; ++s) {
+		const uint32_t co = (uint32_t)(((2 * s + h) ^ x) * 16);
+		fa[0][s] = lds0 + (uint32_t)(wm * 64 + r) * 128u + co;
+		fb[0][s] = lds0 + (uint32_t)T128_TILE_BYTES + (uint32_t)(wn * 64 + r) * 128u + co;
+		fa[1][s] = fa[0][s] + (uint32_t)T128_STAGE_BYTES;
+		fb[1][s] = fb[0][s] + (uint32_t)T128_STAGE_BYTES;
+	}
+	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+	const uint32_t lds0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds0);
+	f32x16g acc[2][2];
+#pragma unroll
+	for (int m = 0; m < 2; ++m)
+#pragma unroll
+		for (int t = 0; t < 2; ++t)
+#pragma unroll
+			for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
+
+#define T128_PIECE(BASE, OFF, TILE_OFF, i)                                                                        \
+	do {                                                                                                          \
+		const uint32_t m0v_ = lds0_u + (uint32_t)(TILE_OFF) + (uint32_t)(wave_u * 4 + (i)) * 1024u;               \
+		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v_), "v"((OFF)[i]), "s"(BASE) : "memory", "m0"); \
+	} while (0)
+#define T128_DMA2(s)                                                                                              \
+	do {                                                                                                          \
+		if (den) {                                                                                                \
+			if ((s) < 2) { T128_PIECE(da, aoff, dd, 2 * ((s) & 1)); T128_PIECE(da, aoff, dd, 2 * ((s) & 1) + 1); } \
+			else { T128_PIECE(db, boff, dd + T128_TILE_BYTES, 2 * ((s) & 1)); T128_PIECE(db, boff, dd + T128_TILE_BYTES, 2 * ((s) & 1) + 1); } \
+		}                                                                                                         \
+	} while (0)
+#define T128_LOAD(F, STAGE, s)                                                                                    \
+	do {                                                                                                          \
+		_Pragma("unroll") for (int m = 0; m < 2; ++m) t128_read(F.a[m], fa[STAGE][s], m * 4096);                  \
+		_Pragma("unroll") for (int t = 0; t < 2; ++t) t128_read(F.b[t], fb[STAGE][s], t * 4096);                  \
+	} while (0)
+#define T128_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.b[0]), "+v"(F.b[1]) : "n"(N))
+#define T128_MFMA(F)                                                                                              \
+	do {                                                                                                          \
+		_Pragma("unroll") for (int m = 0; m < 2; ++m)                                                             \
+			_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
+				acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, F.a[m]), __builtin_bit_cast(bf16x8g, F.b[t]), acc[m][t], 0, 0, 0); \
+	} while (0)
+#define T128_SYNC()                                                                                               \
+	do {                                                                                                          \
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+		__builtin_amdgcn_s_barrier();                                                                             \
+		asm volatile("" ::: "memory");                                                                            \
+	} while (0)
+#define T128_COMPUTE(STAGE)                                                                                       \
+	do {                                                                                                          \
+		T128Frag f0, f1;                                                                                          \
+		T128_LOAD(f0, STAGE, 0);                                                                                  \
+		T128_LOAD(f1, STAGE, 1); T128_DMA2(0); T128_WAIT(f0, 4); T128_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
+		T128_LOAD(f0, STAGE, 2); T128_DMA2(1); T128_WAIT(f1, 4); T128_MFMA(f1); __builtin_amdgcn_sched_barrier(0); \
+		T128_LOAD(f1, STAGE, 3); T128_DMA2(2); T128_WAIT(f0, 4); T128_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
+		T128_DMA2(3); T128_WAIT(f1, 0); T128_MFMA(f1);                                                            \
+	} while (0)
+
+	const int nk = dp >> 6;
+	{   // k-tile 0 -> stage 0
+		const unsigned char *da = abase, *db = bbase;
+		const uint32_t dd = 0u;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { T128_PIECE(da, aoff, dd, i); T128_PIECE(db, boff, dd + T128_TILE_BYTES, i); }
+	}
+	T128_SYNC();
+	for (int kt = 0; kt < nk; kt += 2) {
+		{   // stage 0 holds k-tile kt: fetch kt + 1 into stage 1 while it is consumed
+			const unsigned char *da = abase + (kt + 1) * 128, *db = bbase + (kt + 1) * 128;
+			const uint32_t dd = (uint32_t)T128_STAGE_BYTES;
+			const bool den = kt + 1 < nk;
+			T128_COMPUTE(0);
+			T128_SYNC();
+		}
+		if (kt + 1 < nk) {   // (uniform) stage 1 holds k-tile kt + 1: fetch kt + 2 into stage 0
+			const unsigned char *da = abase + (kt + 2) * 128, *db = bbase + (kt + 2) * 128;
+			const uint32_t dd = 0u;
+			const bool den = kt + 2 < nk;
+			T128_COMPUTE(1);
+			T128_SYNC();
+		}
+	}
+#undef T128_COMPUTE
+#undef T128_SYNC
+#undef T128_MFMA
+#undef T128_WAIT
+#undef T128_LOAD
+#undef T128_DMA2
+#undef T128_PIECE
+	// C/D layout: col = lane & 31 (vector), row = (e & 3) + 8 (e >> 2) + 4 h (pair) within the 32 x 32 block (m, t) of the wave's tile
+	const int32_t c0 = vt * T128;
+#pragma unroll
+	for (int m = 0; m < 2; ++m)
+#pragma unroll
+		for (int t = 0; t < 2; ++t) {
+			const int n = wn * 64 + t * 32 + r;
+#pragma unroll
+			for (int e = 0; e < 16; ++e) {
+				const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+				if (row < p_rows && n < v_rows) S[(int64_t)orow[row] + (c0 + n)] = acc[m][t][e];
+			}
+		}
+}
+
+// column of a packed score row -> id of the vector (-1 where the score is the -inf padding of a short row)
+__global__ __launch_bounds__(256) void ivf_map_ids_packed_kernel(const int32_t *__restrict__ col, const float *__restrict__ val, int64_t n, int32_t k,
+																  const int32_t *__restrict__ probe, int32_t nprobe, const uint32_t *__restrict__ coff,
+																  const int32_t *__restrict__ offsets, int32_t nlist, const int32_t *__restrict__ ids,
+																  int32_t *__restrict__ out) {
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const int32_t c = col[i];
+	int32_t id = -1;
+	if (c >= 0 && val[i] > -INFINITY) {
+		const int64_t q = i / k;
+		for (int s = 0; s < nprobe; ++s) {
+			const int32_t l = probe[q * nprobe + s];
+			if (l < 0 || l >= nlist) continue;
+			const uint32_t co = coff[q * nprobe + s], sz = (uint32_t)(offsets[l + 1] - offsets[l]);
+			if ((uint32_t)c >= co && (uint32_t)c < co + sz) { id = ids[offsets[l] + (int32_t)((uint32_t)c - co)]; break; }
+		}
+	}
+	out[i] = id;
+}
+
 }  // namespace
 
 extern "C" int anncur_ivf_group_scores(const float *Xs, int64_t ldx, int32_t dp, const int32_t *offsets, const float *Q, int64_t ldq, int32_t nprobe,
@@ -380,6 +766,78 @@ extern "C" int anncur_ivf_group_scores_dev(const void *Xs, int dtype, int64_t ld
 	else
 		hipLaunchKernelGGL(ivf_group_scores_bf16_kernel, dim3((unsigned)max_tiles), dim3(256), 0, st, (const uint16_t *)Xs, ldx, dp, offsets, (const uint16_t *)Q, ldq,
 						   nprobe, pair_ids, pair_offsets, tile_start, nlist, lmax, S);
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+// ---- round 5: the whole batched search behind one call (see the kernels above)
+struct IvfSearchWs { size_t counts, pair_off, cursor, tile_start, coff, row_len, pair_q, pair_out, col, total; };
+static IvfSearchWs ivf_search_ws(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k) {
+	IvfSearchWs w;
+	size_t o = 0;
+	auto take = [&](size_t words) { const size_t at = o; o += (words * 4 + 255) & ~(size_t)255; return at; };
+	w.counts = take((size_t)nlist); w.pair_off = take((size_t)nlist + 1); w.cursor = take((size_t)nlist); w.tile_start = take((size_t)nlist + 1);
+	w.coff = take((size_t)nq * nprobe); w.row_len = take((size_t)nq); w.pair_q = take((size_t)nq * nprobe); w.pair_out = take((size_t)nq * nprobe);
+	w.col = take((size_t)nq * k);
+	w.total = o;
+	return w;
+}
+static bool ivf_use_tile128(int dtype, int32_t dp, int64_t ldx, int64_t ldq, int64_t nq) {
+	return dtype == ANNCUR_BF16 && (dp % 64) == 0 && nq * ldq * 2 < ((int64_t)1 << 32) && 128 * ldx * 2 < ((int64_t)1 << 32);
+}
+extern "C" int32_t anncur_ivf_search_tile(int dtype, int32_t dp, int64_t ldx, int64_t ldq, int64_t nq) { return ivf_use_tile128(dtype, dp, ldx, ldq, nq) ? T128 : GT; }
+extern "C" size_t anncur_ivf_search_workspace_bytes(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k) {
+	if (nq < 0 || nprobe < 1 || nlist < 1 || k < 1) return 0;
+	return ivf_search_ws(nq, nprobe, nlist, k).total;
+}
+extern "C" int anncur_ivf_search_grouped(const void *Xs, int dtype, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, int32_t nlist,
+										 const void *Q, int64_t ldq, int64_t nq, const int32_t *probe, int32_t nprobe, int32_t k, int64_t max_tiles,
+										 float *S, int64_t pitch, void *workspace, size_t workspace_bytes, float *out_val, int32_t *out_idx, void *stream) {
+	ANNCUR_REQUIRE(dtype_ok(dtype) && dp >= 1 && ldx >= dp && ldq >= dp && nprobe >= 1 && nlist >= 1 && nq >= 0 && max_tiles >= 0 && max_tiles < (int64_t)0x7fffffff,
+				   ANNCUR_E_INVALID, "ivf_search_grouped: bad sizes");
+	ANNCUR_REQUIRE(dtype == ANNCUR_F32 || ((dp % 16) == 0 && (ldx % 8) == 0 && (ldq % 8) == 0 && ((uintptr_t)Xs % 16) == 0 && ((uintptr_t)Q % 16) == 0), ANNCUR_E_INVALID,
+				   "ivf_search_grouped: bf16 rows must be zero-padded to a multiple of 16 elements and 16-byte aligned");
+	ANNCUR_REQUIRE(k >= 1 && pitch >= k && (pitch % 4) == 0 && nq * pitch < ((int64_t)1 << 32) && nq * (int64_t)nprobe < (int64_t)0x7fffffff, ANNCUR_E_INVALID,
+				   "ivf_search_grouped: need k <= pitch, pitch a multiple of 4, nq * pitch < 2^32 elements (split the queries)");
+	if (k > IVF_RAGGED_MAX_K || nlist > IVF_MAX_NLIST_LDS) {
+		anncur_set_error("ivf_search_grouped: k = %d (<= %d) / nlist = %d (<= %d) outside this path", k, IVF_RAGGED_MAX_K, nlist, IVF_MAX_NLIST_LDS);
+		return ANNCUR_E_UNSUPPORTED;
+	}
+	if (nq == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(Xs && offsets && ids && Q && probe && S && out_val && out_idx && ((uintptr_t)S % 16) == 0, ANNCUR_E_INVALID, "ivf_search_grouped: null or misaligned pointer");
+	const IvfSearchWs w = ivf_search_ws(nq, nprobe, nlist, k);
+	ANNCUR_REQUIRE(workspace && workspace_bytes >= w.total && ((uintptr_t)workspace % 256) == 0, ANNCUR_E_WORKSPACE, "ivf_search_grouped: workspace of %zu bytes needed (256-byte aligned)", w.total);
+	unsigned char *wb = reinterpret_cast<unsigned char *>(workspace);
+	int32_t *counts = reinterpret_cast<int32_t *>(wb + w.counts), *pair_off = reinterpret_cast<int32_t *>(wb + w.pair_off), *cursor = reinterpret_cast<int32_t *>(wb + w.cursor);
+	int32_t *tile_start = reinterpret_cast<int32_t *>(wb + w.tile_start), *row_len = reinterpret_cast<int32_t *>(wb + w.row_len), *pair_q = reinterpret_cast<int32_t *>(wb + w.pair_q);
+	uint32_t *coff = reinterpret_cast<uint32_t *>(wb + w.coff), *pair_out = reinterpret_cast<uint32_t *>(wb + w.pair_out);
+	int32_t *col = reinterpret_cast<int32_t *>(wb + w.col);
+	hipStream_t st = (hipStream_t)stream;
+	const bool t128 = ivf_use_tile128(dtype, dp, ldx, ldq, nq);
+	const unsigned qgrid = (unsigned)ceil_div64(nq, 256);
+	ANNCUR_HIP_OK(hipMemsetAsync(counts, 0, (size_t)nlist * 4, st));
+	hipLaunchKernelGGL(ivf_layout_kernel, dim3(qgrid), dim3(256), (size_t)nlist * 4, st, probe, nq, nprobe, offsets, nlist, k, pitch, coff, row_len, counts, S);
+	hipLaunchKernelGGL(ivf_pair_offsets_kernel, dim3(1), dim3(256), 0, st, counts, offsets, nlist, t128 ? T128 : GT, pair_off, cursor, tile_start);
+	hipLaunchKernelGGL(ivf_scatter_kernel, dim3(qgrid), dim3(256), (size_t)nlist * 8, st, probe, nq, nprobe, nlist, pitch, coff, cursor, pair_q, pair_out);
+	ANNCUR_LAUNCH_OK();
+	if (max_tiles > 0) {
+		if (t128) {
+			const int rc = anncur_ensure_dyn_lds((const void *)ivf_tile128_kernel, T128_LDS_TOTAL);
+			if (rc != ANNCUR_OK) return rc;
+			hipLaunchKernelGGL(ivf_tile128_kernel, dim3((unsigned)max_tiles), dim3(256), T128_LDS_TOTAL, st, (const uint16_t *)Xs, ldx, dp, offsets, (const uint16_t *)Q, ldq,
+							   pair_q, pair_out, pair_off, tile_start, nlist, S);
+		} else if (dtype == ANNCUR_F32)
+			hipLaunchKernelGGL(ivf_tile64_packed_kernel<float>, dim3((unsigned)max_tiles), dim3(256), 0, st, (const float *)Xs, ldx, dp, offsets, (const float *)Q, ldq, pair_q,
+							   pair_out, pair_off, tile_start, nlist, S);
+		else
+			hipLaunchKernelGGL(ivf_tile64_packed_kernel<uint16_t>, dim3((unsigned)max_tiles), dim3(256), 0, st, (const uint16_t *)Xs, ldx, dp, offsets, (const uint16_t *)Q, ldq,
+							   pair_q, pair_out, pair_off, tile_start, nlist, S);
+		ANNCUR_LAUNCH_OK();
+	}
+	const int rc = anncur_rowwise_topk_ragged(S, ANNCUR_F32, nq, pitch, pitch, row_len, k, out_val, col, stream);
+	if (rc != ANNCUR_OK) return rc;
+	const int64_t n = nq * (int64_t)k;
+	hipLaunchKernelGGL(ivf_map_ids_packed_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, col, out_val, n, k, probe, nprobe, coff, offsets, nlist, ids, out_idx);
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

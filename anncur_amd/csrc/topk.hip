@@ -281,16 +281,18 @@ struct ScanGather {
 	void *cq;                // [Q x ldo] of A's element type
 	int64_t ldo;
 };
-template <typename T, bool GATHER = false, bool BUF = true>
-__global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I, int64_t lda, uint32_t k,
+// RAGGED (round 5, the IVF search's packed score rows): row q holds row_len[q] elements (k <= row_len[q] <= I_all, the caller's contract).
+template <typename T, bool GATHER = false, bool BUF = true, bool RAGGED = false>
+__global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I_all, int64_t lda, uint32_t k,
 																 uint32_t trig, float *__restrict__ out_val, int32_t *__restrict__ out_idx,
-																 const ScanGather gt = ScanGather{}) {
+																 const ScanGather gt = ScanGather{}, const int32_t *__restrict__ row_len = nullptr) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// (the wave index through readfirstlane: the compiler then knows the row pointer is wave-uniform and keeps the stream's base address
 	//  in scalar registers -- without it every load of the stream carried 64-bit per-lane address arithmetic)
 	const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
 	if (q >= Q) return;
+	const int64_t I = RAGGED ? (int64_t)__builtin_amdgcn_readfirstlane(row_len[q]) : I_all;
 	// (A start stagger -- the workgroups resident at launch sleeping hashed offsets of up to 8..48 us so that the select phases of a CU's waves
 	//  do not coincide -- was measured in round 4 and dropped: 0.580 -> 0.589..0.621 ms on 96 CUs, 0.330 -> 0.337..0.340 on the chip.  The
 	//  phases are not what holds a part of the chip at 35 GB/s per CU: see DESIGN.md 4.4, 'what bounds the scan on part of the chip'.)
@@ -817,6 +819,33 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 		if (kc == 128) LAUNCH_ROWTOPK(uint16_t, 128); else if (kc == 512) LAUNCH_ROWTOPK(uint16_t, 512); else LAUNCH_ROWTOPK(uint16_t, 2048);
 	}
 #undef LAUNCH_ROWTOPK
+	ANNCUR_LAUNCH_OK();
+	return ANNCUR_OK;
+}
+
+/* Ragged rows (round 5: the IVF search's packed score rows, ivf.hip): anncur_rowwise_topk of a matrix whose row q holds row_len[q]
+ * elements; the wave-per-row scan only (k <= 128). */
+extern "C" int anncur_rowwise_topk_ragged(const void *A, int dtype, int64_t Q, int64_t I_max, int64_t lda, const int32_t *row_len, int32_t k,
+										  float *out_val, int32_t *out_idx, void *stream) {
+	ANNCUR_REQUIRE(dtype_ok(dtype), ANNCUR_E_INVALID, "rowwise_topk_ragged: bad dtype %d", dtype);
+	ANNCUR_REQUIRE(Q >= 0 && Q < (int64_t)0x7fffffff && I_max >= 1 && I_max < (int64_t)0x7fffffff && lda >= I_max, ANNCUR_E_INVALID,
+				   "rowwise_topk_ragged: bad shape Q=%lld I_max=%lld lda=%lld", (long long)Q, (long long)I_max, (long long)lda);
+	ANNCUR_REQUIRE(k >= 1 && k <= I_max, ANNCUR_E_INVALID, "rowwise_topk_ragged: k=%d out of range (1..I_max)", k);
+	if (k > WSEL_K) { anncur_set_error("rowwise_topk_ragged: k = %d above the wave-per-row scan's %d", k, WSEL_K); return ANNCUR_E_UNSUPPORTED; }
+	if (Q == 0) return ANNCUR_OK;
+	ANNCUR_REQUIRE(A && row_len && out_val && out_idx && ((uintptr_t)A % dtype_size(dtype)) == 0, ANNCUR_E_INVALID, "rowwise_topk_ragged: null or misaligned pointer");
+	hipStream_t st = (hipStream_t)stream;
+	const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
+	const unsigned grid = (unsigned)ceil_div64(Q, 4);
+	const uint32_t trig = ws_trigger((uint32_t)k);
+	const bool buf = I_max * (int64_t)dtype_size(dtype) < ((int64_t)1 << 31);
+	if (dtype == ANNCUR_F32) {
+		if (buf) hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, true, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
+		else hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, false, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
+	} else {
+		if (buf) hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, false, true, true>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
+		else hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, false, false, true>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
+	}
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

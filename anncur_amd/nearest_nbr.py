@@ -93,13 +93,16 @@ class IVFFlatIPIndex:
 		self.niter, self.seed, self.max_points_per_centroid = niter, seed, max_points_per_centroid
 		self.nprobe = 1
 		self.batched_from = 256                     # queries per search() call from which the list-grouped MFMA search runs
+		self.grouped_call = True                    # batched search through anncur_ivf_search_grouped (False: round 4's sequence of calls)
 		self.ntotal = 0
 		self.is_trained = False
 		self.centroids = None                       # [nlist x d] fp32
 		self._X = None                              # vectors in insertion order
 		self._Xs = self._offsets = self._ids = None  # vectors in list order (rows zero-padded to a multiple of 16 floats), list bounds, ids
 		self._Xs16 = None                            # dtype "bf16": the same rows rounded to bf16 (batched search)
-		self._dp = -(-self.d // 16) * 16
+		# row length of the stored vectors / queries, zero padded: a multiple of 16 floats; of 64 elements for bf16 lists (the 128 x 128-tile
+		# GEMM of the batched search streams 64-wide k-tiles)
+		self._dp = -(-self.d // 64) * 64 if dtype == "bf16" else -(-self.d // 16) * 16
 
 	def _dev32(self, x):
 		x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)
@@ -175,6 +178,11 @@ class IVFFlatIPIndex:
 		if q.shape[0] >= self.batched_from:
 			# many queries (hard-negative mining: every mention): pairs grouped by list, each list one MFMA GEMM -- a list's vectors
 			# are read once per 64 queries instead of once per query (28 -> ~3 ms for 10^4 queries on 10^5 x 768 vectors)
+			if profile is None and self.grouped_call and ops.ivf_search_grouped_ok(k_eff, self.nlist):
+				# round 5: the whole batched search behind one library call (packed score rows, 128 x 128 bf16 tiles)
+				if self._Xs16 is not None:
+					return ops.ivf_search_grouped(self._Xs16, self._offsets, self._ids, self._sizes, ops.convert(qp, torch.bfloat16), probe, k_eff)
+				return ops.ivf_search_grouped(self._Xs, self._offsets, self._ids, self._sizes, qp, probe, k_eff)
 			return ops.ivf_scan_grouped(self._Xs, self._offsets, self._ids, self._sizes, qp, probe, k_eff, lists_bf16=self._Xs16, profile=profile)
 		return ops.ivf_scan(self._Xs, self._offsets, self._ids, qp, probe, k_eff)
 

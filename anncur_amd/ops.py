@@ -333,6 +333,20 @@ def rowwise_topk(A, k, out=None):
 	return TopK(val, idx)
 
 
+@_on_device
+def rowwise_topk_ragged(A, row_len, k):
+	"""rowwise_topk over ragged rows: row q of A holds row_len[q] (int32 tensor, k <= row_len[q] <= A.shape[1]) elements; k <= 128."""
+	_dev(A, row_len)
+	A = _rowmajor(A)
+	Q, I = A.shape
+	if row_len.dtype != torch.int32 or row_len.numel() != Q or not row_len.is_contiguous():
+		raise ValueError("rowwise_topk_ragged: row_len must be a contiguous int32 tensor with one entry per row")
+	val = torch.empty((Q, k), dtype=torch.float32, device=A.device)
+	idx = torch.empty((Q, k), dtype=torch.int32, device=A.device)
+	check(_lib.load().anncur_rowwise_topk_ragged(_p(A), _dt(A), Q, I, _ld(A), _p(row_len), k, _p(val), _p(idx), _stream()), "rowwise_topk_ragged")
+	return TopK(val, idx)
+
+
 GatherTables = namedtuple("GatherTables", ["col_idx", "vec_tab", "n_items", "dtype"])
 
 
@@ -837,6 +851,73 @@ def ivf_scan_grouped(Xs, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 3
 		val[q0:q1, :k_eff] = v
 		if k_eff < k:
 			idx[q0:q1, :k_eff] = out_i
+			val[q0:q1, k_eff:] = float("-inf"); idx[q0:q1, k_eff:] = -1
+	return TopK(val, idx)
+
+
+IVF_GROUPED_MAX_K, IVF_GROUPED_MAX_NLIST = 128, 8192
+
+
+def ivf_search_grouped_ok(k, nlist):
+	"""True where ivf_search_grouped serves the search (the wave-per-row scan's k, list histograms in LDS); ivf_scan_grouped otherwise."""
+	return k <= IVF_GROUPED_MAX_K and nlist <= IVF_GROUPED_MAX_NLIST
+
+
+class _ByteScratch:
+	"""Grow-only 256-byte aligned workspace per device (ivf_search_grouped)."""
+	_bufs = {}
+
+	@classmethod
+	def get(cls, n, device):
+		key = (device.type, device.index)
+		buf = cls._bufs.get(key)
+		if buf is None or buf.numel() < n + 256:
+			cls._bufs[key] = buf = torch.empty(n + 256, dtype=torch.uint8, device=device)
+		off = (-buf.data_ptr()) % 256
+		return buf[off:off + n]
+
+
+@_on_device
+def ivf_search_grouped(lists, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 30, _skip_gemm=False):
+	"""The batched IVF search of ivf_scan_grouped as ONE library call per query chunk (round 5): pairs grouped by list on the device, one tile
+	GEMM launch on the matrix cores (bf16 `lists` / Q with rows a multiple of 64 elements: 128 x 128 tiles), scores in PACKED rows (query q's
+	probed lists back to back, nothing pre-filled), ragged scan, column -> id map.  lists / Q: fp32 or bf16 (the same for both), rows
+	zero-padded to a multiple of 16 elements.  probe int32 [nq x nprobe].  k <= 128, nlist <= 8192 (ivf_search_grouped_ok).
+	_skip_gemm: measurement only (bench.py times the call with and without its tile launch; the results are then meaningless)."""
+	_dev(lists, offsets, ids, Q, probe)
+	lib = _lib.load()
+	if lists.dtype != Q.dtype:
+		raise ValueError("ivf_search_grouped: lists and queries must have the same dtype")
+	nq_all, dp = Q.shape
+	probe = probe.to(torch.int32).contiguous()
+	nprobe, nlist = probe.shape[1], sizes_host.shape[0]
+	lmax = int(max(int(sizes_host.max()), 1))
+	k_eff = min(k, nprobe * lmax)
+	pitch = -(-max(nprobe * lmax, k_eff) // 8) * 8                 # any row fits: nprobe lists of at most lmax vectors
+	val = torch.empty((nq_all, k), dtype=torch.float32, device=Q.device)
+	idx = torch.empty((nq_all, k), dtype=torch.int32, device=Q.device)
+	step = max(64, min(nq_all, max_bytes // (pitch * 4), ((1 << 32) - 1) // pitch))
+	for q0 in range(0, nq_all, step):
+		q1 = min(nq_all, q0 + step)
+		nq = q1 - q0
+		Qc = Q[q0:q1]
+		T = int(lib.anncur_ivf_search_tile(_dt(lists), dp, _ld(lists), _ld(Qc), nq))
+		vt = -(-sizes_host // T)
+		max_tiles = (nq * nprobe // T) * int(max(int(vt.max()), 1)) + int(vt.sum())    # sum_l ceil(pairs_l / T) vt_l <= (pairs / T) max vt + sum vt
+		if _skip_gemm: max_tiles = 0
+		S = _ScoreScratch.get(nq * pitch, Q.device)
+		nbytes = lib.anncur_ivf_search_workspace_bytes(nq, nprobe, nlist, k_eff)
+		ws = _ByteScratch.get(nbytes, Q.device)
+		pr = probe[q0:q1]
+		if k_eff == k:
+			ov, oi = val[q0:q1], idx[q0:q1]
+		else:
+			ov = torch.empty((nq, k_eff), dtype=torch.float32, device=Q.device)
+			oi = torch.empty((nq, k_eff), dtype=torch.int32, device=Q.device)
+		check(lib.anncur_ivf_search_grouped(_p(lists), _dt(lists), _ld(lists), dp, _p(offsets), _p(ids), nlist, _p(Qc), _ld(Qc), nq, _p(pr), nprobe, k_eff, max_tiles,
+											_p(S), pitch, _p(ws), nbytes, _p(ov), _p(oi), _stream()), "ivf_search_grouped")
+		if k_eff < k:
+			val[q0:q1, :k_eff] = ov; idx[q0:q1, :k_eff] = oi
 			val[q0:q1, k_eff:] = float("-inf"); idx[q0:q1, k_eff:] = -1
 	return TopK(val, idx)
 

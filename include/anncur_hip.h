@@ -147,6 +147,11 @@ int anncur_eval_fused(const void *X, int64_t ldx, const void *Et, int64_t lde, c
 int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t lda, int32_t k,
                         float *out_val, int32_t *out_idx, void *stream);
 
+/* The same scan over RAGGED rows (round 5; the batched IVF search's packed score rows): row q of A holds row_len[q] elements,
+ * k <= row_len[q] <= I_max <= lda (the caller's contract; not checked on the device).  k <= 128 (ANNCUR_E_UNSUPPORTED above). */
+int anncur_rowwise_topk_ragged(const void *A, int dtype, int64_t Q, int64_t I_max, int64_t lda, const int32_t *row_len, int32_t k,
+                               float *out_val, int32_t *out_idx, void *stream);
+
 /* a2 folded into a8's pass over A (SURVEY a2 "fold into the first pass"; reference ..._splits.py:297,300 + 86): the scan of
  * anncur_rowwise_topk (k <= 128) also copies the anchor columns, cq[q, j] = A[q, col_idx[j]], as their 16-byte vectors stream past --
  * C_q costs no second read of the rows' sectors.  col_idx: n_idx (<= 65535) ascending, distinct columns in [0, I);
@@ -316,6 +321,23 @@ int anncur_ivf_group_scores_dev(const void *Xs, int dtype, int64_t ldx, int32_t 
                                 float *S, void *stream);
 int anncur_ivf_map_ids(const int32_t *col, const float *val, int64_t nq, int32_t k, int64_t lmax, const int32_t *probe, int32_t nprobe,
                        const int32_t *offsets, const int32_t *ids, int32_t *out_idx, void *stream);
+
+/* The batched search as ONE stream-ordered call (round 5) -- faiss.IndexIVFFlat.search for many queries, models/nearest_nbr.py:50-52 as
+ * the reference's hard-negative mining drives it (utils/data_process.py:343-365).  From the probed lists (probe int32[nq x nprobe], entries
+ * outside 0..nlist-1 skipped) to the k best (out_val float[nq x k] descending, out_idx int32[nq x k] ids; (-inf, -1) where the probed lists
+ * hold fewer than k vectors): pairs grouped by list on the device, one tile GEMM launch on the matrix cores (bf16 rows with dp a multiple
+ * of 64: 128 x 128 tiles, v_mfma_f32_32x32x16_bf16; fp32 rows or other bf16 row lengths: the 64 x 64 tiles of anncur_ivf_group_scores),
+ * scores written to PACKED rows -- S float[nq x pitch], 16-byte aligned, query q's probed lists back to back, nothing pre-filled -- and
+ * scanned by anncur_rowwise_topk_ragged.  Xs / Q as for anncur_ivf_group_scores(_bf16) (dtype selects fp32 or bf16 rows for BOTH).
+ * pitch >= max(k, longest packed row) -- nprobe x longest list always suffices -- a multiple of 4, nq x pitch < 2^32 (split the queries).
+ * max_tiles: any upper bound on sum_l ceil(pairs_l / T) ceil(size_l / T), T = anncur_ivf_search_tile(...) (the launch's grid: workgroups
+ * past the last tile exit), e.g. (nq nprobe / T) max_l ceil(size_l / T) + sum_l ceil(size_l / T).  k <= 128 and nlist <= 8192
+ * (ANNCUR_E_UNSUPPORTED otherwise: the calls above).  Workspace: anncur_ivf_search_workspace_bytes, 256-byte aligned. */
+int32_t anncur_ivf_search_tile(int dtype, int32_t dp, int64_t ldx, int64_t ldq, int64_t nq);
+size_t anncur_ivf_search_workspace_bytes(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k);
+int anncur_ivf_search_grouped(const void *Xs, int dtype, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, int32_t nlist,
+                              const void *Q, int64_t ldq, int64_t nq, const int32_t *probe, int32_t nprobe, int32_t k, int64_t max_tiles,
+                              float *S, int64_t pitch, void *workspace, size_t workspace_bytes, float *out_val, int32_t *out_idx, void *stream);
 
 /* Index-build hint of anncur_score_topk_ex: bucket[i] in 0..n_buckets-1 by the squared norm of row i of the fp32 matrix A, largest
  * norms first (linear between the matrix' largest and smallest row norm); norms float[n_rows] and minmax2 uint32[2] are scratch

@@ -4,7 +4,7 @@ import os, re, shutil, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 SMEM = re.compile(r"^\s*(s_load_|s_buffer_load_|s_memtime|s_memrealtime|s_scratch_load|s_atc_probe|s_dcache)")
-KERNELS = re.compile(r"score_kernel|score16_kernel|score16r_kernel|evalf_kernel|error_lds_kernel|scoreq1_kernel|scoreq16_kernel|wide_kernel|error_kernel")
+KERNELS = re.compile(r"ivf_tile128_kernel|score_kernel|score16_kernel|score16r_kernel|evalf_kernel|error_lds_kernel|scoreq1_kernel|scoreq16_kernel|wide_kernel|error_kernel")
 
 
 def disassemble(lib: str):

@@ -365,6 +365,89 @@ def test_ivf_batched_search_equals_the_per_query_scan(gpu):
 		assert (I2[j, :m] >= 0).all() and (I2[j, m:] == -1).all() and (D2[j, m:] == np.finfo(np.float32).min).all()
 
 
+@pytest.mark.parametrize("dtype,d,nlist,nprobe,nq,k", [
+	("fp32", 200, 120, 9, 1500, 20),      # 64 x 64 fp32 tiles on packed rows
+	("bf16", 200, 100, 7, 1000, 20),      # rows padded to 256 elements: the 128 x 128-tile kernel, an even number of k-tiles
+	("bf16", 130, 57, 5, 777, 128),       # 192 elements: an odd number of k-tiles; the scan's largest k; nq not a multiple of 256
+	("bf16", 64, 300, 40, 600, 64),       # one k-tile; many small lists, empty ones among them; rows shorter than k
+	("fp32", 33, 64, 64, 300, 100),       # every list probed
+])
+def test_ivf_search_grouped_call_equals_the_round4_sequence(gpu, dtype, d, nlist, nprobe, nq, k):
+	"""anncur_ivf_search_grouped (round 5: pairs grouped by list on the device, packed score rows, ragged scan, 128 x 128 bf16 tiles) against
+	the sequence of calls it replaces (ops.ivf_scan_grouped: stable pair sort, [nq x nprobe x lmax] score matrix pre-filled with -inf,
+	64 x 64 tiles): the same MFMA products accumulated in the same order along d -- scores BIT-EQUAL, ids equal (ties: both scans prefer
+	the smaller column and the packed layout keeps the columns' order), (-inf, -1) padding where the probed lists hold fewer than k vectors."""
+	from anncur_amd.nearest_nbr import IVFFlatIPIndex
+	from anncur_amd import ops
+	g = np.random.default_rng(1000 + d)
+	n = 20000
+	centers = g.standard_normal((30, d)).astype(np.float32) * 2
+	X = (centers[g.integers(0, 30, n)] + g.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+	q = torch.tensor((centers[g.integers(0, 30, nq)] + g.standard_normal((nq, d)).astype(np.float32)).astype(np.float32), device=gpu)
+	index = IVFFlatIPIndex(d, nlist, niter=3, dtype=dtype)
+	index.train(X); index.add(X)
+	index.nprobe = nprobe
+	index.batched_from = 1
+	assert index._dp % (64 if dtype == "bf16" else 16) == 0 and ops.ivf_search_grouped_ok(k, nlist)
+	index.grouped_call = True
+	v1, i1 = index.search_device(q, k)
+	index.grouped_call = False
+	v0, i0 = index.search_device(q, k)
+	torch.cuda.synchronize()
+	assert torch.equal(v1, v0)
+	assert torch.equal(i1, i0)
+	sizes = np.diff(index._offsets.cpu().numpy())
+	probe = ops.score_topk_dense(q, index.centroids, min(nprobe, nlist)).indices.cpu().numpy()
+	have = np.minimum(sizes[probe].sum(1), k)
+	i1h = i1.cpu().numpy()
+	assert all((i1h[j, :have[j]] >= 0).all() and (i1h[j, have[j]:] == -1).all() for j in range(nq))
+	if nlist == 300: assert sizes.min() < 64   # (the many-small-lists case)
+
+
+def test_ivf_search_grouped_direct_call_ragged_rows_and_bad_arguments(gpu):
+	"""ops.ivf_search_grouped on hand-built lists: bf16 rows of 80 elements (not a multiple of 64: the 64 x 64 bf16 tiles on packed rows),
+	probe entries of -1 (skipped), a query whose probed lists are all empty; against a dense fp32 product restricted to the probed lists.
+	The ragged scan on its own; the entry's refusals."""
+	from anncur_amd import ops, _lib
+	g = np.random.default_rng(5)
+	n, dp, nlist, nq, nprobe, k = 3000, 80, 40, 300, 6, 50
+	sizes = g.multinomial(n, g.dirichlet(np.ones(nlist) * 0.5)).astype(np.int64)
+	sizes[[3, 17]] += sizes[[4, 18]]; sizes[[4, 18]] = 0                                 # two empty lists
+	off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+	ids = g.permutation(n).astype(np.int32)
+	Xs = torch.tensor(g.standard_normal((n, dp)).astype(np.float32)).bfloat16()
+	Qh = torch.tensor(g.standard_normal((nq, dp)).astype(np.float32)).bfloat16()
+	probe = np.stack([g.choice(nlist, nprobe, replace=False) for _ in range(nq)]).astype(np.int32)
+	probe[5, 2:] = -1
+	probe[9, :] = [4, 18, -1, -1, -1, -1]                                                # nothing to scan
+	got = ops.ivf_search_grouped(Xs.to(gpu), torch.tensor(off, device=gpu), torch.tensor(ids, device=gpu), sizes, Qh.to(gpu), torch.tensor(probe, device=gpu), k)
+	S = Qh.float().numpy().astype(np.float64) @ Xs.float().numpy().astype(np.float64).T
+	gv, gi = got.values.cpu().numpy(), got.indices.cpu().numpy()
+	for j in range(nq):
+		rows = np.concatenate([np.arange(off[l], off[l + 1]) for l in probe[j] if l >= 0] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+		m = min(k, len(rows))
+		order = rows[np.argsort(-S[j, rows], kind="stable")[:m]]
+		np.testing.assert_allclose(gv[j, :m], S[j, order], rtol=1e-5, atol=1e-4)
+		assert (gv[j, m:] == -np.inf).all() and (gi[j, m:] == -1).all()
+		assert len(set(gi[j, :m].tolist()) ^ set(ids[order].tolist())) <= 2               # (a boundary near-tie may swap)
+	# the ragged scan alone against torch.topk of every row's prefix
+	A = torch.randn(37, 5000, device=gpu)
+	rl = torch.tensor(g.integers(64, 5001, 37).astype(np.int32), device=gpu); rl[0] = 64; rl[1] = 5000
+	r = ops.rowwise_topk_ragged(A, rl, 64)
+	for j in range(37):
+		w = torch.topk(A[j, :int(rl[j])], 64)
+		assert torch.equal(r.values[j], w.values) and torch.equal(r.indices[j].long(), w.indices)
+	Ab = A.bfloat16()
+	rb = ops.rowwise_topk_ragged(Ab, rl, 10)
+	for j in range(37):
+		assert torch.equal(rb.values[j], torch.topk(Ab[j, :int(rl[j])].float(), 10).values)
+	with pytest.raises(_lib.AnncurHipError):
+		ops.rowwise_topk_ragged(A, rl, 129)
+	assert not ops.ivf_search_grouped_ok(129, 100) and not ops.ivf_search_grouped_ok(10, 8193)
+	with pytest.raises(ValueError):
+		ops.ivf_search_grouped(Xs.to(gpu), torch.tensor(off, device=gpu), torch.tensor(ids, device=gpu), sizes, Qh.float().to(gpu), torch.tensor(probe, device=gpu), k)
+
+
 # ------------------------------------------------------------------ row-sharded evaluation: 2 ranks sharing the one GPU, gloo
 def _sharded_worker(rank, world, port, q):
 	import torch.distributed as dist

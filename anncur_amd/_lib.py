@@ -77,7 +77,7 @@ SIGNATURES = {
 	"anncur_ivf_group_scores_dev": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
 	"anncur_rowwise_topk_ragged": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
 	"anncur_ivf_search_tile": (c_int32, [c_int, c_int32, c_int64, c_int64, c_int64]),
-	"anncur_ivf_search_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
+	"anncur_ivf_search_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int64]),
 	"anncur_ivf_search_grouped": (c_int, [c_void_p, c_int, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int32, c_int64,
 										  c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
 	"anncur_ivf_map_ids": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -546,52 +546,64 @@ __global__ __launch_bounds__(256) void ivf_tile64_packed_kernel(const T *__restr
 	}
 }
 
-// ---- bf16, 128 pairs x 128 vectors per workgroup (round 5).  Four waves, wave (wm, wn) owns pairs [64 wm, +64) x vectors [64 wn, +64): 2 x 2
+// ---- bf16, 128 pairs x 128 vectors per tile (round 5).  Four waves, wave (wm, wn) owns pairs [64 wm, +64) x vectors [64 wn, +64): 2 x 2
 // accumulators of v_mfma_f32_32x32x16_bf16; d streamed in 64-wide k-tiles through two 32 KiB LDS stages (pairs' query rows 16 KiB + vectors
 // 16 KiB) filled by global_load_lds_dwordx4 -- the query rows gathered by the per-lane source address --, one barrier per k-tile, fragment
 // reads as inline asm with counted waits (the scheme of score_wide.hpp; the LDS image and its swizzle are that kernel's: row-major 128-byte
 // rows, 16-byte chunk index XOR (row >> 1) & 7 on the DMA's source address and again at the reads).  Two workgroups per CU.
-// Rows: dp a multiple of 64, 16-byte aligned; nq * ldq * 2 < 2^32 (32-bit source offsets behind a uniform base).
+// PERSISTENT workgroups: a tile is 12 k-tiles at d = 768 -- about as long as the chain of dependent loads that finds it (tile -> list ->
+// its pairs' rows -> first operand bytes); the first version, one workgroup per tile, ran at 0.17 of the bf16 peak.  Here the tiles' (list,
+// first pair, first vector, counts) are expanded to 32-byte descriptors by a kernel of their own, workgroup b walks the tiles start_x + (b >> 3),
+// + gridDim / 8, ... of its XCD's contiguous share (the tiles of a list run on one XCD around the same time and meet in its L2), reads the next
+// tile's descriptor and pair rows while the current one is multiplied, and the last k-tile's DMA slots fetch the next tile's first k-tile.
+// Rows: dp a multiple of 128 (an even number of k-tiles: a tile begins in stage 0), 16-byte aligned; nq * ldq * 2 < 2^32.
 constexpr int T128 = 128;
-constexpr int T128_TILE_BYTES = 128 * 128, T128_STAGE_BYTES = 2 * T128_TILE_BYTES, T128_LDS_BYTES = 2 * T128_STAGE_BYTES, T128_LDS_TOTAL = T128_LDS_BYTES + 2 * T128 * 4 + 16;
+constexpr int T128_TILE_BYTES = 128 * 128, T128_STAGE_BYTES = 2 * T128_TILE_BYTES, T128_LDS_BYTES = 2 * T128_STAGE_BYTES;
+constexpr int T128_LDS_TOTAL = T128_LDS_BYTES + 3 * 2 * T128 * 4;   // + three generations of (query row, output offset) per tile row
 struct T128Frag { u32x4g a[2], b[2]; };
+struct T128Desc { int32_t l, p0, p_rows, v0, v_rows, c0, pad0, pad1; };
 __device__ __forceinline__ void t128_read(u32x4g &dst, uint32_t addr, int off) {   // `off` folds to an immediate after unrolling
 #if defined(__HIP_DEVICE_COMPILE__)
 	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
 #endif
 }
-__global__ __launch_bounds__(256, 2) void ivf_tile128_kernel(const uint16_t *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
-															  const uint16_t *__restrict__ Q, int64_t ldq, const int32_t *__restrict__ pair_q,
-															  const uint32_t *__restrict__ pair_out, const int32_t *__restrict__ pair_off,
-															  const int32_t *__restrict__ tile_start, int32_t nlist, float *__restrict__ S) {
-	extern __shared__ __attribute__((aligned(16))) unsigned char t128_smem[];   // the two stages at offset 0, then the tile's rows
-	int32_t *arow = reinterpret_cast<int32_t *>(t128_smem + T128_LDS_BYTES);
-	uint32_t *orow = reinterpret_cast<uint32_t *>(arow + T128);
-	int32_t *meta = reinterpret_cast<int32_t *>(orow + T128);
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-	const int32_t n_tiles = tile_start[nlist];
-	if ((int32_t)blockIdx.x >= n_tiles) return;   // (uniform: before any barrier)
-	int32_t l, qt, vt;
-	ivf_find_tile(tile_start, nlist, offsets, T128, ivf_xcd_remap((int)blockIdx.x, n_tiles), meta, l, qt, vt);
-	const int32_t p0 = pair_off[l] + qt * T128, p_rows = min(T128, pair_off[l + 1] - p0);
-	const int32_t v0 = offsets[l] + vt * T128, v_rows = min(T128, offsets[l + 1] - v0);
-	if (tid < T128) {   // rows past the tile's pairs re-read its last pair's query (their scores are not stored)
-		const int32_t p = p0 + min(tid, p_rows - 1);
-		arow[tid] = pair_q[p];
-		orow[tid] = pair_out[p];
+// tile id -> descriptor (one thread per tile; tile_start lives in L2)
+__global__ __launch_bounds__(256) void ivf_tile_desc_kernel(const int32_t *__restrict__ tile_start, int32_t nlist, const int32_t *__restrict__ offsets,
+															 const int32_t *__restrict__ pair_off, int32_t T, T128Desc *__restrict__ desc) {
+	const int32_t t = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+	if (t >= tile_start[nlist]) return;
+	int32_t lo = 0, hi = nlist;   // largest l with tile_start[l] <= t (empty lists repeat their start: the search lands past them)
+	while (hi - lo > 1) {
+		const int32_t mid = (lo + hi) >> 1;
+		if (tile_start[mid] <= t) lo = mid; else hi = mid;
 	}
-	__syncthreads();
+	const int32_t l = lo, vcnt = (offsets[l + 1] - offsets[l] + T - 1) / T, within = t - tile_start[l];
+	const int32_t qt = within / vcnt, vt = within - qt * vcnt;
+	T128Desc d;
+	d.l = l;
+	d.p0 = pair_off[l] + qt * T; d.p_rows = min(T, pair_off[l + 1] - d.p0);
+	d.v0 = offsets[l] + vt * T; d.v_rows = min(T, offsets[l + 1] - d.v0);
+	d.c0 = vt * T; d.pad0 = d.pad1 = 0;
+	desc[t] = d;
+}
 
-	// ---- DMA sources: piece (wave * 4 + i) = tile rows 8 (wave * 4 + i) .. + 8, this lane: row + (lane >> 3), chunk lane & 7
+__global__ __launch_bounds__(256, 2) void ivf_tile128_kernel(const uint16_t *__restrict__ Xs, int64_t ldx, int32_t dp, const uint16_t *__restrict__ Q, int64_t ldq,
+															  const int32_t *__restrict__ pair_q, const uint32_t *__restrict__ pair_out,
+															  const int32_t *__restrict__ tile_start, int32_t nlist, const T128Desc *__restrict__ desc,
+															  float *__restrict__ S) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char t128_smem[];   // the two stages at offset 0, then the tiles' rows
+	int32_t *rows_lds = reinterpret_cast<int32_t *>(t128_smem + T128_LDS_BYTES);   // generation g: query rows at [g * 256, +128), output offsets at [g * 256 + 128, +128)
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+	// ---- this workgroup's tiles: its XCD's contiguous share of [0, n_tiles), strided by the workgroups of the XCD (gridDim.x is a multiple of 8)
+	const int32_t n_tiles = tile_start[nlist];
+	const int32_t xcd = (int32_t)(blockIdx.x & 7), lw = (int32_t)(blockIdx.x >> 3), wpx = (int32_t)(gridDim.x >> 3);
+	const int32_t share = n_tiles >> 3, rem = n_tiles & 7;
+	const int32_t t_begin = xcd < rem ? xcd * (share + 1) : rem * (share + 1) + (xcd - rem) * share, t_end = t_begin + share + (xcd < rem ? 1 : 0);
+	int32_t t = t_begin + lw;
+	if (t >= t_end) return;   // (uniform: before any barrier)
+
 	const unsigned char *abase = reinterpret_cast<const unsigned char *>(Q);
-	const unsigned char *bbase = reinterpret_cast<const unsigned char *>(Xs) + (int64_t)v0 * ldx * 2;
-	uint32_t aoff[4], boff[4];
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int prow = (wave * 4 + i) * 8 + (lane >> 3), pchunk = (lane & 7) ^ ((prow >> 1) & 7);
-		aoff[i] = (uint32_t)arow[prow] * (uint32_t)(ldq * 2) + (uint32_t)pchunk * 16u;
-		boff[i] = (uint32_t)min(prow, v_rows - 1) * (uint32_t)(ldx * 2) + (uint32_t)pchunk * 16u;
-	}
+	const uint32_t lda_b = (uint32_t)(ldq * 2), ldb_b = (uint32_t)(ldx * 2);
 	const int x = (r >> 1) & 7;
 	const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)t128_smem;
 	uint32_t fa[2][4], fb[2][4];
@@ -605,98 +617,176 @@ __global__ __launch_bounds__(256, 2) void ivf_tile128_kernel(const uint16_t *__r
 	}
 	const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 	const uint32_t lds0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds0);
-	f32x16g acc[2][2];
-#pragma unroll
-	for (int m = 0; m < 2; ++m)
-#pragma unroll
-		for (int t = 0; t < 2; ++t)
-#pragma unroll
-			for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
 
 #define T128_PIECE(BASE, OFF, TILE_OFF, i)                                                                        \
 	do {                                                                                                          \
 		const uint32_t m0v_ = lds0_u + (uint32_t)(TILE_OFF) + (uint32_t)(wave_u * 4 + (i)) * 1024u;               \
 		asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v_), "v"((OFF)[i]), "s"(BASE) : "memory", "m0"); \
 	} while (0)
-#define T128_DMA2(s)                                                                                              \
+	// DMA of the next k-tile: two of the wave's eight 1 KiB pieces per k-step, between the fragment reads and the MFMAs of the step
+#ifdef ANNCUR_V_IVF_NODMA   // (ablation build, results wrong: scripts/r5/ivf_ablation.sh)
+#define T128_DEN(DEN) ((DEN) && false)
+#define T128_ROWS_WAIT 0
+#else
+#define T128_DEN(DEN) (DEN)
+#define T128_ROWS_WAIT 8   // the phase's DMA pieces, issued after the rows' loads
+#endif
+#define T128_DMA2(s, DA, AOFF, DB, BOFF, DD, DEN)                                                                 \
 	do {                                                                                                          \
-		if (den) {                                                                                                \
-			if ((s) < 2) { T128_PIECE(da, aoff, dd, 2 * ((s) & 1)); T128_PIECE(da, aoff, dd, 2 * ((s) & 1) + 1); } \
-			else { T128_PIECE(db, boff, dd + T128_TILE_BYTES, 2 * ((s) & 1)); T128_PIECE(db, boff, dd + T128_TILE_BYTES, 2 * ((s) & 1) + 1); } \
+		if (T128_DEN(DEN)) {                                                                                              \
+			if ((s) < 2) { T128_PIECE(DA, AOFF, DD, 2 * ((s) & 1)); T128_PIECE(DA, AOFF, DD, 2 * ((s) & 1) + 1); } \
+			else { T128_PIECE(DB, BOFF, (DD) + T128_TILE_BYTES, 2 * ((s) & 1)); T128_PIECE(DB, BOFF, (DD) + T128_TILE_BYTES, 2 * ((s) & 1) + 1); } \
 		}                                                                                                         \
 	} while (0)
 #define T128_LOAD(F, STAGE, s)                                                                                    \
 	do {                                                                                                          \
 		_Pragma("unroll") for (int m = 0; m < 2; ++m) t128_read(F.a[m], fa[STAGE][s], m * 4096);                  \
-		_Pragma("unroll") for (int t = 0; t < 2; ++t) t128_read(F.b[t], fb[STAGE][s], t * 4096);                  \
+		_Pragma("unroll") for (int tt = 0; tt < 2; ++tt) t128_read(F.b[tt], fb[STAGE][s], tt * 4096);             \
 	} while (0)
 #define T128_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.b[0]), "+v"(F.b[1]) : "n"(N))
 #define T128_MFMA(F)                                                                                              \
 	do {                                                                                                          \
 		_Pragma("unroll") for (int m = 0; m < 2; ++m)                                                             \
-			_Pragma("unroll") for (int t = 0; t < 2; ++t)                                                         \
-				acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, F.a[m]), __builtin_bit_cast(bf16x8g, F.b[t]), acc[m][t], 0, 0, 0); \
+			_Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                      \
+				acc[m][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, F.a[m]), __builtin_bit_cast(bf16x8g, F.b[tt]), acc[m][tt], 0, 0, 0); \
 	} while (0)
-#define T128_SYNC()                                                                                               \
+#define T128_SYNC() T128_SYNC_V(0)
+#define T128_SYNC_V(NV)                                                                                           \
 	do {                                                                                                          \
-		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+		asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NV) : "memory");                                      \
 		__builtin_amdgcn_s_barrier();                                                                             \
 		asm volatile("" ::: "memory");                                                                            \
 	} while (0)
-#define T128_COMPUTE(STAGE)                                                                                       \
+#define T128_COMPUTE(STAGE, DA, AOFF, DB, BOFF, DD, DEN)                                                          \
 	do {                                                                                                          \
 		T128Frag f0, f1;                                                                                          \
 		T128_LOAD(f0, STAGE, 0);                                                                                  \
-		T128_LOAD(f1, STAGE, 1); T128_DMA2(0); T128_WAIT(f0, 4); T128_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
-		T128_LOAD(f0, STAGE, 2); T128_DMA2(1); T128_WAIT(f1, 4); T128_MFMA(f1); __builtin_amdgcn_sched_barrier(0); \
-		T128_LOAD(f1, STAGE, 3); T128_DMA2(2); T128_WAIT(f0, 4); T128_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
-		T128_DMA2(3); T128_WAIT(f1, 0); T128_MFMA(f1);                                                            \
+		T128_LOAD(f1, STAGE, 1); T128_DMA2(0, DA, AOFF, DB, BOFF, DD, DEN); T128_WAIT(f0, 4); T128_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
+		T128_LOAD(f0, STAGE, 2); T128_DMA2(1, DA, AOFF, DB, BOFF, DD, DEN); T128_WAIT(f1, 4); T128_MFMA(f1); __builtin_amdgcn_sched_barrier(0); \
+		T128_LOAD(f1, STAGE, 3); T128_DMA2(2, DA, AOFF, DB, BOFF, DD, DEN); T128_WAIT(f0, 4); T128_MFMA(f0); __builtin_amdgcn_sched_barrier(0); \
+		T128_DMA2(3, DA, AOFF, DB, BOFF, DD, DEN); T128_WAIT(f1, 0); T128_MFMA(f1);                                \
+	} while (0)
+	// this lane's DMA source offsets for a tile whose rows sit in generation g of rows_lds: piece (wave * 4 + i) = tile rows 8 (wave * 4 + i) .. + 8,
+	// this lane: row + (lane >> 3), chunk lane & 7; vector rows past the tile's last re-read it (their scores are not stored)
+#define T128_SOURCES(AOFF, BOFF, g, VROWS)                                                                        \
+	do {                                                                                                          \
+		_Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+			const int prow = (wave * 4 + i) * 8 + (lane >> 3), pchunk = (lane & 7) ^ ((prow >> 1) & 7);            \
+			AOFF[i] = (uint32_t)rows_lds[(g) * 256 + prow] * lda_b + (uint32_t)pchunk * 16u;                       \
+			BOFF[i] = (uint32_t)min(prow, (VROWS) - 1) * ldb_b + (uint32_t)pchunk * 16u;                           \
+		}                                                                                                         \
 	} while (0)
 
 	const int nk = dp >> 6;
-	{   // k-tile 0 -> stage 0
-		const unsigned char *da = abase, *db = bbase;
-		const uint32_t dd = 0u;
+	int gen = 0;
+	T128Desc d = desc[t];
+	if (tid < T128) {   // rows past the tile's pairs re-read its last pair's query (their scores are not stored)
+		const int32_t p = d.p0 + min(tid, d.p_rows - 1);
+		rows_lds[tid] = pair_q[p];
+		rows_lds[128 + tid] = (int32_t)pair_out[p];
+	}
+	__syncthreads();
+	uint32_t aoff[4], boff[4];
+	const unsigned char *bbase = reinterpret_cast<const unsigned char *>(Xs) + (int64_t)__builtin_amdgcn_readfirstlane(d.v0) * ldx * 2;   // (SGPR pair: the DMA's base)
+	T128_SOURCES(aoff, boff, 0, d.v_rows);
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { T128_PIECE(da, aoff, dd, i); T128_PIECE(db, boff, dd + T128_TILE_BYTES, i); }
-	}
+	for (int i = 0; i < 4; ++i) { T128_PIECE(abase, aoff, 0u, i); T128_PIECE(bbase, boff, (uint32_t)T128_TILE_BYTES, i); }
 	T128_SYNC();
-	for (int kt = 0; kt < nk; kt += 2) {
-		{   // stage 0 holds k-tile kt: fetch kt + 1 into stage 1 while it is consumed
-			const unsigned char *da = abase + (kt + 1) * 128, *db = bbase + (kt + 1) * 128;
-			const uint32_t dd = (uint32_t)T128_STAGE_BYTES;
-			const bool den = kt + 1 < nk;
-			T128_COMPUTE(0);
+
+	for (;;) {
+		const int32_t t_next = t + wpx;
+		const bool has_next = t_next < t_end;   // (uniform)
+		T128Desc dn = d;
+		if (has_next) dn = desc[t_next];
+		// The next tile's rows (query row, output offset), by inline-asm loads that every thread issues (the last tile re-reads its own): hipcc
+		// tracks the loads it emits and waits for them where it sees fit -- `vmcnt(0)` in front of the LDS write below and, on the path around
+		// that write, in front of every store of the epilogue -- and each such wait also drains what this kernel keeps in flight on purpose.
+		int32_t nrow, nout;
+		{
+			const int32_t p = dn.p0 + min(tid & 127, dn.p_rows - 1);
+			const int32_t *pq = pair_q + p;
+			const uint32_t *po = pair_out + p;
+			asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(nrow), "=&v"(nout) : "v"(pq), "v"(po) : "memory");
+		}
+		const int gen_next = gen == 2 ? 0 : gen + 1;
+		const unsigned char *bbase_n = reinterpret_cast<const unsigned char *>(Xs) + (int64_t)__builtin_amdgcn_readfirstlane(dn.v0) * ldx * 2;
+		uint32_t aoff_n[4] = {0u, 0u, 0u, 0u}, boff_n[4] = {0u, 0u, 0u, 0u};
+		f32x16g acc[2][2];
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+				for (int e = 0; e < 16; ++e) acc[m][tt][e] = 0.f;
+		for (int kt = 0; kt < nk; kt += 2) {
+			{   // stage 0 holds k-tile kt: fetch kt + 1 into stage 1 while it is consumed
+				const unsigned char *da = abase + (kt + 1) * 128, *db = bbase + (kt + 1) * 128;
+				T128_COMPUTE(0, da, aoff, db, boff, (uint32_t)T128_STAGE_BYTES, true);
+				// the rows' loads have landed once all but this phase's eight DMA pieces have (memory operations return in order); published by
+				// the barrier below, written again, unchanged, by every later k-tile pair (no first-iteration copy of the loop)
+				asm volatile("s_waitcnt vmcnt(%2)" : "+v"(nrow), "+v"(nout) : "n"(T128_ROWS_WAIT));
+				if (has_next && tid < T128) {
+					rows_lds[gen_next * 256 + tid] = nrow;
+					rows_lds[gen_next * 256 + 128 + tid] = nout;
+				}
+				T128_SYNC();
+			}
+			// stage 1 holds k-tile kt + 1: fetch kt + 2 into stage 0 -- or the next tile's first k-tile
+			const bool last = kt + 2 >= nk;
+			if (last && has_next) T128_SOURCES(aoff_n, boff_n, gen_next, dn.v_rows);
+			const unsigned char *da = last ? abase : abase + (kt + 2) * 128, *db = last ? bbase_n : bbase + (kt + 2) * 128;
+			uint32_t ao[4], bo[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) { ao[i] = last ? aoff_n[i] : aoff[i]; bo[i] = last ? boff_n[i] : boff[i]; }
+			const bool den = !last || has_next;
+			T128_COMPUTE(1, da, ao, db, bo, 0u, den);
 			T128_SYNC();
 		}
-		if (kt + 1 < nk) {   // (uniform) stage 1 holds k-tile kt + 1: fetch kt + 2 into stage 0
-			const unsigned char *da = abase + (kt + 2) * 128, *db = bbase + (kt + 2) * 128;
-			const uint32_t dd = 0u;
-			const bool den = kt + 2 < nk;
-			T128_COMPUTE(1);
-			T128_SYNC();
+		// ---- this tile's scores.  C/D layout: col = lane & 31 (vector), row = (e & 3) + 8 (e >> 2) + 4 h (pair) within the 32 x 32 block (m, tt).
+		// The rows' output offsets first, all of them, by inline-asm reads: hipcc cannot prove that an LDS read does not alias the DMA in
+		// flight and put `s_waitcnt vmcnt(1)` in front of EVERY compiler-generated read -- one store's round trip per store, 64 in a row
+		// (the first version: 0.06 of the kernel's 0.20 ms).
+		u32x4g ro[2][4];
+		{
+			const uint32_t oaddr = lds0 + (uint32_t)T128_LDS_BYTES + (uint32_t)(gen * 256 + 128 + wm * 64 + 4 * h) * 4u;
+#pragma unroll
+			for (int m = 0; m < 2; ++m)
+#pragma unroll
+				for (int g = 0; g < 4; ++g) t128_read(ro[m][g], oaddr, (m * 32 + 8 * g) * 4);
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ro[0][0]), "+v"(ro[0][1]), "+v"(ro[0][2]), "+v"(ro[0][3]), "+v"(ro[1][0]), "+v"(ro[1][1]), "+v"(ro[1][2]), "+v"(ro[1][3]));
 		}
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int tt = 0; tt < 2; ++tt) {
+				const int n = wn * 64 + tt * 32 + r;
+				float *col = S + (d.c0 + n);
+#pragma unroll
+				for (int e = 0; e < 16; ++e) {
+					const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#ifdef ANNCUR_V_IVF_NOSTORE   // (ablation build)
+					if (row < d.p_rows && n < d.v_rows && acc[m][tt][e] == 1.2345e30f) col[ro[m][e >> 2][e & 3]] = acc[m][tt][e];
+#else
+					if (row < d.p_rows && n < d.v_rows) col[ro[m][e >> 2][e & 3]] = acc[m][tt][e];
+#endif
+				}
+			}
+		if (!has_next) break;
+		t = t_next; d = dn; gen = gen_next; bbase = bbase_n;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { aoff[i] = aoff_n[i]; boff[i] = boff_n[i]; }
 	}
+#undef T128_SOURCES
 #undef T128_COMPUTE
 #undef T128_SYNC
+#undef T128_SYNC_V
 #undef T128_MFMA
 #undef T128_WAIT
 #undef T128_LOAD
 #undef T128_DMA2
+#undef T128_DEN
+#undef T128_ROWS_WAIT
 #undef T128_PIECE
-	// C/D layout: col = lane & 31 (vector), row = (e & 3) + 8 (e >> 2) + 4 h (pair) within the 32 x 32 block (m, t) of the wave's tile
-	const int32_t c0 = vt * T128;
-#pragma unroll
-	for (int m = 0; m < 2; ++m)
-#pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			const int n = wn * 64 + t * 32 + r;
-#pragma unroll
-			for (int e = 0; e < 16; ++e) {
-				const int row = wm * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-				if (row < p_rows && n < v_rows) S[(int64_t)orow[row] + (c0 + n)] = acc[m][t][e];
-			}
-		}
 }
 
 // column of a packed score row -> id of the vector (-1 where the score is the -inf padding of a short row)
@@ -771,24 +861,25 @@ extern "C" int anncur_ivf_group_scores_dev(const void *Xs, int dtype, int64_t ld
 }
 
 // ---- round 5: the whole batched search behind one call (see the kernels above)
-struct IvfSearchWs { size_t counts, pair_off, cursor, tile_start, coff, row_len, pair_q, pair_out, col, total; };
-static IvfSearchWs ivf_search_ws(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k) {
+struct IvfSearchWs { size_t counts, pair_off, cursor, tile_start, coff, row_len, pair_q, pair_out, col, desc, total; };
+static IvfSearchWs ivf_search_ws(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k, int64_t max_tiles) {
 	IvfSearchWs w;
 	size_t o = 0;
 	auto take = [&](size_t words) { const size_t at = o; o += (words * 4 + 255) & ~(size_t)255; return at; };
 	w.counts = take((size_t)nlist); w.pair_off = take((size_t)nlist + 1); w.cursor = take((size_t)nlist); w.tile_start = take((size_t)nlist + 1);
 	w.coff = take((size_t)nq * nprobe); w.row_len = take((size_t)nq); w.pair_q = take((size_t)nq * nprobe); w.pair_out = take((size_t)nq * nprobe);
 	w.col = take((size_t)nq * k);
+	w.desc = take((size_t)max_tiles * 8);   // (the 128 x 128-tile kernel's descriptors)
 	w.total = o;
 	return w;
 }
 static bool ivf_use_tile128(int dtype, int32_t dp, int64_t ldx, int64_t ldq, int64_t nq) {
-	return dtype == ANNCUR_BF16 && (dp % 64) == 0 && nq * ldq * 2 < ((int64_t)1 << 32) && 128 * ldx * 2 < ((int64_t)1 << 32);
+	return dtype == ANNCUR_BF16 && (dp % 128) == 0 && nq * ldq * 2 < ((int64_t)1 << 32) && 128 * ldx * 2 < ((int64_t)1 << 32);
 }
 extern "C" int32_t anncur_ivf_search_tile(int dtype, int32_t dp, int64_t ldx, int64_t ldq, int64_t nq) { return ivf_use_tile128(dtype, dp, ldx, ldq, nq) ? T128 : GT; }
-extern "C" size_t anncur_ivf_search_workspace_bytes(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k) {
-	if (nq < 0 || nprobe < 1 || nlist < 1 || k < 1) return 0;
-	return ivf_search_ws(nq, nprobe, nlist, k).total;
+extern "C" size_t anncur_ivf_search_workspace_bytes(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k, int64_t max_tiles) {
+	if (nq < 0 || nprobe < 1 || nlist < 1 || k < 1 || max_tiles < 0) return 0;
+	return ivf_search_ws(nq, nprobe, nlist, k, max_tiles).total;
 }
 extern "C" int anncur_ivf_search_grouped(const void *Xs, int dtype, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, int32_t nlist,
 										 const void *Q, int64_t ldq, int64_t nq, const int32_t *probe, int32_t nprobe, int32_t k, int64_t max_tiles,
@@ -805,7 +896,7 @@ extern "C" int anncur_ivf_search_grouped(const void *Xs, int dtype, int64_t ldx,
 	}
 	if (nq == 0) return ANNCUR_OK;
 	ANNCUR_REQUIRE(Xs && offsets && ids && Q && probe && S && out_val && out_idx && ((uintptr_t)S % 16) == 0, ANNCUR_E_INVALID, "ivf_search_grouped: null or misaligned pointer");
-	const IvfSearchWs w = ivf_search_ws(nq, nprobe, nlist, k);
+	const IvfSearchWs w = ivf_search_ws(nq, nprobe, nlist, k, max_tiles);
 	ANNCUR_REQUIRE(workspace && workspace_bytes >= w.total && ((uintptr_t)workspace % 256) == 0, ANNCUR_E_WORKSPACE, "ivf_search_grouped: workspace of %zu bytes needed (256-byte aligned)", w.total);
 	unsigned char *wb = reinterpret_cast<unsigned char *>(workspace);
 	int32_t *counts = reinterpret_cast<int32_t *>(wb + w.counts), *pair_off = reinterpret_cast<int32_t *>(wb + w.pair_off), *cursor = reinterpret_cast<int32_t *>(wb + w.cursor);
@@ -824,8 +915,13 @@ extern "C" int anncur_ivf_search_grouped(const void *Xs, int dtype, int64_t ldx,
 		if (t128) {
 			const int rc = anncur_ensure_dyn_lds((const void *)ivf_tile128_kernel, T128_LDS_TOTAL);
 			if (rc != ANNCUR_OK) return rc;
-			hipLaunchKernelGGL(ivf_tile128_kernel, dim3((unsigned)max_tiles), dim3(256), T128_LDS_TOTAL, st, (const uint16_t *)Xs, ldx, dp, offsets, (const uint16_t *)Q, ldq,
-							   pair_q, pair_out, pair_off, tile_start, nlist, S);
+			T128Desc *desc = reinterpret_cast<T128Desc *>(wb + w.desc);
+			hipLaunchKernelGGL(ivf_tile_desc_kernel, dim3((unsigned)ceil_div64(max_tiles, 256)), dim3(256), 0, st, tile_start, nlist, offsets, pair_off, T128, desc);
+			int64_t wgs = 2 * (int64_t)anncur_num_cu();   // two resident workgroups per CU walk the tiles
+			wgs = (wgs + 7) & ~(int64_t)7;
+			if (wgs > ((max_tiles + 7) & ~(int64_t)7)) wgs = (max_tiles + 7) & ~(int64_t)7;
+			hipLaunchKernelGGL(ivf_tile128_kernel, dim3((unsigned)wgs), dim3(256), T128_LDS_TOTAL, st, (const uint16_t *)Xs, ldx, dp, (const uint16_t *)Q, ldq,
+							   pair_q, pair_out, tile_start, nlist, desc, S);
 		} else if (dtype == ANNCUR_F32)
 			hipLaunchKernelGGL(ivf_tile64_packed_kernel<float>, dim3((unsigned)max_tiles), dim3(256), 0, st, (const float *)Xs, ldx, dp, offsets, (const float *)Q, ldq, pair_q,
 							   pair_out, pair_off, tile_start, nlist, S);

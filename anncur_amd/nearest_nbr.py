@@ -100,9 +100,9 @@ class IVFFlatIPIndex:
 		self._X = None                              # vectors in insertion order
 		self._Xs = self._offsets = self._ids = None  # vectors in list order (rows zero-padded to a multiple of 16 floats), list bounds, ids
 		self._Xs16 = None                            # dtype "bf16": the same rows rounded to bf16 (batched search)
-		# row length of the stored vectors / queries, zero padded: a multiple of 16 floats; of 64 elements for bf16 lists (the 128 x 128-tile
-		# GEMM of the batched search streams 64-wide k-tiles)
-		self._dp = -(-self.d // 64) * 64 if dtype == "bf16" else -(-self.d // 16) * 16
+		# row length of the stored vectors / queries, zero padded: a multiple of 16 floats; of 128 elements for bf16 lists (the 128 x 128-tile
+		# GEMM of the batched search streams pairs of 64-wide k-tiles)
+		self._dp = -(-self.d // 128) * 128 if dtype == "bf16" else -(-self.d // 16) * 16
 
 	def _dev32(self, x):
 		x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)

@@ -880,7 +880,7 @@ class _ByteScratch:
 @_on_device
 def ivf_search_grouped(lists, offsets, ids, sizes_host, Q, probe, k, max_bytes=8 << 30, _skip_gemm=False):
 	"""The batched IVF search of ivf_scan_grouped as ONE library call per query chunk (round 5): pairs grouped by list on the device, one tile
-	GEMM launch on the matrix cores (bf16 `lists` / Q with rows a multiple of 64 elements: 128 x 128 tiles), scores in PACKED rows (query q's
+	GEMM launch on the matrix cores (bf16 `lists` / Q with rows a multiple of 128 elements: 128 x 128 tiles), scores in PACKED rows (query q's
 	probed lists back to back, nothing pre-filled), ragged scan, column -> id map.  lists / Q: fp32 or bf16 (the same for both), rows
 	zero-padded to a multiple of 16 elements.  probe int32 [nq x nprobe].  k <= 128, nlist <= 8192 (ivf_search_grouped_ok).
 	_skip_gemm: measurement only (bench.py times the call with and without its tile launch; the results are then meaningless)."""
@@ -906,7 +906,7 @@ def ivf_search_grouped(lists, offsets, ids, sizes_host, Q, probe, k, max_bytes=8
 		max_tiles = (nq * nprobe // T) * int(max(int(vt.max()), 1)) + int(vt.sum())    # sum_l ceil(pairs_l / T) vt_l <= (pairs / T) max vt + sum vt
 		if _skip_gemm: max_tiles = 0
 		S = _ScoreScratch.get(nq * pitch, Q.device)
-		nbytes = lib.anncur_ivf_search_workspace_bytes(nq, nprobe, nlist, k_eff)
+		nbytes = lib.anncur_ivf_search_workspace_bytes(nq, nprobe, nlist, k_eff, max_tiles)
 		ws = _ByteScratch.get(nbytes, Q.device)
 		pr = probe[q0:q1]
 		if k_eff == k:

@@ -222,10 +222,10 @@ def self_launch(args):
 def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 	"""models/nearest_nbr.py:40-52 at the size of the reference's hard-negative mining (utils/data_process.py:343-365: every mention queries
 	the entity index): n clustered vectors, nlist = floor(sqrt(n)), nprobe = floor(sqrt(nlist)); batched list-grouped search on the matrix
-	cores.  Two figures per index dtype: the whole search() call with host numpy in / out like FAISS (probe, pair sort, host-built tile
-	copies), and the KERNELS alone on device-resident queries (HIP events around the per-list GEMM launch and around the exact scan
-	of the scores + id map) against the matrix peak of the operand type (fp32: 157 TFLOP/s; bf16 lists: 2500).  Algorithmic flops = 2 x
-	vectors scanned x d; the GEMM launch also multiplies the padding of its 64 x 64 tiles (reported as tile_flops_ratio)."""
+	cores.  Figures per index dtype: the whole search() call with host numpy in / out like FAISS, search_device() on device-resident queries (probe
+	GEMM + top-nprobe, then anncur_ivf_search_grouped: pair grouping, tile GEMM, ragged scan of the packed score rows, id map), and the tile
+	kernel alone against the matrix peak of the operand type (fp32: 157 TFLOP/s; bf16 lists: 2500).  Algorithmic flops = 2 x vectors scanned x d;
+	the tile launch also multiplies the padding of its 128 x 128 (bf16) / 64 x 64 (fp32) tiles (reported as tile_flops_ratio)."""
 	from anncur_amd import ops
 	from anncur_amd.nearest_nbr import build_flat_or_ivff_index
 	g = torch.Generator(device=device).manual_seed(seed + 99)
@@ -248,12 +248,36 @@ def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 		scanned = float(sizes[probe].sum())
 		flops = 2.0 * scanned * d
 		gemm_ms, scan_ms, tile_flops = [], [], 0.0
-		for _ in range(5):   # kernels alone: device-resident queries and results, events on the launch stream
-			prof = {}
-			index.search_device(q_dev, k, profile=prof)
-			torch.cuda.synchronize()
-			gemm_ms.append(sum(e[0].elapsed_time(e[1]) for e in prof["events"])); scan_ms.append(sum(e[1].elapsed_time(e[2]) for e in prof["events"]))
-			tile_flops = 2.0 * sum(int(t[-1].item()) for t in prof["tile_starts"]) * 64 * 64 * index._dp   # (the device-built worklist's tile count)
+		k_eff = min(k, ops._lib.MAX_TOPK)
+		grouped = index.grouped_call and ops.ivf_search_grouped_ok(k_eff, index.nlist)
+		if grouped:
+			# kernels alone, the one-call search (round 5): the call timed WITH and WITHOUT its tile launch on the same device-resident operands (HIP
+			# events on the launch stream; without the launch the scan reads the scores the previous call left) -- the difference is the tile kernel,
+			# the remainder pair grouping + ragged scan + id map.  The profiler's per-kernel figures are in profiles/r05_ivf_*.
+			lists = index._Xs16 if index._Xs16 is not None else index._Xs
+			qd = torch.zeros((nq, index._dp), dtype=torch.float32, device=device); qd[:, :d] = q_dev
+			qd = ops.convert(qd, torch.bfloat16) if index._Xs16 is not None else qd
+			pr = torch.as_tensor(probe).to(device)
+			def timed(skip):
+				for _ in range(2): ops.ivf_search_grouped(lists, index._offsets, index._ids, sizes, qd, pr, k_eff, _skip_gemm=skip)
+				ms = []
+				for _ in range(9):
+					e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+					e0.record(); ops.ivf_search_grouped(lists, index._offsets, index._ids, sizes, qd, pr, k_eff, _skip_gemm=skip); e1.record(); torch.cuda.synchronize()
+					ms.append(e0.elapsed_time(e1))
+				return float(np.median(ms))
+			full, rest = timed(False), timed(True)
+			gemm_ms, scan_ms = [max(full - rest, 1e-6)], [rest]
+			T = int(ops._lib.load().anncur_ivf_search_tile(ops._dt(lists), index._dp, ops._ld(lists), ops._ld(qd), nq))
+			pairs = np.bincount(probe.reshape(-1), minlength=index.nlist)
+			tile_flops = 2.0 * float((-(-pairs // T) * -(-sizes // T)).sum()) * T * T * index._dp
+		else:
+			for _ in range(5):   # kernels alone: device-resident queries and results, events on the launch stream
+				prof = {}
+				index.search_device(q_dev, k, profile=prof)
+				torch.cuda.synchronize()
+				gemm_ms.append(sum(e[0].elapsed_time(e[1]) for e in prof["events"])); scan_ms.append(sum(e[1].elapsed_time(e[2]) for e in prof["events"]))
+				tile_flops = 2.0 * sum(int(t[-1].item()) for t in prof["tile_starts"]) * 64 * 64 * index._dp   # (the device-built worklist's tile count)
 		gm, sm = float(np.median(gemm_ms)), float(np.median(scan_ms))
 		# the whole search on DEVICE-RESIDENT queries and results (probe GEMM + top-nprobe, pair sort, tile worklist, per-list GEMMs, scan, id map):
 		# what a caller that already holds its embeddings on the GPU pays (VERDICT r4 item 8 asks for this figure)
@@ -267,7 +291,9 @@ def ivf_sideline(device, seed, n=100000, d=768, nq=10000, k=64):
 			   "vectors_scanned_per_query": scanned / nq,
 			   "search_device_ms": dm, "queries_per_s_device_resident": nq / (dm * 1e-3),
 			   "kernels": {"group_gemm_ms": gm, "scan_and_id_map_ms": sm, "queries_per_s_kernels_only": nq / ((gm + sm) * 1e-3), "tile_flops_ratio": tile_flops / flops,
-						   "roofline": {"bound": "mfma", "kernel": "ivf_group_scores_bf16_kernel (bf16 MFMA)" if dtype == "bf16" else "ivf_group_scores_kernel (fp32 MFMA)",
+						   "how": ("anncur_ivf_search_grouped timed with and without its tile launch: group_gemm_ms = the difference, scan_and_id_map_ms = the rest "
+								   "(pair grouping, ragged scan, id map)") if grouped else "HIP events around the launches of the round-4 call sequence",
+						   "roofline": {"bound": "mfma", "kernel": (("ivf_tile128_kernel (bf16 MFMA, 128 x 128 tiles)" if index._dp % 128 == 0 else "ivf_tile64_packed_kernel<bf16>") if dtype == "bf16" else "ivf_tile64_packed_kernel<float> (fp32 MFMA)") if grouped else ("ivf_group_scores_bf16_kernel (bf16 MFMA)" if dtype == "bf16" else "ivf_group_scores_kernel (fp32 MFMA)"),
 										"achieved": flops / (gm * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / (gm * 1e-3) / 1e12 / peak,
 										"what": "the per-list GEMM launch alone (HIP events), algorithmic flops = 2 x vectors scanned x d"}},
 			   "whole_call": {"achieved_tflops": flops / search_s / 1e12, "what": "search() incl. host numpy in / out (30 MB of queries over PCIe), probe, pair sort, exact scan of the scores"}}

@@ -326,7 +326,7 @@ int anncur_ivf_map_ids(const int32_t *col, const float *val, int64_t nq, int32_t
  * the reference's hard-negative mining drives it (utils/data_process.py:343-365).  From the probed lists (probe int32[nq x nprobe], entries
  * outside 0..nlist-1 skipped) to the k best (out_val float[nq x k] descending, out_idx int32[nq x k] ids; (-inf, -1) where the probed lists
  * hold fewer than k vectors): pairs grouped by list on the device, one tile GEMM launch on the matrix cores (bf16 rows with dp a multiple
- * of 64: 128 x 128 tiles, v_mfma_f32_32x32x16_bf16; fp32 rows or other bf16 row lengths: the 64 x 64 tiles of anncur_ivf_group_scores),
+ * of 128: 128 x 128 tiles, v_mfma_f32_32x32x16_bf16; fp32 rows or other bf16 row lengths: the 64 x 64 tiles of anncur_ivf_group_scores),
  * scores written to PACKED rows -- S float[nq x pitch], 16-byte aligned, query q's probed lists back to back, nothing pre-filled -- and
  * scanned by anncur_rowwise_topk_ragged.  Xs / Q as for anncur_ivf_group_scores(_bf16) (dtype selects fp32 or bf16 rows for BOTH).
  * pitch >= max(k, longest packed row) -- nprobe x longest list always suffices -- a multiple of 4, nq x pitch < 2^32 (split the queries).
@@ -334,7 +334,7 @@ int anncur_ivf_map_ids(const int32_t *col, const float *val, int64_t nq, int32_t
  * past the last tile exit), e.g. (nq nprobe / T) max_l ceil(size_l / T) + sum_l ceil(size_l / T).  k <= 128 and nlist <= 8192
  * (ANNCUR_E_UNSUPPORTED otherwise: the calls above).  Workspace: anncur_ivf_search_workspace_bytes, 256-byte aligned. */
 int32_t anncur_ivf_search_tile(int dtype, int32_t dp, int64_t ldx, int64_t ldq, int64_t nq);
-size_t anncur_ivf_search_workspace_bytes(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k);
+size_t anncur_ivf_search_workspace_bytes(int64_t nq, int32_t nprobe, int32_t nlist, int32_t k, int64_t max_tiles);
 int anncur_ivf_search_grouped(const void *Xs, int dtype, int64_t ldx, int32_t dp, const int32_t *offsets, const int32_t *ids, int32_t nlist,
                               const void *Q, int64_t ldq, int64_t nq, const int32_t *probe, int32_t nprobe, int32_t k, int64_t max_tiles,
                               float *S, int64_t pitch, void *workspace, size_t workspace_bytes, float *out_val, int32_t *out_idx, void *stream);

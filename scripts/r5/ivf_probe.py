@@ -22,6 +22,25 @@ def main():
 		probe = ops.score_topk_dense(q, index.centroids, index.nprobe).indices.cpu().numpy()
 		per_q = s[probe].sum(1)
 		print(f"   vectors scanned per query: mean {per_q.mean():.0f} max {per_q.max()}  (nprobe x lmax = {index.nprobe * int(s.max())})", flush=True)
+		pairs = np.bincount(probe.reshape(-1), minlength=index.nlist)
+		for T in (64, 128, 256):
+			nt = int((-(-pairs // T) * -(-s // T)).sum())
+			print(f"   tiles of {T} x {T}: {nt}  tile flops / algorithmic flops = {nt * T * T / float((pairs * s).sum()):.3f}", flush=True)
+		if dtype == "bf16" and os.environ.get("GEMM_ONLY", "1") == "1":
+			qb = ops.convert(q, torch.bfloat16)
+			pr = torch.as_tensor(probe).to(dev)
+			t = {}
+			for skip in (False, True):
+				for _ in range(3): ops.ivf_search_grouped(index._Xs16, index._offsets, index._ids, index._sizes, qb, pr, k, _skip_gemm=skip)
+				torch.cuda.synchronize()
+				ms = []
+				for _ in range(reps):
+					e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+					e0.record(); ops.ivf_search_grouped(index._Xs16, index._offsets, index._ids, index._sizes, qb, pr, k, _skip_gemm=skip); e1.record(); torch.cuda.synchronize()
+					ms.append(e0.elapsed_time(e1))
+				t[skip] = float(np.median(ms))
+			flops = 2.0 * float((pairs * s).sum()) * d
+			print(f"   grouped call {t[False]:.3f} ms, without its tile launch {t[True]:.3f} ms -> tile kernel {t[False] - t[True]:.3f} ms = {flops / (t[False] - t[True]) / 1e9:.0f} TFLOP/s algorithmic", flush=True)
 		res = {}
 		for grouped in (os.environ.get("MODES", "0,1").split(",")):
 			index.grouped_call = grouped == "1"

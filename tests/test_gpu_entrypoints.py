@@ -367,9 +367,10 @@ def test_ivf_batched_search_equals_the_per_query_scan(gpu):
 
 @pytest.mark.parametrize("dtype,d,nlist,nprobe,nq,k", [
 	("fp32", 200, 120, 9, 1500, 20),      # 64 x 64 fp32 tiles on packed rows
-	("bf16", 200, 100, 7, 1000, 20),      # rows padded to 256 elements: the 128 x 128-tile kernel, an even number of k-tiles
-	("bf16", 130, 57, 5, 777, 128),       # 192 elements: an odd number of k-tiles; the scan's largest k; nq not a multiple of 256
-	("bf16", 64, 300, 40, 600, 64),       # one k-tile; many small lists, empty ones among them; rows shorter than k
+	("bf16", 200, 100, 7, 1000, 20),      # rows padded to 256 elements: the persistent 128 x 128-tile kernel, two pairs of k-tiles per tile
+	("bf16", 300, 57, 5, 777, 128),       # 384 elements: three pairs; the scan's largest k; nq not a multiple of 256
+	("bf16", 64, 300, 40, 600, 64),       # 128 elements: ONE pair of k-tiles (first = last); many small lists, empty ones among them; rows shorter than k
+	("bf16", 96, 8, 3, 5000, 10),         # few long lists: many tiles per list, more tiles than resident workgroups
 	("fp32", 33, 64, 64, 300, 100),       # every list probed
 ])
 def test_ivf_search_grouped_call_equals_the_round4_sequence(gpu, dtype, d, nlist, nprobe, nq, k):
@@ -388,7 +389,7 @@ def test_ivf_search_grouped_call_equals_the_round4_sequence(gpu, dtype, d, nlist
 	index.train(X); index.add(X)
 	index.nprobe = nprobe
 	index.batched_from = 1
-	assert index._dp % (64 if dtype == "bf16" else 16) == 0 and ops.ivf_search_grouped_ok(k, nlist)
+	assert index._dp % (128 if dtype == "bf16" else 16) == 0 and ops.ivf_search_grouped_ok(k, nlist)
 	index.grouped_call = True
 	v1, i1 = index.search_device(q, k)
 	index.grouped_call = False

@@ -396,12 +396,13 @@ def test_entry_point_sweeps_random_vs_oracle(ops, n_train, n_test, n_ent, rank, 
 				assert float(a[subset]["approx_error_relative"]) == pytest.approx(float(b[subset]["approx_error_relative"]), rel=2e-2, abs=1e-4), subset
 
 
-@settings(max_examples=(_N // 20) or 6, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=(_N // 10) or 12, deadline=None, derandomize=not _FUZZ, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(n=st.integers(200, 30000), d=st.integers(3, 200), nlist=st.integers(2, 120), nprobe=st.integers(1, 120), nq=st.integers(1, 60), k=st.integers(1, 300),
-	   clusters=st.integers(1, 40), seed=st.integers(0, 10 ** 6))
-def test_ivf_flat_random(ops, n, d, nlist, nprobe, nq, k, clusters, seed):
+	   clusters=st.integers(1, 40), seed=st.integers(0, 10 ** 6), batched=st.booleans())
+def test_ivf_flat_random(ops, n, d, nlist, nprobe, nq, k, clusters, seed, batched):
 	"""IVF-flat index on random sizes: lists complete and disjoint, the search equals a brute-force search restricted to the probed
-	lists (scores exact, FAISS padding), and probing every list equals the exact search."""
+	lists (scores exact, FAISS padding), and probing every list equals the exact search.  batched: the list-grouped search whatever the
+	number of queries (round 5: anncur_ivf_search_grouped for k <= 128 -- packed score rows, ragged scan --, round 4's sequence above)."""
 	from anncur_amd.nearest_nbr import IVFFlatIPIndex
 	g = np.random.default_rng(seed)
 	nlist = min(nlist, n)
@@ -411,6 +412,7 @@ def test_ivf_flat_random(ops, n, d, nlist, nprobe, nq, k, clusters, seed):
 	index = IVFFlatIPIndex(d, nlist, niter=5)
 	index.train(X); index.add(X)
 	index.nprobe = nprobe
+	if batched: index.batched_from = 1
 	D, I = index.search(q, k)
 	off, ids = index._offsets.cpu().numpy(), index._ids.cpu().numpy()
 	assert off[0] == 0 and off[-1] == n and (np.sort(ids) == np.arange(n)).all()

@@ -46,6 +46,8 @@ SIGNATURES = {
 	"anncur_eval_fused_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
 	"anncur_eval_fused": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
 								  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+	"anncur_eval_fused_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+								  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 	"anncur_approx_error": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int64,
 									c_int64, c_void_p, c_void_p, c_void_p]),
 	"anncur_rowwise_topk": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),

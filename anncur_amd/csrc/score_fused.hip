@@ -2042,7 +2042,7 @@ void co_abort(CoScan *co, hipStream_t st) {
 bool exact_tile_offsets_fit(int64_t lda, int bq) { return lda >= 0 && (uint64_t)(bq - 1) * (uint64_t)lda * 2u + 64u < ((uint64_t)1 << 32); }
 
 // anncur_eval_fused: the exact matrix and the two per-row sums the sweep stages also produce (evalf_kernel)
-struct EvalArgs { const uint16_t *A; int64_t lda; float *err_sq, *norm_sq; };
+struct EvalArgs { const uint16_t *A; int64_t lda; float *err_sq, *norm_sq; const uint16_t *Et_hint; };   // Et_hint: see anncur_eval_fused_ex (may be null)
 
 template <int KP, int QTV = FusedCfg<KP>::QT>
 int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et, int64_t Q, int64_t I, int k, float *out_val,
@@ -2094,10 +2094,16 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	EV(0);
 	// 1. prepass
 	p.n_wg = P.n_rb * P.S0;
-	if (P.group == 16)
-		hipLaunchKernelGGL((score_kernel<KP, 0, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
-	else
-		hipLaunchKernelGGL((score_kernel<KP, 0, 4, false, false, QTV>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, p);
+	{
+		// anncur_eval_fused_ex's hint: the prepass samples the LEADING tiles of the norm-ordered copy (the likeliest high scorers: a tighter first
+		// threshold), the sweep keeps the item order the exact tiles need.  Any subset of the items gives a valid threshold.
+		FusedParams pp = p;
+		if (ea && ea->Et_hint) { pp.Et = ea->Et_hint; pp.sample_leading = 1; }
+		if (P.group == 16)
+			hipLaunchKernelGGL((score_kernel<KP, 0, 16, false, false, QTV>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, pp);
+		else
+			hipLaunchKernelGGL((score_kernel<KP, 0, 4, false, false, QTV>), dim3(p.n_wg), dim3(256), 2 * Cfg::TILE_BYTES, st, pp);
+	}
 	ANNCUR_LAUNCH_OK();
 	EV(1);
 	// 2. tau = k-th largest group maximum (beside it: the first chunk of the exact scan, anncur_eval_topk only)
@@ -2500,9 +2506,17 @@ extern "C" size_t anncur_eval_fused_workspace_bytes(int64_t Q, int64_t I, int32_
 	return P.ok ? P.total : 0;
 }
 
+extern "C" int anncur_eval_fused_ex(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *Et_hint, const void *A, int a_dtype, int64_t lda,
+									int64_t Q, int64_t I, int32_t Kp, int32_t k, float *out_val, int32_t *out_idx, float *err_sq, float *norm_sq,
+									void *workspace, size_t workspace_bytes, void *stream);
 extern "C" int anncur_eval_fused(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *A, int a_dtype, int64_t lda,
 								 int64_t Q, int64_t I, int32_t Kp, int32_t k, float *out_val, int32_t *out_idx, float *err_sq, float *norm_sq,
 								 void *workspace, size_t workspace_bytes, void *stream) {
+	return anncur_eval_fused_ex(X, ldx, Et, lde, nullptr, A, a_dtype, lda, Q, I, Kp, k, out_val, out_idx, err_sq, norm_sq, workspace, workspace_bytes, stream);
+}
+extern "C" int anncur_eval_fused_ex(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *Et_hint, const void *A, int a_dtype, int64_t lda,
+									int64_t Q, int64_t I, int32_t Kp, int32_t k, float *out_val, int32_t *out_idx, float *err_sq, float *norm_sq,
+									void *workspace, size_t workspace_bytes, void *stream) {
 	ANNCUR_REQUIRE(Kp == 64 || Kp == 128 || Kp == 256, ANNCUR_E_UNSUPPORTED, "eval_fused: Kp must be 64, 128 or 256 (got %d): use anncur_score_topk + anncur_approx_error_packed", Kp);
 	ANNCUR_REQUIRE(a_dtype == ANNCUR_BF16 && A && (lda % 8) == 0 && ((uintptr_t)A % 16) == 0 && lda >= I, ANNCUR_E_UNSUPPORTED,
 				   "eval_fused: the exact matrix must be bf16 with 16-byte aligned rows (lda a multiple of 8): use anncur_score_topk + anncur_approx_error(_packed) otherwise");
@@ -2522,7 +2536,7 @@ extern "C" int anncur_eval_fused(const void *X, int64_t ldx, const void *Et, int
 														(const void *)((const uint16_t *)A + I_full), a_dtype, lda, Q, I - I_full, Kp, err_sq, norm_sq, stream);
 		if (rc != ANNCUR_OK) return rc;
 	}
-	const EvalArgs ea{(const uint16_t *)A, lda, err_sq, norm_sq};
+	const EvalArgs ea{(const uint16_t *)A, lda, err_sq, norm_sq, (const uint16_t *)Et_hint};
 	return score_topk_impl(X, ldx, Et, lde, Q, I, Kp, k, out_val, out_idx, workspace, workspace_bytes, stream, nullptr, 0, nullptr, nullptr, &ea);
 }
 

@@ -250,7 +250,7 @@ class CURApprox(object):
 			raise NotImplementedError("This is not designed to give good approx of rows as C and U matrix are multiplied together. Build index w/ approx_preference = rows instead.")
 		X, A = self._to_dev(sparse_rows), self._to_dev(exact_rows)
 		if (self.compute_dtype == "bf16" and self._Etp is not None and ops.eval_fused_ok(self._Etp.shape[1], A, X.shape[0], self.m, k)):
-			return ops.eval_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, A, self.m, k)
+			return ops.eval_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, A, self.m, k, hint=self._Etp_sorted)
 		approx = self.topk_in_row_device(sparse_rows, k)
 		err, nrm = self.approx_error_rows(sparse_rows, exact_rows)
 		return approx, err, nrm
@@ -336,7 +336,7 @@ class CURRowIndex(object):
 		with torch.cuda.stream(side):
 			exact = ops.rowwise_topk(exact_rows, k, out=(ev, ei))
 		if self.compute_dtype == "bf16" and self._Etp is not None and ops.eval_fused_ok(self._Etp.shape[1], exact_rows, Q, self.m, k_retvr):
-			approx, err, nrm = ops.eval_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, exact_rows, self.m, k_retvr)
+			approx, err, nrm = ops.eval_fused(ops.pack_bf16(X, self._Etp.shape[1]), self._Etp, exact_rows, self.m, k_retvr, hint=self._Etp_sorted)
 		else:
 			approx = self.topk(X, k_retvr)
 			err, nrm = self.approx_error_rows(X, exact_rows)

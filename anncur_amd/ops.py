@@ -288,9 +288,10 @@ def eval_fused_ok(Kp, A_exact, Q, I, k):
 
 
 @_on_device
-def eval_fused(Xp, Etp, A_exact, n_items, k, return_fallbacks=False):
+def eval_fused(Xp, Etp, A_exact, n_items, k, return_fallbacks=False, hint=None):
 	"""One sweep for a grid cell of entry point A (reference: eval/run_retrieval_eval_wrt_exact_crossenc.py:84,106,146-147):
-	(TopK of S_hat = Xp . Etp^T, err_sq [Q], norm_sq [Q]).  Xp [Q x Kp], Etp [ceil32(I) x Kp] packed bf16 in ITEM order, A_exact [Q x I] bf16."""
+	(TopK of S_hat = Xp . Etp^T, err_sq [Q], norm_sq [Q]).  Xp [Q x Kp], Etp [ceil32(I) x Kp] packed bf16 in ITEM order, A_exact [Q x I] bf16.
+	hint: a copy of Etp's rows in descending-norm order (same shape): the prepass samples ITS leading tiles -- a tighter first threshold, same results."""
 	_dev(Xp, Etp, A_exact)
 	Q, Kp = Xp.shape
 	if Xp.dtype != torch.bfloat16 or Etp.dtype != torch.bfloat16 or Etp.shape[1] != Kp or not Etp.is_contiguous() or Etp.shape[0] < -(-n_items // 32) * 32 \
@@ -306,8 +307,12 @@ def eval_fused(Xp, Etp, A_exact, n_items, k, return_fallbacks=False):
 	idx = torch.empty((Q, k), dtype=torch.int32, device=Xp.device)
 	err = torch.empty(Q, dtype=torch.float32, device=Xp.device)
 	nrm = torch.empty(Q, dtype=torch.float32, device=Xp.device)
-	check(lib.anncur_eval_fused(_p(Xp), _ld(Xp), _p(Etp), Kp, _p(A_exact), _dt(A_exact), _ld(A_exact), Q, n_items, Kp, k, _p(val), _p(idx), _p(err), _p(nrm),
-								_p(ws), nbytes, _stream()), "eval_fused")
+	if hint is not None:
+		_dev(hint)
+		if hint.dtype != torch.bfloat16 or tuple(hint.shape) != tuple(Etp.shape) or not hint.is_contiguous():
+			raise ValueError("eval_fused: hint must be a contiguous bf16 copy of Etp's rows (same shape)")
+	check(lib.anncur_eval_fused_ex(_p(Xp), _ld(Xp), _p(Etp), Kp, _p(hint) if hint is not None else None, _p(A_exact), _dt(A_exact), _ld(A_exact), Q, n_items, Kp, k,
+								   _p(val), _p(idx), _p(err), _p(nrm), _p(ws), nbytes, _stream()), "eval_fused")
 	if return_fallbacks:
 		return TopK(val, idx), err, nrm, ws[:4].view(torch.int32)
 	return TopK(val, idx), err, nrm

@@ -137,6 +137,13 @@ size_t anncur_eval_fused_workspace_bytes(int64_t Q, int64_t I, int32_t Kp, int32
 int anncur_eval_fused(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *A, int a_dtype, int64_t lda,
                       int64_t Q, int64_t I, int32_t Kp, int32_t k, float *out_val, int32_t *out_idx, float *err_sq, float *norm_sq,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* The same with a HINT for the first threshold (round 5): Et_hint = a copy of Et's rows in any other order, same shape and pitch -- CURApprox
+ * keeps one in descending-norm order for anncur_score_topk_ex (ANNCUR_TOPK_LEADING_SAMPLE) -- whose LEADING tiles the prepass samples instead of a
+ * strided sample of Et: with the largest-norm items in the sample the first threshold is tighter and the sweep keeps fewer candidates.  The
+ * sweep itself runs on Et (item order).  Same results bit for bit (any subset of the items yields a valid threshold); null = anncur_eval_fused. */
+int anncur_eval_fused_ex(const void *X, int64_t ldx, const void *Et, int64_t lde, const void *Et_hint, const void *A, int a_dtype, int64_t lda,
+                         int64_t Q, int64_t I, int32_t Kp, int32_t k, float *out_val, int32_t *out_idx, float *err_sq, float *norm_sq,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* a7/a8: exact row-wise top-k of a stored matrix (HBM-streaming scan) ---------------
  *   torch.topk(S, k, dim=1)                  eval/matrix_approx_zeshel.py:106,126

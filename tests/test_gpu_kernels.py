@@ -224,6 +224,18 @@ def test_eval_fused_equals_the_two_kernel_route(ops, Q, I, K, k):
 	torch.testing.assert_close(nrm[rows.cuda()].double().cpu(), (A64 ** 2).sum(1), rtol=1e-4, atol=1e-6)
 	plan_codes = ops.fused_plan(Q, I, Kp, k)   # (the public plan is untouched by the new entry point)
 	assert 6 not in plan_codes["stage_pred"]
+	# round 5, anncur_eval_fused_ex: the first threshold sampled from the LEADING tiles of a norm-ordered copy of E^T (CURApprox's hint copy) --
+	# and from the worst copy there is, norms ascending: the same results bit for bit (any subset of the items yields a valid threshold)
+	order = torch.argsort(E.float().norm(dim=0), descending=True)
+	for perm in (order, order.flip(0)):
+		hint = torch.zeros_like(Etp); hint[:I] = Etp[:I][perm.cuda()]
+		(tk3, err3, nrm3, nfb3) = ops.eval_fused(Xp, Etp, A, I, k, return_fallbacks=True, hint=hint)
+		torch.cuda.synchronize()
+		assert torch.equal(tk3.values, tk.values) and torch.equal(torch.sort(tk3.indices, 1).values, torch.sort(tk.indices, 1).values)
+		torch.testing.assert_close(err3, err, rtol=2e-5, atol=1e-6)
+		torch.testing.assert_close(nrm3, nrm, rtol=2e-5, atol=1e-6)
+	with pytest.raises(ValueError):
+		ops.eval_fused(Xp, Etp, A, I, k, hint=Etp[:32])
 	# unsupported operands are refused loudly, not routed elsewhere
 	with pytest.raises(Exception):
 		ops.eval_fused(Xp, Etp, A.float(), I, k)

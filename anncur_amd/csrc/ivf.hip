@@ -347,6 +347,13 @@ __global__ __launch_bounds__(256) void ivf_map_ids_kernel(const int32_t *__restr
 //   tiles: tile_start over (list, 128-pair tile, 128-vector tile) for bf16 (64 x 64 for fp32), workgroup b takes tile xcd_remap(b, n_tiles):
 //     the tiles of a list run on ONE XCD around the same time and share the list's vectors and its pairs' queries in that L2 (round 4:
 //     consecutive tiles on eight XCDs, every operand tile from beyond L2 -- 2.7 GB per search).
+// (scripts/placement_sweep.sh: ANNCUR_PLACEMENT_PAD = 1..n extra instructions in front of the tile loop -- a result that depends on code placement
+//  is a missing wait state; the tile kernel's fragment reads and row loads are inline asm with counted waits)
+#ifdef ANNCUR_PLACEMENT_PAD
+#define IVF_PAD_HERE() asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(ANNCUR_PLACEMENT_PAD) : "memory")
+#else
+#define IVF_PAD_HERE() do { } while (0)
+#endif
 constexpr int IVF_MAX_NLIST_LDS = 8192;   // 2 x nlist words of LDS in the sort kernels
 constexpr int IVF_RAGGED_MAX_K = 128;    // anncur_rowwise_topk_ragged: the wave-per-row scan (WSEL_K of wave_select.hpp)
 
@@ -693,6 +700,7 @@ __global__ __launch_bounds__(256, 2) void ivf_tile128_kernel(const uint16_t *__r
 	for (int i = 0; i < 4; ++i) { T128_PIECE(abase, aoff, 0u, i); T128_PIECE(bbase, boff, (uint32_t)T128_TILE_BYTES, i); }
 	T128_SYNC();
 
+	IVF_PAD_HERE();
 	for (;;) {
 		const int32_t t_next = t + wpx;
 		const bool has_next = t_next < t_end;   // (uniform)

@@ -12,13 +12,15 @@ if [ "$mode" = build ]; then
   for i in $(seq 1 $n); do
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include -Wall -Wno-unused-function -DANNCUR_PLACEMENT_PAD=$i \
         -c $root/anncur_amd/csrc/score_fused.hip -o /tmp/pad_score_fused_$i.o && \
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/libanncur_hip_pad$i.so $lib/misc.o $lib/topk.o $lib/gemm.o $lib/gemm64.o $lib/ivf.o /tmp/pad_score_fused_$i.o ) &
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include -Wall -Wno-unused-function -DANNCUR_PLACEMENT_PAD=$i \
+        -c $root/anncur_amd/csrc/ivf.hip -o /tmp/pad_ivf_$i.o && \
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib/libanncur_hip_pad$i.so $lib/misc.o $lib/topk.o $lib/gemm.o $lib/gemm64.o /tmp/pad_ivf_$i.o /tmp/pad_score_fused_$i.o ) &
     if [ $((i % 4)) = 0 ]; then wait; fi
   done
   wait; ls -la $lib/libanncur_hip_pad*.so
 else
   for i in $(seq 1 $n); do
     echo "== pad $i"
-    ANNCUR_LIB=$lib/libanncur_hip_pad$i.so python -m pytest $root/tests/test_gpu_kernels.py $root/tests/test_gpu_random_shapes.py -m gpu -x -q -k "fused or wide or cfg or sweep" 2>&1 | tail -2
+    ANNCUR_LIB=$lib/libanncur_hip_pad$i.so python -m pytest $root/tests/test_gpu_kernels.py $root/tests/test_gpu_random_shapes.py $root/tests/test_gpu_entrypoints.py -m gpu -x -q -k "fused or wide or cfg or sweep or ivf" 2>&1 | tail -2
   done
 fi

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void ivf_tile64_packed_kernel(const T *__restr
 	__shared__ uint32_t orow[GT];
 	__shared__ int32_t meta[2];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-	const int32_t n_tiles = tile_start[nlist];
+	const int32_t n_tiles = min(tile_start[nlist], (int32_t)gridDim.x);   // (the grid is the caller's bound on the tile count)
 	if ((int32_t)blockIdx.x >= n_tiles) return;   // (uniform: before any barrier)
 	int32_t l, qt, vt;
 	ivf_find_tile(tile_start, nlist, offsets, GT, ivf_xcd_remap((int)blockIdx.x, n_tiles), meta, l, qt, vt);
@@ -576,9 +576,9 @@ __device__ __forceinline__ void t128_read(u32x4g &dst, uint32_t addr, int off) {
 }
 // tile id -> descriptor (one thread per tile; tile_start lives in L2)
 __global__ __launch_bounds__(256) void ivf_tile_desc_kernel(const int32_t *__restrict__ tile_start, int32_t nlist, const int32_t *__restrict__ offsets,
-															 const int32_t *__restrict__ pair_off, int32_t T, T128Desc *__restrict__ desc) {
+															 const int32_t *__restrict__ pair_off, int32_t T, int32_t max_tiles, T128Desc *__restrict__ desc) {
 	const int32_t t = (int32_t)(blockIdx.x * 256 + threadIdx.x);
-	if (t >= tile_start[nlist]) return;
+	if (t >= min(tile_start[nlist], max_tiles)) return;   // (max_tiles: the caller's bound = the descriptor array's length; a bound that is too small loses tiles, never memory)
 	int32_t lo = 0, hi = nlist;   // largest l with tile_start[l] <= t (empty lists repeat their start: the search lands past them)
 	while (hi - lo > 1) {
 		const int32_t mid = (lo + hi) >> 1;
@@ -596,13 +596,13 @@ __global__ __launch_bounds__(256) void ivf_tile_desc_kernel(const int32_t *__res
 
 __global__ __launch_bounds__(256, 2) void ivf_tile128_kernel(const uint16_t *__restrict__ Xs, int64_t ldx, int32_t dp, const uint16_t *__restrict__ Q, int64_t ldq,
 															  const int32_t *__restrict__ pair_q, const uint32_t *__restrict__ pair_out,
-															  const int32_t *__restrict__ tile_start, int32_t nlist, const T128Desc *__restrict__ desc,
+															  const int32_t *__restrict__ tile_start, int32_t nlist, int32_t max_tiles, const T128Desc *__restrict__ desc,
 															  float *__restrict__ S) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char t128_smem[];   // the two stages at offset 0, then the tiles' rows
 	int32_t *rows_lds = reinterpret_cast<int32_t *>(t128_smem + T128_LDS_BYTES);   // generation g: query rows at [g * 256, +128), output offsets at [g * 256 + 128, +128)
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
 	// ---- this workgroup's tiles: its XCD's contiguous share of [0, n_tiles), strided by the workgroups of the XCD (gridDim.x is a multiple of 8)
-	const int32_t n_tiles = tile_start[nlist];
+	const int32_t n_tiles = min(tile_start[nlist], max_tiles);
 	const int32_t xcd = (int32_t)(blockIdx.x & 7), lw = (int32_t)(blockIdx.x >> 3), wpx = (int32_t)(gridDim.x >> 3);
 	const int32_t share = n_tiles >> 3, rem = n_tiles & 7;
 	const int32_t t_begin = xcd < rem ? xcd * (share + 1) : rem * (share + 1) + (xcd - rem) * share, t_end = t_begin + share + (xcd < rem ? 1 : 0);
@@ -924,12 +924,12 @@ extern "C" int anncur_ivf_search_grouped(const void *Xs, int dtype, int64_t ldx,
 			const int rc = anncur_ensure_dyn_lds((const void *)ivf_tile128_kernel, T128_LDS_TOTAL);
 			if (rc != ANNCUR_OK) return rc;
 			T128Desc *desc = reinterpret_cast<T128Desc *>(wb + w.desc);
-			hipLaunchKernelGGL(ivf_tile_desc_kernel, dim3((unsigned)ceil_div64(max_tiles, 256)), dim3(256), 0, st, tile_start, nlist, offsets, pair_off, T128, desc);
+			hipLaunchKernelGGL(ivf_tile_desc_kernel, dim3((unsigned)ceil_div64(max_tiles, 256)), dim3(256), 0, st, tile_start, nlist, offsets, pair_off, T128, (int32_t)max_tiles, desc);
 			int64_t wgs = 2 * (int64_t)anncur_num_cu();   // two resident workgroups per CU walk the tiles
 			wgs = (wgs + 7) & ~(int64_t)7;
 			if (wgs > ((max_tiles + 7) & ~(int64_t)7)) wgs = (max_tiles + 7) & ~(int64_t)7;
 			hipLaunchKernelGGL(ivf_tile128_kernel, dim3((unsigned)wgs), dim3(256), T128_LDS_TOTAL, st, (const uint16_t *)Xs, ldx, dp, (const uint16_t *)Q, ldq,
-							   pair_q, pair_out, tile_start, nlist, desc, S);
+							   pair_q, pair_out, tile_start, nlist, (int32_t)max_tiles, desc, S);
 		} else if (dtype == ANNCUR_F32)
 			hipLaunchKernelGGL(ivf_tile64_packed_kernel<float>, dim3((unsigned)max_tiles), dim3(256), 0, st, (const float *)Xs, ldx, dp, offsets, (const float *)Q, ldq, pair_q,
 							   pair_out, pair_off, tile_start, nlist, S);

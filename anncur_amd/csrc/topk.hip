@@ -459,6 +459,29 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	wsel_finish<WS_CAP, HP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
 }
 
+// SHORT rows (round 5: I <= WS_CAP = 1024 -- the IVF probe's [queries x nlist] centroid scores, the k-means assignment, small matrices): the
+// whole row goes into the wave's candidate buffer, then the final select + sort of the stream kernel (wsel_finish): no seed, no prefetch
+// set, no staging -- the stream kernel spent ~2 500 instructions per 316-element row on its loop's fixed parts (42 us per 10 000 rows).
+// Same result: exact, score descending, ties by ascending index, NaN never selected, -inf an ordinary candidate, (-inf, -1) padding.
+template <typename T, int E = 2>   // E: keys per lane of the final sort (k <= 64 E)
+__global__ __launch_bounds__(256) void rowwise_topk_short_kernel(const T *__restrict__ A, int64_t Q, int32_t I, int64_t lda, uint32_t k,
+																  float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+	if (q >= Q) return;
+	WaveSel w = wsel_init<WS_CAP>(smem + wave * WaveSelLayout<WS_CAP>::BYTES);
+	constexpr int HP = sizeof(T) == 2 ? 2 : 4;
+	const T *row = A + q * lda;
+	for (int32_t i0 = 0; i0 < I; i0 += WAVE) {
+		const int32_t i = i0 + lane;
+		const float v = i < I ? load_as_f32<T>(row + i) : 0.f;
+		wsel_push(w, i < I && v == v, f32_sortable(v), 0xffffffffu - (uint32_t)i);
+	}
+	__builtin_amdgcn_wave_barrier();
+	wsel_finish<WS_CAP, HP, E>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+}
+
 // ------------------------------------------------------------------ k-th largest VALUE of short fp32 rows, one wave per row
 // (the fused path's threshold step: rows of a few hundred group maxima).  The row's sortable keys go to a wave-private LDS
 // array; MSB-first radix select with 8-bit digits (wsel_kth: four histogram passes instead of 32 bit-by-bit ballot rounds).
@@ -786,6 +809,19 @@ extern "C" int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t 
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (getenv("ANNCUR_DEBUG_BLOCK_SCAN")) wave_scan = false;
 #endif
+	if (wave_scan && I <= (int64_t)WS_CAP) {   // short rows: the whole row into the wave's buffer, then the final select + sort
+		const size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
+		const unsigned grid = (unsigned)ceil_div64(Q, 4);
+		if (dtype == ANNCUR_F32) {
+			if (k <= 64) hipLaunchKernelGGL((rowwise_topk_short_kernel<float, 1>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, (int32_t)I, lda, (uint32_t)k, out_val, out_idx);
+			else hipLaunchKernelGGL((rowwise_topk_short_kernel<float, 2>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, (int32_t)I, lda, (uint32_t)k, out_val, out_idx);
+		} else {
+			if (k <= 64) hipLaunchKernelGGL((rowwise_topk_short_kernel<uint16_t, 1>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, (int32_t)I, lda, (uint32_t)k, out_val, out_idx);
+			else hipLaunchKernelGGL((rowwise_topk_short_kernel<uint16_t, 2>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, (int32_t)I, lda, (uint32_t)k, out_val, out_idx);
+		}
+		ANNCUR_LAUNCH_OK();
+		return ANNCUR_OK;
+	}
 	if (wave_scan) {
 		size_t lds = 4 * (size_t)WaveSelLayout<WS_CAP>::BYTES;
 #ifdef ANNCUR_TIMING_EXPERIMENTS

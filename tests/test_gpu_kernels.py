@@ -75,7 +75,8 @@ def test_gather_and_convert(ops):
 # ------------------------------------------------------------------ exact scan
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Q,I,k", [(3, 1, 1), (5, 7, 7), (9, 100, 10), (17, 5000, 100), (4, 10031, 64), (6, 40000, 1000),
-								  (2, 70001, 2048), (33, 4097, 129), (3, 20000, 513)])
+								  (2, 70001, 2048), (33, 4097, 129), (3, 20000, 513),
+								  (1001, 316, 17), (7, 1024, 128), (7, 1025, 128), (5, 1000, 129), (130, 64, 64), (9, 65, 1)])   # (short rows: rowwise_topk_short_kernel up to 1024 x 128)
 def test_rowwise_topk_matches_torch(ops, dtype, Q, I, k):
 	A = torch.randn(Q, I, generator=_g(Q * 1000 + I)).to(dtype)
 	# torch ties on bf16 are arbitrary: compare values exactly, and index SETS above the k-th value

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 		}                                                                                                                       \
 		scnt = 0;                                                                                                               \
 		__builtin_amdgcn_wave_barrier();                                                                                        \
-		if (w.cnt > trig) wsel_compact_call<WS_CAP, HP, true>(w, k, tie_limit);                                                 \
+		if (w.cnt > trig) wsel_compact_call<WS_CAP, HP, true>(w, k, tie_limit, wsel_base16(w.tau));                             \
 	}
 #define SCAN_STEP(d, FULL, POS)                                                                                                 \
 	{                                                                                                                           \
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 			if ((int64_t)c >= tail0 && (int64_t)c < I) cqrow[j] = row[c];
 		}
 	}
-	wsel_finish<WS_CAP, HP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k);
+	wsel_finish<WS_CAP, HP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k, nullptr, wsel_base16(w.tau));
 }
 
 // SHORT rows (round 5: I <= WS_CAP = 1024 -- the IVF probe's [queries x nlist] centroid scores, the k-means assignment, small matrices): the

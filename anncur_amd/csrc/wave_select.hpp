@@ -99,9 +99,9 @@ __device__ __forceinline__ void wsel_find_bin(const uint32_t *hist, uint32_t lan
 // PASSES < 4: the keys are known to be zero below bit 32 - 8*PASSES (bf16 scores: 2 passes).
 template <bool GATED, int PASSES = 4>
 __device__ __forceinline__ uint32_t wsel_kth(const WaveSel &w, const uint32_t *key, uint32_t n, uint32_t k, uint32_t &need_out,
-											  const uint32_t *gate, uint32_t gate_val) {
+											  const uint32_t *gate, uint32_t gate_val, uint32_t *in_bin_out = nullptr) {
 	const uint32_t lane = (uint32_t)lane_id();
-	uint32_t prefix = 0, need = k;
+	uint32_t prefix = 0, need = k, hb_last = 0;
 	for (int pass = 0; pass < PASSES; ++pass) {
 		const int shift = 24 - 8 * pass;
 #pragma unroll
@@ -122,10 +122,43 @@ __device__ __forceinline__ uint32_t wsel_kth(const WaveSel &w, const uint32_t *k
 		wsel_find_bin(w.hist, lane, need, bin, a, hb);
 		need -= a;
 		prefix = (prefix << 8) | bin;
+		hb_last = hb;
 		__builtin_amdgcn_wave_barrier();
 	}
 	need_out = need;
+	if (in_bin_out) *in_bin_out = hb_last;   // keys (passing the gate) whose significant bits equal the returned key's
 	return prefix << (32 - 8 * PASSES);
+}
+
+// ONE pass for keys with 16 significant bits (bf16 scores) that are known to lie at or above `base16` (the 16-bit prefix of the threshold every
+// candidate of an in-order stream has passed): the digit is (key >> 16) - base16, the last bin collects everything 255 or more above the base.
+// Returns false -- nothing decided -- when the k-th largest key falls into that last bin (keys spread over more than 255 bf16 values above the
+// threshold: the caller takes the two fixed-digit passes).  Round 5: candidates above a threshold share their sign /
+// exponent byte, so the first of the two fixed-digit passes told next to nothing and serialised its atomics on one or two LDS words.
+__device__ __forceinline__ bool wsel_kth16_based(const WaveSel &w, const uint32_t *key, uint32_t n, uint32_t k, uint32_t base16, uint32_t &T,
+												  uint32_t &need_out, uint32_t &in_bin_out) {
+	const uint32_t lane = (uint32_t)lane_id();
+#pragma unroll
+	for (int i = 0; i < 4; ++i) w.hist[lane * 4 + i] = 0;
+	__builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+	for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+		const uint32_t j = j0 + lane;
+		if (j < n) {
+			const uint32_t x = key[j] >> 16;
+			const uint32_t d = x >= base16 ? x - base16 : 0u;   // (keys below the base do not occur; they would count as the base)
+			atomicAdd(&w.hist[d < 255u ? d : 255u], 1u);
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	uint32_t bin, a, hb;
+	wsel_find_bin(w.hist, lane, k, bin, a, hb);
+	__builtin_amdgcn_wave_barrier();
+	if (bin == 255u) return false;
+	T = (base16 + bin) << 16;
+	need_out = k - a;
+	in_bin_out = hb;
+	return true;
 }
 
 // The same for keys that crowd into a narrow range (candidates of the fused sweep: every score is >= the sweep's threshold, so the
@@ -174,23 +207,29 @@ __device__ __forceinline__ uint32_t wsel_kth_ranged(const WaveSel &w, const uint
 // index, as long as they fit below `tie_limit`; the buffer then holds >= k entries and the threshold is the k-th SCORE,
 // which is all an in-order stream needs (later elements lose score ties).  The final call must be exact.
 // RANGED: the keys are expected in a narrow range (wsel_kth_ranged; full 32-bit keys only).
-template <int HI_PASSES = 4, bool KEEP_TIES = false, bool RANGED = false>
-__device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t tie_limit = 0) {
+// BASED (HI_PASSES = 2 only): every key is known to be at or above base16 << 16 (wsel_kth16_based: one pass where that decides).
+template <int HI_PASSES = 4, bool KEEP_TIES = false, bool RANGED = false, bool BASED = false>
+__device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t tie_limit = 0, uint32_t base16 = 0) {
 	static_assert(!RANGED || HI_PASSES == 4, "the ranged radix select takes whole keys");
+	static_assert(!BASED || HI_PASSES == 2, "the based select takes 16-bit keys");
 	const uint32_t lane = (uint32_t)lane_id();
 	const uint32_t n = w.cnt;
 	__builtin_amdgcn_wave_barrier();
 	uint32_t need, need2;
 	// with HI_PASSES < 4 only the top 8*HI_PASSES key bits are significant (and the low bits of all keys of one sign agree)
 	constexpr uint32_t M = HI_PASSES >= 4 ? 0xffffffffu : (0xffffffffu << (32 - 8 * HI_PASSES));
-	uint32_t T;
-	if constexpr (RANGED) T = wsel_kth_ranged(w, w.whi, n, k, need);
-	else T = wsel_kth<false, HI_PASSES>(w, w.whi, n, k, need, w.whi, 0u);
-	uint32_t cnt_eq = 0;
+	uint32_t T = 0, cnt_eq = 0;   // cnt_eq: keys that tie with the k-th score = the keys in the last digit's bin (round 5: a pass over the buffer counted them)
+	if constexpr (RANGED) {
+		T = wsel_kth_ranged(w, w.whi, n, k, need);
 #pragma unroll 4
-	for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
-		const uint32_t j = j0 + lane;
-		cnt_eq += (uint32_t)__popcll(__ballot(j < n && (w.whi[j] & M) == T));
+		for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+			const uint32_t j = j0 + lane;
+			cnt_eq += (uint32_t)__popcll(__ballot(j < n && (w.whi[j] & M) == T));
+		}
+	} else {
+		bool done = false;
+		if constexpr (BASED) done = wsel_kth16_based(w, w.whi, n, k, base16, T, need, cnt_eq);   // (uniform)
+		if (!done) T = wsel_kth<false, HI_PASSES>(w, w.whi, n, k, need, w.whi, 0u, &cnt_eq);
 	}
 	uint32_t Tlo = 0;  // ties at the k-th score: the `need` smallest indices (largest lo) win
 	if (cnt_eq > need && !(KEEP_TIES && (k - need) + cnt_eq <= tie_limit)) {
@@ -215,42 +254,56 @@ __device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t ti
 		const unsigned long long m = __ballot(sel);
 		__builtin_amdgcn_wave_barrier();
 		if (sel) {
-			const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 			w.whi[pos] = h;
 			w.wlo[pos] = l;
-			const uint64_t key = ((uint64_t)h << 32) | l;
-			if (key < kmin) kmin = key;
+			if constexpr (!KEEP_TIES) {
+				const uint64_t key = ((uint64_t)h << 32) | l;
+				if (key < kmin) kmin = key;
+			}
 		}
 		base += (uint32_t)__popcll(m);
 	}
-	// smallest kept key = smallest hi, then the smallest lo among the lanes that hold it (two DPP reductions, no shuffles)
-	const uint32_t min_hi = wave_reduce<DppMin>((uint32_t)(kmin >> 32));
-	const uint32_t min_lo = wave_reduce<DppMin>((uint32_t)(kmin >> 32) == min_hi ? (uint32_t)kmin : 0xffffffffu);
 	w.cnt = base;  // == k (or k + extra score ties under KEEP_TIES)
-	w.tau_hi = min_hi;  // the smallest kept key: exactly the k-th best in exact mode
-	w.tau_lo = min_lo;
+	if constexpr (KEEP_TIES) {
+		// mid-stream: the threshold an in-order stream needs is the k-th SCORE, and that is T itself -- a key that ties with it is always kept,
+		// so the smallest kept key's score bits are T (round 5: two wave reductions over the kept keys found the same value)
+		w.tau_hi = T;
+		w.tau_lo = Tlo;
+	} else {
+		// smallest kept key = smallest hi, then the smallest lo among the lanes that hold it (two DPP reductions, no shuffles)
+		const uint32_t min_hi = wave_reduce<DppMin>((uint32_t)(kmin >> 32));
+		const uint32_t min_lo = wave_reduce<DppMin>((uint32_t)(kmin >> 32) == min_hi ? (uint32_t)kmin : 0xffffffffu);
+		w.tau_hi = min_hi;  // the smallest kept key: exactly the k-th best in exact mode
+		w.tau_lo = min_lo;
+	}
 	w.tau = f32_unsortable(w.tau_hi);
 	__builtin_amdgcn_wave_barrier();
 }
+
+// base16 of an in-order stream whose candidates all passed `v > tau` (or every element, while tau is -inf): the 16-bit key prefix of tau --
+// a bf16 score above tau has a key prefix at or above it.
+__device__ __forceinline__ uint32_t wsel_base16(float tau) { return tau > -INFINITY ? f32_sortable(tau) >> 16 : 0u; }
 
 // Out-of-line compaction for kernels that reach it from many unrolled sites (the scan: one inline copy is ~6 KB of code, a
 // dozen of them no longer fit the instruction cache).  The selector's state crosses the call as plain scalars: the LDS offset
 // of the wave's region going in, (count, threshold key) coming back through the histogram words.
 template <int CAP, int HI_PASSES, bool KEEP_TIES>
-__device__ __attribute__((noinline)) void wsel_compact_outlined(uint32_t lds_off, uint32_t n, uint32_t k, uint32_t tie_limit) {
+__device__ __attribute__((noinline)) void wsel_compact_outlined(uint32_t lds_off, uint32_t n, uint32_t k, uint32_t tie_limit, uint32_t base16) {
 	WaveSel w;
 	w.whi = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)lds_off;
 	w.wlo = w.whi + CAP;
 	w.sort_buf = reinterpret_cast<uint2 *>(w.wlo + CAP);
 	w.hist = reinterpret_cast<uint32_t *>(w.sort_buf + 128);
 	w.cnt = n; w.tau_hi = 0; w.tau_lo = 0; w.tau = 0.f;
-	wsel_compact<HI_PASSES, KEEP_TIES>(w, k, tie_limit);
+	wsel_compact<HI_PASSES, KEEP_TIES, false, (HI_PASSES == 2)>(w, k, tie_limit, base16);
 	if (lane_id() == 0) { w.hist[0] = w.cnt; w.hist[1] = w.tau_hi; w.hist[2] = w.tau_lo; }
 	__builtin_amdgcn_wave_barrier();
 }
+// base16: see wsel_compact (16-bit keys only; 0 = nothing known: the fixed-digit passes run after one wasted pass at most)
 template <int CAP, int HI_PASSES, bool KEEP_TIES>
-__device__ __forceinline__ void wsel_compact_call(WaveSel &w, uint32_t k, uint32_t tie_limit = 0) {
-	wsel_compact_outlined<CAP, HI_PASSES, KEEP_TIES>((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)w.whi, w.cnt, k, tie_limit);
+__device__ __forceinline__ void wsel_compact_call(WaveSel &w, uint32_t k, uint32_t tie_limit = 0, uint32_t base16 = 0) {
+	wsel_compact_outlined<CAP, HI_PASSES, KEEP_TIES>((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)w.whi, w.cnt, k, tie_limit, base16);
 	__builtin_amdgcn_wave_barrier();
 	w.cnt = __builtin_amdgcn_readfirstlane(w.hist[0]);
 	w.tau_hi = __builtin_amdgcn_readfirstlane(w.hist[1]);
@@ -337,10 +390,10 @@ __device__ __forceinline__ void wave_sort_desc(uint32_t (&hi)[E], uint32_t (&lo)
 // Reduce to the k best, sort them, write the output row.  Fewer than k candidates -> (-inf, -1) padding.
 // E = keys per lane of the final sort (k <= 64 E).
 template <int OUTLINED_CAP = 0, int HI_PASSES = 4, int E = 2, bool RANGED = false>
-__device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx, const int32_t *__restrict__ remap = nullptr) {
+__device__ __forceinline__ void wsel_finish(WaveSel &w, uint32_t k, float *out_val, int32_t *out_idx, const int32_t *__restrict__ remap = nullptr, uint32_t base16 = 0) {
 	const int lane = lane_id();
 	if (w.cnt > k) {
-		if constexpr (OUTLINED_CAP > 0) wsel_compact_call<OUTLINED_CAP, HI_PASSES, false>(w, k);
+		if constexpr (OUTLINED_CAP > 0) wsel_compact_call<OUTLINED_CAP, HI_PASSES, false>(w, k, 0, base16);
 		else wsel_compact<HI_PASSES, false, RANGED>(w, k);
 	}
 	__builtin_amdgcn_wave_barrier();

@@ -389,7 +389,10 @@ def run_config(args, cfg_name, ctx, light=False):
 	# launch) the retrieval absorbs whatever share of the chip the scan leaves it, and the optimum moved to a larger scan partition -- same box, steps
 	# after the sustained loop / sustained: 96 CUs 0.900 / 0.909 ms, 128 0.878-0.885 / 0.887-0.889, 160 0.852-0.865 / 0.869-0.886, 192 0.872 / 0.877,
 	# 224 0.986 / 0.994 (one retrieval stream: 0.867 / 0.870 at 128, 0.878 / 0.883 at 160, 0.953 at 192); --scan-mode side 0.959 / 0.955.
-	scan_cus = args.scan_cus if args.scan_cus else (160 if Kp <= 256 else 64)
+	# Late round 5: the scan's selector got cheaper (one histogram pass instead of two per compaction, no reductions: csrc/wave_select.hpp) -- alone
+	# it streams 7-9 % faster on a part of the chip (96 CUs 0.580 -> 0.538 ms, 128 0.470 -> 0.437) -- and the split moved back: one box, sustained,
+	# three runs each: 96 CUs 0.904-0.908 ms, 128 0.880-0.883, 160 0.908-0.915 (the scan before the change at 160: 0.891-0.893).
+	scan_cus = args.scan_cus if args.scan_cus else (128 if Kp <= 256 else 64)
 	rounds_rows = int(os.environ.get("ANNCUR_BENCH_ROUND_ROWS", "4096"))
 
 	def retrieve(workspace=None):
@@ -985,10 +988,10 @@ def main():
 	ap.add_argument("--no-ivf", action="store_true", help="skip the ivf_search side-line (the IVF-flat branch of build_flat_or_ivff_index at the hard-negative-mining size)")
 	ap.add_argument("--seed", type=int, default=0)
 	ap.add_argument("--no-overlap", action="store_true", help="exact scan and retrieval one after the other on one stream (= --scan-mode serial)")
-	ap.add_argument("--scan-cus", type=int, default=None, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD); default 160 for Kp <= 256, 64 above")
+	ap.add_argument("--scan-cus", type=int, default=None, help="CUs the exact scan streams on in --scan-mode partition (a multiple of 32: four per XCD); default 128 for Kp <= 256, 64 above")
 	ap.add_argument("--scan-mode", default=None, choices=["side", "partition", "tail", "chunks", "serial"],
 					help="how the exact scan is scheduled against the retrieval: partition = on a stream whose CU mask leaves it --scan-cus CUs, beside the "
-						 "retrieval on all of them (the default at every Kp: 160 scan CUs for Kp <= 256, 64 above); side = on a second stream "
+						 "retrieval on all of them (the default at every Kp: 128 scan CUs for Kp <= 256, 64 above); side = on a second stream "
 						 "from the start of the step, joined before the overlap count (the fallback when CU-masked streams are unavailable or a partition run died); chunks = anncur_eval_topk (row chunks forked "
 						 "beside the retrieval's latency-bound launches); serial = one stream")
 	ap.add_argument("--retr-streams", type=int, default=2, choices=[1, 2], help="--scan-mode partition: retrieval chains of consecutive steps on one stream or on two (a workspace each)")

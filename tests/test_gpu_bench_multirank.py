@@ -77,8 +77,8 @@ def test_bench_default_config_is_one_workload_at_every_n():
 	assert c4["n_gpus"] == 2 and c4["value"] == pytest.approx(2 * 6250 * 2 / (c4["ms_per_step"] * 2e-3), rel=1e-6)
 	assert c4["allgather_ms"] > 0 and c4["solo_rank0"]["value"] > 0 and c4["roofline"]["bound"] == "mfma" and c4["roofline"]["achieved"] > 0
 	assert 0.5 < c4["recall"]["recall@100"] <= 1.0
-	# the scan's placement: the CU partition at both shapes, 160 scan CUs at cfg2's shape (one sweep launch per retrieval since round 5), 64 where it is a quarter
-	assert two["scan_mode"]["used"] == "partition" and two["scan_mode"]["scan_cus"] == 160
+	# the scan's placement: the CU partition at both shapes, 128 scan CUs at cfg2's shape (one sweep launch per retrieval and the cheaper selector of round 5), 64 where it is a quarter
+	assert two["scan_mode"]["used"] == "partition" and two["scan_mode"]["scan_cus"] == 128
 	assert c4["scan_mode"]["used"] == "partition" and c4["scan_mode"]["scan_cus"] == 64
 
 
@@ -121,7 +121,7 @@ def test_bench_single_gpu_default_line_and_scan_placements():
 	outs = {mode: _n1_default_line(mode) for mode in (None, "side")}
 	d = outs[None]
 	assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "queries/s" and d["vs_baseline"] is None and d["dtype"] == "bf16"
-	assert d["scan_mode"]["used"] == "partition" and d["scan_mode"]["scan_cus"] == 160 and outs["side"]["scan_mode"]["used"] == "side"
+	assert d["scan_mode"]["used"] == "partition" and d["scan_mode"]["scan_cus"] == 128 and outs["side"]["scan_mode"]["used"] == "side"
 	assert d["value"] == pytest.approx(10000 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-6)
 	assert d["roofline"]["bound"] == "mfma" and 0.2 < d["roofline"]["frac"] < 1.0 and d["roofline_scan"]["bound"] == "hbm"
 	assert all(b == 2 for b in d["fused_plan"]["stage_pred"])          # the 16x16x32 body

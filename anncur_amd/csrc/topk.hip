@@ -254,6 +254,23 @@ template <> __device__ __forceinline__ float dyn_elem<float>(const u32x4 &v, int
 	return __uint_as_float(e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3])));
 }
 
+// element e of a 16-byte vector as fp32: e a compile-time constant / a per-lane value (select chain: the vector stays in registers)
+template <typename T> __device__ __forceinline__ float vec_elem_f32(const u32x4 &v, int e);
+template <> __device__ __forceinline__ float vec_elem_f32<uint16_t>(const u32x4 &v, int e) {
+	const uint32_t x = v[e >> 1];
+	return __uint_as_float((e & 1) ? (x & 0xffff0000u) : (x << 16));
+}
+template <> __device__ __forceinline__ float vec_elem_f32<float>(const u32x4 &v, int e) { return __uint_as_float(v[e]); }
+template <typename T> __device__ __forceinline__ float vec_elem_f32_dyn(const u32x4 &v, int e);
+template <> __device__ __forceinline__ float vec_elem_f32_dyn<uint16_t>(const u32x4 &v, int e) {
+	const int wi = e >> 1;
+	const uint32_t x = wi == 0 ? v[0] : (wi == 1 ? v[1] : (wi == 2 ? v[2] : v[3]));
+	return __uint_as_float((e & 1) ? (x & 0xffff0000u) : (x << 16));
+}
+template <> __device__ __forceinline__ float vec_elem_f32_dyn<float>(const u32x4 &v, int e) {
+	return __uint_as_float(e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3])));
+}
+
 // the two tables of ScanGather from the ascending anchor columns: one thread per vector
 __global__ __launch_bounds__(256) void gather_tables_kernel(const int32_t *__restrict__ col_idx, int n_idx, int64_t n_vec, int vec,
 															uint32_t *__restrict__ vtab) {
@@ -362,18 +379,31 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	// (Round 4, measured and dropped: a threshold-only refresh -- the k-th select without the pass that rewrites the buffer -- every 16 / 32 / 50 /
 	//  64 / 100 candidates, compaction only when the buffer runs out of room at 512: 0.578 -> 0.674 / 0.664 / 0.631 / 0.599 / 0.594 ms on 96 CUs,
 	//  0.331 -> 0.367 ... 0.335 on the chip.  The select IS the cost of a compaction, and a buffer that is not trimmed makes every later one longer.)
+	// (Round 5: the staged vector comes back in ONE ds_read_b128 and its elements are judged in registers -- a bit per element that passes --, then
+	//  every lane pushes its passing elements one per round: as many rounds as the fullest lane has hits, two or three, where the loop over the
+	//  eight element positions read LDS and ran the push path eight times.  The order of the pushes inside a batch is free: see above.)
 #define SCAN_DRAIN()                                                                                                            \
 	{                                                                                                                           \
 		__builtin_amdgcn_wave_barrier();                                                                                        \
 		const bool have = (uint32_t)lane < scnt;                                                                                \
-		const T *sv = reinterpret_cast<const T *>(stage_vec + lane);                                                            \
+		const u32x4 zero_ = {0u, 0u, 0u, 0u};                                                                                   \
+		const u32x4 sv = have ? stage_vec[lane] : zero_;                                                                        \
 		const uint32_t i0 = have ? stage_idx[lane] : 0u;                                                                        \
 		const bool nothr = !(w.tau > -INFINITY);  /* no threshold yet: every real number is a candidate, -inf included */        \
-		_Pragma("unroll 1") for (int e = 0; e < VEC; ++e) {                                                                     \
-			const float v = have ? load_as_f32<T>(sv + e) : 0.f;                                                                \
-			const bool hit = have && v == v && (v > w.tau || nothr);                                                            \
+		uint32_t pmask = 0u;                                                                                                    \
+		_Pragma("unroll") for (int e = 0; e < VEC; ++e) {                                                                       \
+			const float v = vec_elem_f32<T>(sv, e);                                                                             \
+			const bool hit = nothr ? (v == v) : (v > w.tau);   /* (NaN fails both) */                                           \
+			pmask |= hit ? (1u << e) : 0u;                                                                                      \
+		}                                                                                                                       \
+		if (!have) pmask = 0u;                                                                                                  \
+		for (;;) {                                                                                                              \
+			const bool hit = pmask != 0u;                                                                                       \
 			const unsigned long long hm = __ballot(hit);                                                                        \
-			if (hm != 0ull) wsel_push_mask(w, hm, hit, f32_sortable(v), 0xffffffffu - (i0 + (uint32_t)e));                      \
+			if (hm == 0ull) break;                                                                                              \
+			const int e = hit ? __builtin_ctz(pmask) : 0;                                                                       \
+			wsel_push_mask(w, hm, hit, f32_sortable(vec_elem_f32_dyn<T>(sv, e)), 0xffffffffu - (i0 + (uint32_t)e));             \
+			pmask &= pmask - 1u;                                                                                                \
 		}                                                                                                                       \
 		scnt = 0;                                                                                                               \
 		__builtin_amdgcn_wave_barrier();                                                                                        \

@@ -683,14 +683,20 @@ __global__ __launch_bounds__(256) void overlap_wave_kernel(const int32_t *__rest
 		bv[e] = j < lb ? b[q * lb + j] : -2;
 		pos[e] = 0x7fffffff;
 	}
+	// position of every a-element in b.  Round 5: b's elements from the LAST to the first, each broadcast as a scalar and compared against the
+	// lanes' a-elements with a compare that yields a lane mask -- a set bit is one v_writelane (the earliest position is written last, so it
+	// stays); the version before kept a running minimum in every lane: two compares, two conditional moves per element and list half.
 #pragma unroll
-	for (int e = 0; e < 2; ++e) {
+	for (int e = 1; e >= 0; --e) {
 		const int lim = min(WAVE, lb - e * WAVE);
-		for (int t = 0; t < lim; ++t) {
+		for (int t = lim - 1; t >= 0; --t) {
 			const int32_t x = __builtin_amdgcn_readlane(bv[e], t);
 			const int p = e * WAVE + t;
-			if (av[0] == x && p < pos[0]) pos[0] = p;
-			if (av[1] == x && p < pos[1]) pos[1] = p;
+			const unsigned long long m0 = __ballot(av[0] == x), m1 = __ballot(av[1] == x);
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (m0 != 0ull) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pos[0]) : "s"(p), "s"((int)__builtin_ctzll(m0)) : "m0");   // (more than one lane: a's -1 padding, never counted)
+			if (m1 != 0ull) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pos[1]) : "s"(p), "s"((int)__builtin_ctzll(m1)) : "m0");
+#endif
 		}
 	}
 	for (int p = 0; p < n_pairs; ++p) {

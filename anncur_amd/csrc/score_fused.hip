@@ -35,6 +35,13 @@
 #else
 #define ANNCUR_PAD_HERE() do { } while (0)
 #endif
+// Tuning knobs (ANNCUR_DEBUG_* environment variables) exist in the experiments library only (`make experiments`, -DANNCUR_TIMING_EXPERIMENTS):
+// the product library reads no environment -- knob() is the constant nullptr there and every `if (const char *dbg = knob(...))` folds away.
+#ifdef ANNCUR_TIMING_EXPERIMENTS
+static inline const char *knob(const char *name) { return getenv(name); }
+#else
+static inline const char *knob(const char *) { return nullptr; }
+#endif
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 __device__ unsigned long long *d_sweep_stamps = nullptr;  // diagnostic build: {d s_memtime, d s_memrealtime} of the sweep's tile loop per workgroup
 __device__ unsigned long long *d_sel_stamps = nullptr;  // diagnostic build: phase stamps of the wave-level select kernels (4 per workgroup)
@@ -1647,9 +1654,7 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 	// 0.453 at 0.26, 0.450 at 0.22, 0.453 at 0.18, 0.461 at 0.14 -> 0.63 of the model's fraction.
 	if (P.n_stages == 2) {
 		double shrink = P.body16 ? 0.63 : (k <= WSEL_K ? 1.0 : 0.6);
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-		if (const char *dbg = getenv("ANNCUR_DEBUG_F1_SHRINK")) shrink = atof(dbg);
-#endif
+		if (const char *dbg = knob("ANNCUR_DEBUG_F1_SHRINK")) shrink = atof(dbg);
 		const double f1 = frac[0] * shrink;
 		frac[0] = f1 > fmin ? f1 : (fmin < frac[0] ? fmin : frac[0]);
 	}
@@ -1681,9 +1686,7 @@ void plan_stages(FusedPlan &P, int64_t Q, int k, double exp_hits, bool staged, d
 		// 0.84 vs 0.88; I = 10^6, Kp = 256 (P ~ 0.2 over most of the sweep) 2.80 vs 2.76 -> exec above P = 0.25.
 		// (staggered Kp <= 256 loop only: launch_fused ignores it elsewhere)
 		P.stage_pred[i] = (1.0 - exp(-4.0 * rate)) > 0.25 ? 1 : 0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-		if (const char *dbg = getenv("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = atoi(dbg) != 0;
-#endif
+		if (const char *dbg = knob("ANNCUR_DEBUG_ALL_PRED")) P.stage_pred[i] = atoi(dbg) != 0;
 		// next stage: threshold = k-th best of the fraction seen so far
 		rate = (double)k / ((double)end * unit_items) * 16.0 * 1.2;
 		prev = end;
@@ -1709,9 +1712,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.n_full = (int)(I / TILE_I);
 	// prepass sample: enough groups that the k-th largest group maximum is a tight bound
 	int target = (4 * k > 512) ? 4 * k : 512;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_SAMPLE_GROUPS")) target = atoi(dbg);   // prepass sample size in groups (tuning knob)
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_SAMPLE_GROUPS")) target = atoi(dbg);   // prepass sample size in groups (tuning knob)
 	int n_st16 = (target + 1) / 2;
 	if ((int64_t)n_st16 * 8 <= P.n_full) { P.group = 16; P.n_st = n_st16; }
 	else { P.group = 4; P.n_st = (target + 7) / 8; }
@@ -1719,27 +1720,19 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	P.n_groups = P.n_st * (P.group == 16 ? 2 : 8);
 	if (P.n_groups < k) return P;
 	int slots = ((P.QT == 1 && KP <= 256) ? 3 : 2) * num_cu();
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_ONE_WG")) slots = num_cu();  // one sweep workgroup per CU (co-residence experiment)
-#endif
+	if (knob("ANNCUR_DEBUG_ONE_WG")) slots = num_cu();  // one sweep workgroup per CU (co-residence experiment)
 	// Dynamic tile schedule (staggered 32x32x16 sweep, Kp <= 256): tickets of CHUNK_TILES tiles per query row block instead of fixed shares
 	// (score_kernel).  Workgroups per row block: enough to fill every slot (rounded UP -- a workgroup that finds no ticket left ends at
 	// once), at most 32 so that the 2 S segments of a query fit the wave-level select.
 	// Kp = 512: the body with the wave-level queue (score_q1.hpp: queue + counters + ticket words fit the 16 KB the rings took) unless
 	// ANNCUR_TOPK_MFMA32 asks for the per-lane-ring body (static shares: no LDS left for its ticket words) or I >= 2^26
 	P.bodyq1 = KP == 512 && !mfma32 && I < (int64_t)(1 << 26);
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_NO_Q1")) P.bodyq1 = false;
-#endif
+	if (knob("ANNCUR_DEBUG_NO_Q1")) P.bodyq1 = false;
 	P.bodyq16 = P.bodyq1;   // (16x16x32 MFMAs: cfg4 per-GPU shape, one box, alternating: sweep launches 5.21 -> 5.02 ms, step 7.19 -> 7.00; scoreq1_kernel stays for A/B)
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_Q16")) P.bodyq16 = P.bodyq1 && atoi(dbg) != 0;
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_Q16")) P.bodyq16 = P.bodyq1 && atoi(dbg) != 0;
 	const bool ticketed = (P.QT == 2 || P.bodyq1) && !evalf;   // the bodies with the ticket schedule
 	P.chunk = ticketed ? CHUNK_TILES : 0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_CHUNK")) P.chunk = ticketed ? atoi(dbg) : 0;
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_CHUNK")) P.chunk = ticketed ? atoi(dbg) : 0;
 	// Body of the sweep stages, decided here because the ring body changes the decomposition (512-query workgroups, one per CU)
 	const bool can16 = KP <= 256 && P.QT == 2 && I < (int64_t)(1 << 26);
 	// (default up to k = 384 since late round 4: same process, warm, round robin at cfg2 size -- k = 150: 0.733 vs 0.738 ms for the 32x32x16 body,
@@ -1751,22 +1744,16 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	constexpr int BODY16_MAX_K = 384, BODY16_MAX_K_LADDER = 1024;
 	const bool ladder_possible = !no_ladder && ticketed && P.n_groups <= 4096;
 	P.body16 = can16 && !mfma32 && !evalf && (mfma16 || k <= (ladder_possible ? BODY16_MAX_K_LADDER : BODY16_MAX_K));
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (getenv("ANNCUR_DEBUG_MFMA16") && !evalf) P.body16 = can16 && atoi(getenv("ANNCUR_DEBUG_MFMA16")) != 0;
-#endif
+	if (knob("ANNCUR_DEBUG_MFMA16") && !evalf) P.body16 = can16 && atoi(knob("ANNCUR_DEBUG_MFMA16")) != 0;
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	P.ring16 = P.body16 && k <= WSEL_K && KP >= 128 && P.chunk == CHUNK_TILES && ring;   // opt-in (ANNCUR_TOPK_RING): measured slower than the barrier body, see score16r.hpp
 #else
 	P.ring16 = false;   // (the tile-ring body is compiled into the experiments library only; the product refuses the flag: score_topk_impl)
 	(void)ring;
 #endif
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_RING16")) P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && atoi(dbg) != 0;
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_RING16")) P.ring16 = P.body16 && KP >= 128 && P.chunk == CHUNK_TILES && atoi(dbg) != 0;
 	P.wg8 = false;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_WG8")) P.wg8 = P.body16 && !P.ring16 && KP >= 128 && atoi(dbg) != 0;
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_WG8")) P.wg8 = P.body16 && !P.ring16 && KP >= 128 && atoi(dbg) != 0;
 	P.BQ_s = (P.ring16 || P.wg8) ? 512 : P.BQ;
 	P.n_rb_s = (int)ceil_div64(Q, P.BQ_s);
 	const int slots_s = (P.ring16 || P.wg8) ? num_cu() : slots;   // sweep workgroups resident at once
@@ -1798,9 +1785,7 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	int capg = next_pow2((int)(4.0 * per_seg) + 32);
 	if (capg < 64) capg = 64;
 	if (capg > 16384) capg = 16384;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_CAPG")) capg = atoi(dbg);
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_CAPG")) capg = atoi(dbg);
 	P.capg = capg;
 	// queue window: keep the expected hits per (lane, sub-tile) window near 0.5 so that 8 slots overflow with p ~ 1e-9
 	const double per_lane_tile = exp_hits / ((double)P.n_tiles * 2.0);  // hits per query-half per tile
@@ -1810,14 +1795,10 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 	// runs unstaged.  The ladder's top level = the sample's group maximum of rank k2 ~ where the k-th best of ALL items is expected to fall among
 	// the sample's (k x sample items / I; the norm-ordered leading sample holds about twice its share of the high scorers), at least 3, at most k / 2.
 	P.ladder = P.body16 && !P.ring16 && !P.wg8 && !no_ladder && P.n_groups <= 4096 && P.chunk > 0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_LADDER")) P.ladder = P.ladder && atoi(dbg) != 0;
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_LADDER")) P.ladder = P.ladder && atoi(dbg) != 0;
 	{
 		double r = (double)k * ((double)P.n_st * TILE_I / (double)I) * (leading ? 2.0 : 1.25);
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-		if (const char *dbg = getenv("ANNCUR_DEBUG_LADDER_K2")) r = atof(dbg);
-#endif
+		if (const char *dbg = knob("ANNCUR_DEBUG_LADDER_K2")) r = atof(dbg);
 		int k2 = (int)(r + 0.5);
 		if (k2 > k / 2) k2 = k / 2;
 		if (k2 < 3) k2 = 3;
@@ -1848,17 +1829,13 @@ FusedPlan plan_fused(int64_t Q, int64_t I, int KP, int k, bool leading = false, 
 
 // contiguous item ranges per split instead of interleaved tiles (timing experiment)
 bool contiguous_splits() {
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_CONTIG")) return atoi(dbg) != 0;
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_CONTIG")) return atoi(dbg) != 0;
 	return false;
 }
 
 // k <= 128: which wave-level candidate select runs (the buffer-and-compact one or the streaming one)
 bool stream_select_small() {
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_STREAM128")) return atoi(dbg) != 0;
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_STREAM128")) return atoi(dbg) != 0;
 	return false;
 }
 
@@ -2060,15 +2037,11 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 	p.chunk_tiles = 0; p.n_chunks = 0; p.chunk_ctr = nullptr; p.chunk_owner = nullptr;
 	p.nfb = (uint32_t *)ws;
 	p.ring_stagger = 0; p.ring_spin_sleep = 1;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_RING_STAGGER")) p.ring_stagger = atoi(dbg);
-	if (const char *dbg = getenv("ANNCUR_DEBUG_RING_SLEEP")) p.ring_spin_sleep = atoi(dbg);
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_RING_STAGGER")) p.ring_stagger = atoi(dbg);
+	if (const char *dbg = knob("ANNCUR_DEBUG_RING_SLEEP")) p.ring_spin_sleep = atoi(dbg);
 	p.nseg = P.lg * P.S;
 	p.prio_mode = 0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_PRIO")) p.prio_mode = atoi(dbg);
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_PRIO")) p.prio_mode = atoi(dbg);
 	p.ladder_on = P.ladder ? 1 : 0; p.ladder_k = (uint32_t)k; p.ladder_mask = (uint32_t)(LADDER_PERIOD - 1);
 #ifdef ANNCUR_TIMING_EXPERIMENTS
 	if (const char *dbg = getenv("ANNCUR_DEBUG_LADDER_PERIOD")) { int v = atoi(dbg); if (v >= 1 && (v & (v - 1)) == 0) p.ladder_mask = (uint32_t)(v - 1); }
@@ -2130,18 +2103,14 @@ int launch_fused(const FusedPlan &P, const void *X, int64_t ldx, const void *Et,
 			// (row-block-major work ids -- the workgroups of a row block on ONE XCD -- were measured for the ticket schedule, round 3, one box:
 			//  cfg4 shape sweep 5.13 -> 6.28 ms and L2-miss traffic 9.0 -> 13.0 GB per launch, cfg2 0.451 -> 0.480 ms: split-major stays)
 			p.rb_major = 0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-			if (const char *dbg = getenv("ANNCUR_DEBUG_RB_MAJOR")) p.rb_major = atoi(dbg);
-#endif
+			if (const char *dbg = knob("ANNCUR_DEBUG_RB_MAJOR")) p.rb_major = atoi(dbg);
 			p.chunk_tiles = chunk; p.n_chunks = (p.tile_end - p.tile_begin + chunk - 1) / chunk;
 			// XCD-sliced tickets: the wave-queue bodies (Kp = 512: the shape whose sweep was close to the fabric's bandwidth; Kp <= 256: traffic only); [row block][slice] counters
 			// (Kp <= 256: measured at cfg2, one process, interleaved -- sweep launches 0.5030 ms sliced vs 0.4914 unsliced, bare loops level:
 			//  there the fabric is nowhere near its limit and the steals' blocking atomics cost more than the traffic they save (328 -> 180 MB
 			//  per launch); the score16 body keeps the code path (ANNCUR_DEBUG_SLICED=2 in the experiments build) but runs unsliced)
 			p.sliced = (P.bodyq1 || P.bodyq16) ? 1 : 0;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-			if (const char *dbg = getenv("ANNCUR_DEBUG_SLICED")) p.sliced = (atoi(dbg) == 2 && P.body16 && !P.ring16) ? 1 : (p.sliced && atoi(dbg) != 0);
-#endif
+			if (const char *dbg = knob("ANNCUR_DEBUG_SLICED")) p.sliced = (atoi(dbg) == 2 && P.body16 && !P.ring16) ? 1 : (p.sliced && atoi(dbg) != 0);
 			p.chunks_per_slice = (p.n_chunks + N_SLICES - 1) / N_SLICES;
 			p.chunk_ctr = (uint32_t *)(ws + P.off_ctr) + (size_t)stg * P.n_rb * N_SLICES;
 			p.chunk_owner = (uint8_t *)(ws + P.off_owner) + (size_t)stg * owner_stride;
@@ -2663,9 +2632,7 @@ extern "C" int anncur_approx_error_packed(const void *X, int64_t ldx, const void
 	p.tiles_per_split = (p.n_tiles + S - 1) / S;
 	S = (p.n_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
 	p.n_wg = n_rb * S;
-#ifdef ANNCUR_TIMING_EXPERIMENTS
-	if (const char *dbg = getenv("ANNCUR_DEBUG_ERR_MODE")) p.ring_stagger = atoi(dbg);
-#endif
+	if (const char *dbg = knob("ANNCUR_DEBUG_ERR_MODE")) p.ring_stagger = atoi(dbg);
 #define LAUNCH_ERR(KPV, TA)                                                                                                   \
 	hipLaunchKernelGGL((error_kernel<KPV, TA>), dim3(p.n_wg), dim3(256), 2 * FusedCfg<KPV>::TILE_BYTES, st, p, (const TA *)A, lda, err_sq, norm_sq)
 #define LAUNCH_ERR_K(TA)                                                                                                      \

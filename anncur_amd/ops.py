@@ -718,13 +718,20 @@ def rerank(A, approx_idx, k_retvr, k_out):
 
 
 @_on_device
-def overlap_counts(a, b, pairs):
-	"""common[p, q] = |set(a[q, :ka_p]) & set(b[q, :kb_p])| for pairs = [(ka, kb), ...] -> int32 [n_pairs, Q]."""
+def overlap_counts(a, b, pairs, mapped_host_out=None):
+	"""common[p, q] = |set(a[q, :ka_p]) & set(b[q, :kb_p])| for pairs = [(ka, kb), ...] -> int32 [n_pairs, Q].
+	mapped_host_out: a contiguous PINNED host tensor int32 [n_pairs, Q] (mapped into the device address space by the HIP runtime): the kernel writes
+	the counts there itself -- no device buffer, no copy launch (graph-capturable; the caller synchronises before reading it)."""
 	_dev(a, b)
 	a = a.to(torch.int32).contiguous()
 	b = b.to(torch.int32).contiguous()
 	Q = a.shape[0]
-	out = torch.empty((len(pairs), Q), dtype=torch.int32, device=a.device)
+	if mapped_host_out is not None:
+		out = mapped_host_out
+		if out.is_cuda or not out.is_pinned() or not out.is_contiguous() or out.dtype != torch.int32 or tuple(out.shape) != (len(pairs), Q):
+			raise ValueError("overlap_counts: mapped_host_out must be a contiguous pinned int32 host tensor [n_pairs, Q]")
+	else:
+		out = torch.empty((len(pairs), Q), dtype=torch.int32, device=a.device)
 	lib = _lib.load()
 	for s in range(0, len(pairs), 64):
 		chunk = pairs[s:s + 64]

@@ -483,7 +483,8 @@ def run_config(args, cfg_name, ctx, light=False):
 			def piece_retr(slot):
 				state[slot]["approx"] = (ops.score_topk_fused(state[slot]["Xq"], cur._Etp_sorted, I, kr, leading_sample=True, item_ids=cur._item_ids, staged=args.sweep_staged, workspace=wss[slot])
 										 if fold else retrieve(wss[slot]))
-			def piece_tail(slot): ops.copy_to_mapped_host(ops.overlap_counts(state[slot]["exact"].indices, state[slot]["approx"].indices, cells), pinned[slot])
+			# (the counts go straight into the mapped pinned buffer: the copy launch that followed the overlap kernel until late round 5 was 5.5 us of every step)
+			def piece_tail(slot): ops.overlap_counts(state[slot]["exact"].indices, state[slot]["approx"].indices, cells, mapped_host_out=pinned[slot])
 			fns = (piece_scan, piece_retr, piece_tail)
 			def stream_of(j, slot): return s_st if j == 0 else mains[slot]
 			for slot in range(2):   # workspaces / code objects loaded outside capture

@@ -1,3 +1,5 @@
+# Round 5 (GPU box): kernel timeline of bench.py's steps under rocprofv3.  --scan-mode side and --no-graph: rocprofv3 dies in its finaliser (SIGSEGV in
+# __cxa_finalize, no output written) when the process has created a CU-masked stream (hipExtStreamCreateWithCUMask), with or without graphs.
 set -e
 mkdir -p gpurun_out/r5_timeline
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -375,6 +375,8 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	const uint32_t tie_limit = k + (trig - k) / 2;  // ties at the k-th score are kept while they fit below
 	u32x4 *stage_vec = reinterpret_cast<u32x4 *>(w.sort_buf);
 	uint32_t *stage_idx = w.hist;
+	const uint32_t stage_vec_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)stage_vec;   // LDS byte addresses of the staging area
+	const uint32_t stage_idx_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)stage_idx;
 	uint32_t scnt = 0;  // staged vectors (wave-uniform)
 	// (Round 4, measured and dropped: a threshold-only refresh -- the k-th select without the pass that rewrites the buffer -- every 16 / 32 / 50 /
 	//  64 / 100 candidates, compaction only when the buffer runs out of room at 512: 0.578 -> 0.674 / 0.664 / 0.631 / 0.599 / 0.594 ms on 96 CUs,
@@ -441,8 +443,9 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 			if (scnt + np > (uint32_t)WAVE) SCAN_DRAIN()                                                                        \
 			if (pass) {                                                                                                         \
 				const uint32_t pos = scnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u)); \
-				stage_vec[pos] = cur;                                                                                           \
-				stage_idx[pos] = (uint32_t)(head + ((s0 + (d)) * WAVE + lane) * VEC);                                           \
+				/* (explicit 32-bit LDS addresses: hipcc derived the second address from the first with a 64-bit multiply-add, a quarter-rate instruction) */ \
+				*reinterpret_cast<__attribute__((address_space(3))) u32x4 *>((uintptr_t)(stage_vec_lds + pos * 16u)) = cur;            \
+				*reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(stage_idx_lds + pos * 4u)) = (uint32_t)(head + ((s0 + (d)) * WAVE + lane) * VEC); \
 			}                                                                                                                   \
 			scnt += np;                                                                                                         \
 		}                                                                                                                       \

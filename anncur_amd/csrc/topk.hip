@@ -299,7 +299,7 @@ struct ScanGather {
 	int64_t ldo;
 };
 // RAGGED (round 5, the IVF search's packed score rows): row q holds row_len[q] elements (k <= row_len[q] <= I_all, the caller's contract).
-template <typename T, bool GATHER = false, bool BUF = true, bool RAGGED = false>
+template <typename T, bool GATHER = false, bool BUF = true, bool RAGGED = false, int E = 2>   // E: keys per lane of the final sort (k <= 64 E; E = 1 from the ragged entry only)
 __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restrict__ A, int64_t Q, int64_t I_all, int64_t lda, uint32_t k,
 																 uint32_t trig, float *__restrict__ out_val, int32_t *__restrict__ out_idx,
 																 const ScanGather gt = ScanGather{}, const int32_t *__restrict__ row_len = nullptr) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 			if ((int64_t)c >= tail0 && (int64_t)c < I) cqrow[j] = row[c];
 		}
 	}
-	wsel_finish<WS_CAP, HP>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k, nullptr, wsel_base16(w.tau));
+	wsel_finish<WS_CAP, HP, E>(w, k, out_val + q * (int64_t)k, out_idx + q * (int64_t)k, nullptr, wsel_base16(w.tau));
 }
 
 // SHORT rows (round 5: I <= WS_CAP = 1024 -- the IVF probe's [queries x nlist] centroid scores, the k-means assignment, small matrices): the
@@ -914,13 +914,15 @@ extern "C" int anncur_rowwise_topk_ragged(const void *A, int dtype, int64_t Q, i
 	const unsigned grid = (unsigned)ceil_div64(Q, 4);
 	const uint32_t trig = ws_trigger((uint32_t)k);
 	const bool buf = I_max * (int64_t)dtype_size(dtype) < ((int64_t)1 << 31);
+#define LAUNCH_RAGGED(T, B, EE) hipLaunchKernelGGL((rowwise_topk_wave_kernel<T, false, B, true, EE>), dim3(grid), dim3(256), lds, st, (const T *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len)
 	if (dtype == ANNCUR_F32) {
-		if (buf) hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, true, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
-		else hipLaunchKernelGGL((rowwise_topk_wave_kernel<float, false, false, true>), dim3(grid), dim3(256), lds, st, (const float *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
+		if (k <= 64) { if (buf) LAUNCH_RAGGED(float, true, 1); else LAUNCH_RAGGED(float, false, 1); }
+		else { if (buf) LAUNCH_RAGGED(float, true, 2); else LAUNCH_RAGGED(float, false, 2); }
 	} else {
-		if (buf) hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, false, true, true>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
-		else hipLaunchKernelGGL((rowwise_topk_wave_kernel<uint16_t, false, false, true>), dim3(grid), dim3(256), lds, st, (const uint16_t *)A, Q, I_max, lda, (uint32_t)k, trig, out_val, out_idx, ScanGather{}, row_len);
+		if (k <= 64) { if (buf) LAUNCH_RAGGED(uint16_t, true, 1); else LAUNCH_RAGGED(uint16_t, false, 1); }
+		else { if (buf) LAUNCH_RAGGED(uint16_t, true, 2); else LAUNCH_RAGGED(uint16_t, false, 2); }
 	}
+#undef LAUNCH_RAGGED
 	ANNCUR_LAUNCH_OK();
 	return ANNCUR_OK;
 }

@@ -268,7 +268,9 @@ __device__ __forceinline__ void wsel_compact(WaveSel &w, uint32_t k, uint32_t ti
 	if constexpr (KEEP_TIES) {
 		// mid-stream: the threshold an in-order stream needs is the k-th SCORE, and that is T itself -- a key that ties with it is always kept,
 		// so the smallest kept key's score bits are T (round 5: two wave reductions over the kept keys found the same value)
-		w.tau_hi = T;
+		// (T carries the significant key bits only: the full key of a NEGATIVE bf16 score has its low bits set -- left clear, the threshold would sit a
+		//  few fp32 ulps below the k-th score and every later element that ties with it would pass the stream's strict compare)
+		w.tau_hi = (HI_PASSES < 4 && T < 0x80000000u) ? (T | ~M) : T;
 		w.tau_lo = Tlo;
 	} else {
 		// smallest kept key = smallest hi, then the smallest lo among the lanes that hold it (two DPP reductions, no shuffles)

@@ -15,6 +15,8 @@ def main():
 	_, A = bench.synth_device(cfg, dev, 0, row_seed=None)
 	Q, I = A.shape
 	datas = {"bench (low rank + noise)": A, "iid gaussian": torch.randn(Q, I, device=dev).to(torch.bfloat16), "constant": torch.full((Q, I), 0.5, device=dev, dtype=torch.bfloat16),
+			 "negative constant (every element ties with the threshold)": torch.full((Q, I), -0.5, device=dev, dtype=torch.bfloat16),
+			 "negative, few distinct values": (-(torch.randint(1, 40, (Q, I), device=dev).float()) / 8).to(torch.bfloat16),
 			 "ascending (every step passes)": torch.arange(I, device=dev, dtype=torch.float32).mul_(1e-3).to(torch.bfloat16).repeat(Q, 1)}
 	streams = [("256 CUs", torch.cuda.Stream(device=dev), 256)] + [(f"{n} CUs", masked_stream(0, n), n) for n in (128, 96, 64)]
 	ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

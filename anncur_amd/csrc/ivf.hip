@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void ivf_map_ids_kernel(const int32_t *__restr
 #define IVF_PAD_HERE() do { } while (0)
 #endif
 constexpr int IVF_MAX_NLIST_LDS = 8192;   // 2 x nlist words of LDS in the sort kernels
+constexpr uint32_t IVF_NO_SLOT = 0xffffffffu;   // coff of a (query, probe slot) pair that takes no part in the search
 constexpr int IVF_RAGGED_MAX_K = 128;    // anncur_rowwise_topk_ragged: the wave-per-row scan (WSEL_K of wave_select.hpp)
 
 __device__ __forceinline__ int ivf_xcd_remap(int b, int n) {   // work ids of one XCD contiguous (blocks b and b + 8 share an XCD); a bijection on [0, n)
@@ -374,11 +375,16 @@ __global__ __launch_bounds__(256) void ivf_layout_kernel(const int32_t *__restri
 		uint32_t run = 0;
 		for (int s = 0; s < nprobe; ++s) {
 			const int32_t l = probe[q * nprobe + s];
-			coff[q * nprobe + s] = run;
+			uint32_t at = IVF_NO_SLOT;   // a slot that is skipped: list id out of range, or the list does not fit the row any more (a pitch below the contract)
 			if (l >= 0 && l < nlist) {
-				run += (uint32_t)(offsets[l + 1] - offsets[l]);
-				atomicAdd(&ivf_hist[l], 1u);
+				const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+				if ((uint64_t)run + size <= (uint64_t)pitch) {
+					at = run;
+					run += size;
+					atomicAdd(&ivf_hist[l], 1u);
+				}
 			}
+			coff[q * nprobe + s] = at;
 		}
 		for (uint32_t c = run; c < (uint32_t)k; ++c) S[q * pitch + c] = -INFINITY;   // fewer than k vectors in the probed lists
 		row_len[q] = (int32_t)(run > (uint32_t)k ? run : (uint32_t)k);
@@ -430,10 +436,8 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int32_t *__restr
 	__syncthreads();
 	const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (q < nq)
-		for (int s = 0; s < nprobe; ++s) {
-			const int32_t l = probe[q * nprobe + s];
-			if (l >= 0 && l < nlist) atomicAdd(&ivf_hist[l], 1u);
-		}
+		for (int s = 0; s < nprobe; ++s)
+			if (coff[q * nprobe + s] != IVF_NO_SLOT) atomicAdd(&ivf_hist[probe[q * nprobe + s]], 1u);   // (a slot with an offset has a valid list id: ivf_layout_kernel)
 	__syncthreads();
 	for (int i = threadIdx.x; i < nlist; i += 256) {
 		const uint32_t c = ivf_hist[i];
@@ -443,11 +447,12 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const int32_t *__restr
 	__syncthreads();
 	if (q < nq)
 		for (int s = 0; s < nprobe; ++s) {
-			const int32_t l = probe[q * nprobe + s];
-			if (l >= 0 && l < nlist) {
+			const uint32_t at = coff[q * nprobe + s];
+			if (at != IVF_NO_SLOT) {
+				const int32_t l = probe[q * nprobe + s];
 				const uint32_t pos = base[l] + atomicAdd(&ivf_hist[l], 1u);
 				pair_q[pos] = (int32_t)q;
-				pair_out[pos] = (uint32_t)(q * pitch) + coff[q * nprobe + s];
+				pair_out[pos] = (uint32_t)(q * pitch) + at;
 			}
 		}
 }
@@ -465,7 +470,7 @@ __device__ __forceinline__ void ivf_find_tile(const int32_t *__restrict__ tile_s
 	qt = within / vcnt; vt = within - qt * vcnt;
 }
 
-// The round-3/4 tile kernels (64 x 64; fp32 lists, and bf16 rows whose length is not a multiple of 64) on the packed layout.
+// The round-3/4 tile kernels (64 x 64; fp32 lists, and bf16 rows whose length is not a multiple of 128) on the packed layout.
 template <typename T>
 __global__ __launch_bounds__(256) void ivf_tile64_packed_kernel(const T *__restrict__ Xs, int64_t ldx, int32_t dp, const int32_t *__restrict__ offsets,
 																 const T *__restrict__ Q, int64_t ldq, const int32_t *__restrict__ pair_q,
@@ -809,9 +814,10 @@ __global__ __launch_bounds__(256) void ivf_map_ids_packed_kernel(const int32_t *
 	if (c >= 0 && val[i] > -INFINITY) {
 		const int64_t q = i / k;
 		for (int s = 0; s < nprobe; ++s) {
+			const uint32_t co = coff[q * nprobe + s];
+			if (co == IVF_NO_SLOT) continue;
 			const int32_t l = probe[q * nprobe + s];
-			if (l < 0 || l >= nlist) continue;
-			const uint32_t co = coff[q * nprobe + s], sz = (uint32_t)(offsets[l + 1] - offsets[l]);
+			const uint32_t sz = (uint32_t)(offsets[l + 1] - offsets[l]);
 			if ((uint32_t)c >= co && (uint32_t)c < co + sz) { id = ids[offsets[l] + (int32_t)((uint32_t)c - co)]; break; }
 		}
 	}

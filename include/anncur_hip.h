@@ -336,7 +336,8 @@ int anncur_ivf_map_ids(const int32_t *col, const float *val, int64_t nq, int32_t
  * of 128: 128 x 128 tiles, v_mfma_f32_32x32x16_bf16; fp32 rows or other bf16 row lengths: the 64 x 64 tiles of anncur_ivf_group_scores),
  * scores written to PACKED rows -- S float[nq x pitch], 16-byte aligned, query q's probed lists back to back, nothing pre-filled -- and
  * scanned by anncur_rowwise_topk_ragged.  Xs / Q as for anncur_ivf_group_scores(_bf16) (dtype selects fp32 or bf16 rows for BOTH).
- * pitch >= max(k, longest packed row) -- nprobe x longest list always suffices -- a multiple of 4, nq x pitch < 2^32 (split the queries).
+ * pitch >= max(k, longest packed row) -- nprobe x longest list always suffices -- a multiple of 4, nq x pitch < 2^32 (split the queries); a
+ * probed list that no longer fits a query's row is left out of that query's search (a pitch below the contract loses candidates, never memory).
  * max_tiles: any upper bound on sum_l ceil(pairs_l / T) ceil(size_l / T), T = anncur_ivf_search_tile(...) (the launch's grid: workgroups
  * past the last tile exit), e.g. (nq nprobe / T) max_l ceil(size_l / T) + sum_l ceil(size_l / T).  k <= 128 and nlist <= 8192
  * (ANNCUR_E_UNSUPPORTED otherwise: the calls above).  Workspace: anncur_ivf_search_workspace_bytes, 256-byte aligned. */

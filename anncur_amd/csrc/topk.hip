@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void rowwise_topk_wave_kernel(const T *__restr
 	const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	const int64_t q = (int64_t)blockIdx.x * 4 + wave;
 	if (q >= Q) return;
-	const int64_t I = RAGGED ? (int64_t)__builtin_amdgcn_readfirstlane(row_len[q]) : I_all;
+	const int64_t I = RAGGED ? min((int64_t)max(__builtin_amdgcn_readfirstlane(row_len[q]), 0), I_all) : I_all;   // (a length outside 0..I_all is clamped: no read past the row)
 	// (A start stagger -- the workgroups resident at launch sleeping hashed offsets of up to 8..48 us so that the select phases of a CU's waves
 	//  do not coincide -- was measured in round 4 and dropped: 0.580 -> 0.589..0.621 ms on 96 CUs, 0.330 -> 0.337..0.340 on the chip.  The
 	//  phases are not what holds a part of the chip at 35 GB/s per CU: see DESIGN.md 4.4, 'what bounds the scan on part of the chip'.)

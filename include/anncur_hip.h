@@ -155,7 +155,7 @@ int anncur_rowwise_topk(const void *A, int dtype, int64_t Q, int64_t I, int64_t 
                         float *out_val, int32_t *out_idx, void *stream);
 
 /* The same scan over RAGGED rows (round 5; the batched IVF search's packed score rows): row q of A holds row_len[q] elements,
- * k <= row_len[q] <= I_max <= lda (the caller's contract; not checked on the device).  k <= 128 (ANNCUR_E_UNSUPPORTED above). */
+ * k <= row_len[q] <= I_max <= lda (a length outside 0..I_max is clamped; a row shorter than k is padded with (-inf, -1)).  k <= 128 (ANNCUR_E_UNSUPPORTED above). */
 int anncur_rowwise_topk_ragged(const void *A, int dtype, int64_t Q, int64_t I_max, int64_t lda, const int32_t *row_len, int32_t k,
                                float *out_val, int32_t *out_idx, void *stream);
 

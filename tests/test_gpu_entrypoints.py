@@ -434,14 +434,18 @@ def test_ivf_search_grouped_direct_call_ragged_rows_and_bad_arguments(gpu):
 	# the ragged scan alone against torch.topk of every row's prefix
 	A = torch.randn(37, 5000, device=gpu)
 	rl = torch.tensor(g.integers(64, 5001, 37).astype(np.int32), device=gpu); rl[0] = 64; rl[1] = 5000
+	rl[2] = 10; rl[3] = 0; rl[4] = 6000                            # shorter than k (padded), empty, beyond the matrix (clamped to its width)
 	r = ops.rowwise_topk_ragged(A, rl, 64)
 	for j in range(37):
-		w = torch.topk(A[j, :int(rl[j])], 64)
-		assert torch.equal(r.values[j], w.values) and torch.equal(r.indices[j].long(), w.indices)
+		n = min(int(rl[j]), A.shape[1]); m = min(n, 64)
+		w = torch.topk(A[j, :n], m)
+		assert torch.equal(r.values[j, :m], w.values) and torch.equal(r.indices[j, :m].long(), w.indices)
+		assert (r.values[j, m:] == -float("inf")).all() and (r.indices[j, m:] == -1).all()
 	Ab = A.bfloat16()
 	rb = ops.rowwise_topk_ragged(Ab, rl, 10)
 	for j in range(37):
-		assert torch.equal(rb.values[j], torch.topk(Ab[j, :int(rl[j])].float(), 10).values)
+		n = min(int(rl[j]), A.shape[1]); m = min(n, 10)
+		assert torch.equal(rb.values[j, :m], torch.topk(Ab[j, :n].float(), m).values)
 	with pytest.raises(_lib.AnncurHipError):
 		ops.rowwise_topk_ragged(A, rl, 129)
 	assert not ops.ivf_search_grouped_ok(129, 100) and not ops.ivf_search_grouped_ok(10, 8193)
